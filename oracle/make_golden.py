@@ -1,0 +1,477 @@
+"""Pin the oracle against the real reference and write the golden vectors.
+
+Run ONLY in the build container (``python -m oracle.make_golden`` from the repo
+root): it imports the reference's Python from /root/reference/src (which does not
+exist on the GPU box), asserts that every oracle function reproduces the reference,
+and writes small ``.npz`` fixtures under tests/golden/.  Nothing from the reference
+is copied: the fixtures are inputs and expected outputs only.
+"""
+import math
+import os
+import sys
+import types
+from unittest import mock
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import autograd
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(REPO, 'tests', 'golden')
+sys.path.insert(0, REPO)
+sys.path.insert(0, '/root/reference/src')
+
+from oracle import ops, networks, step  # noqa: E402
+
+import gan_control.models.gan_model as ref_gm  # noqa: E402
+from gan_control.trainers import utils as ref_tu  # noqa: E402
+
+
+def _import_ref_trainer():
+    """generator_trainer.py needs tensorboard/torchvision/etc.; stub those so its maths can be called."""
+    stubs = {}
+    for name in ['torch.utils.tensorboard', 'torchvision', 'torchvision.transforms', 'torchvision.utils',
+                 'gan_control.fid_utils.calc_inception', 'gan_control.losses.loss_model',
+                 'gan_control.evaluation.tracker', 'gan_control.utils.mini_batch_random_multi_split_utils']:
+        if name not in sys.modules:
+            stubs[name] = mock.MagicMock()
+    op = types.ModuleType('gan_control.models.op')
+    op.upfirdn2d = ref_gm.upfirdn2d
+    stubs['gan_control.models.op'] = op
+    with mock.patch.dict(sys.modules, stubs):
+        import gan_control.trainers.generator_trainer as gt
+        import gan_control.trainers.non_leaking as nl
+    return gt, nl
+
+
+REF_GT, REF_NL = _import_ref_trainer()
+RT = REF_GT.GeneratorTrainer
+
+
+def close(a, b, tol, what):
+    a, b = a.detach().double(), b.detach().double()
+    err = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+    assert err <= tol, f'{what}: oracle differs from reference, rel err {err:.3e} > {tol}'
+    return err
+
+
+def to_np(d):
+    return {k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v)) for k, v in d.items()}
+
+
+def grads3(fn, inputs, gen):
+    """Forward, first-order grads for a fixed cotangent, and second-order grads of <g_in0, v>."""
+    inputs = [t.clone().requires_grad_(True) for t in inputs]
+    out = fn(*inputs)
+    go = torch.randn(out.shape, generator=gen).requires_grad_(True)
+    gi = autograd.grad(out, inputs, go, create_graph=True, allow_unused=True)
+    v = torch.randn(gi[0].shape, generator=gen)
+    gg = autograd.grad((gi[0] * v).sum(), [go] + inputs, allow_unused=True)
+    rec = {'out': out, 'go': go, 'v': v}
+    for i, g in enumerate(gi):
+        if g is not None:
+            rec[f'gi{i}'] = g
+    for i, g in enumerate(gg):
+        if g is not None:
+            rec[f'gg{i}'] = g       # gg0 = d/d(go); gg{i+1} = d/d(inputs[i])
+    return rec
+
+
+# --------------------------------------------------------------------------------------
+def golden_upfirdn2d():
+    gen = torch.Generator().manual_seed(1234)
+    k4 = ref_gm.make_kernel([1, 3, 3, 1])
+    sym6 = torch.tensor(REF_NL.SYM6, dtype=torch.float32)
+    k12 = ref_gm.make_kernel(sym6)
+    krect = torch.randn(3, 5, generator=gen)
+    cases = {
+        # name: (shape, kernel, up, down, pad)   -- SURVEY 8a-1 argument sets (i)-(v) + ADA pair + edge cases
+        'i_torgb_up': ((2, 3, 8, 8), k4 * 4, 2, 1, (2, 1)),
+        'ii_g_blur': ((2, 5, 17, 17), k4 * 4, 1, 1, (1, 1)),
+        'iii_d_blur3': ((2, 4, 16, 16), k4, 1, 1, (2, 2)),
+        'iv_d_blur1': ((2, 4, 16, 16), k4, 1, 1, (1, 1)),
+        'v_down': ((2, 3, 16, 16), k4, 1, 2, (1, 1)),
+        'ada_up12': ((1, 3, 11, 9), k12 * 4, 2, 1, (2 + 5, 1 + 5)),
+        'ada_down12': ((1, 3, 40, 36), k12, 1, 2, (-5 + 2, -5 + 2)),
+        'odd_rect': ((1, 2, 7, 13), krect, 1, 1, (2, 1)),
+        'crop_neg': ((1, 2, 12, 10), k4, 1, 1, (-1, 0)),
+        'up3_down2': ((1, 1, 5, 6), k4, 3, 2, (3, 2)),
+        'wide_row': ((1, 1, 3, 300), k4, 1, 1, (2, 1)),
+        'one_pixel': ((1, 1, 1, 1), k4 * 4, 2, 1, (2, 1)),
+    }
+    out = {}
+    for name, (shape, k, up, down, pad) in cases.items():
+        x = torch.randn(*shape, generator=gen)
+        ref = ref_gm.upfirdn2d(x, k, up=up, down=down, pad=pad)
+        close(ops.upfirdn2d(x, k, up, down, pad), ref, 1e-6, f'upfirdn2d/{name}')
+        rec = grads3(lambda t: ref_gm.upfirdn2d(t, k, up=up, down=down, pad=pad), [x], gen)
+        rec_o = grads3(lambda t: ops.upfirdn2d(t, k, up, down, pad), [x], torch.Generator().manual_seed(0))
+        assert rec_o['out'].shape == rec['out'].shape
+        out.update({f'{name}/x': x, f'{name}/k': k, f'{name}/args': np.array([up, down, pad[0], pad[1]])})
+        out.update({f'{name}/{kk}': vv for kk, vv in rec.items()})
+    np.savez_compressed(os.path.join(GOLD, 'upfirdn2d.npz'), **to_np(out))
+    print('upfirdn2d: %d cases' % len(cases))
+
+
+def golden_bias_act():
+    gen = torch.Generator().manual_seed(99)
+    out = {}
+    for name, shape in {'4d': (2, 6, 5, 7), '2d': (3, 10), '4d_big': (1, 3, 33, 65)}.items():
+        x = torch.randn(*shape, generator=gen)
+        x.view(-1)[::7] = 0.0            # exercise the x + b == 0 corner
+        b = torch.randn(shape[1], generator=gen)
+        b[0] = 0.0
+        ref = ref_gm.fused_leaky_relu(x, b)
+        close(ops.fused_leaky_relu(x, b), ref, 1e-7, f'fused_leaky_relu/{name}')
+        if len(shape) == 4:
+            m = ref_gm.FusedLeakyReLU(shape[1])
+            with torch.no_grad():
+                m.bias.copy_(b)
+            close(m(x), ref, 1e-7, 'FusedLeakyReLU module')
+        rec = grads3(lambda t, bb: ref_gm.fused_leaky_relu(t, bb), [x, b], gen)
+        out.update({f'{name}/x': x, f'{name}/b': b})
+        out.update({f'{name}/{kk}': vv for kk, vv in rec.items()})
+    np.savez_compressed(os.path.join(GOLD, 'bias_act.npz'), **to_np(out))
+    print('bias_act ok')
+
+
+def golden_convs():
+    gen = torch.Generator().manual_seed(4321)
+    out = {}
+    # --- ModulatedConv2d: plain / upsample / 1x1 no-demod (ToRGB) ------------------------------
+    sdim = 16
+    for name, (b, ic, oc, k, h, demod, up) in {
+        'mod_plain': (3, 8, 6, 3, 7, True, False),
+        'mod_up': (2, 8, 6, 3, 5, True, True),
+        'mod_rgb': (2, 8, 3, 1, 6, False, False),
+        'mod_plain_wide': (2, 16, 40, 3, 12, True, False),
+        'mod_up_wide': (1, 40, 16, 3, 9, True, True),
+    }.items():
+        m = ref_gm.ModulatedConv2d(ic, oc, k, sdim, demodulate=demod, upsample=up, conv_transpose=True)
+        with torch.no_grad():
+            m.weight.copy_(torch.randn(m.weight.shape, generator=gen))
+            m.modulation.weight.copy_(torch.randn(m.modulation.weight.shape, generator=gen))
+            m.modulation.bias.copy_(1 + 0.1 * torch.randn(ic, generator=gen))
+        x = torch.randn(b, ic, h, h, generator=gen)
+        st = torch.randn(b, sdim, generator=gen)
+
+        def ref_fn(x_, st_, w_, mw_, mb_):
+            return torch.func.functional_call(m, {'weight': w_, 'modulation.weight': mw_, 'modulation.bias': mb_}, (x_, st_))
+
+        def ora_fn(x_, st_, w_, mw_, mb_):
+            return ops.modulated_conv2d(x_, st_, w_, mw_, mb_, demodulate=demod, upsample=up)
+
+        ins = [x, st, m.weight.detach(), m.modulation.weight.detach(), m.modulation.bias.detach()]
+        close(ora_fn(*ins), ref_fn(*ins), 2e-6, f'modconv/{name}')
+        rec = grads3(ref_fn, ins, gen)
+        rec_o = grads3(ora_fn, ins, torch.Generator().manual_seed(0))
+        assert set(rec) == set(rec_o)
+        for i, nm in enumerate(['x', 'style', 'weight', 'mod_weight', 'mod_bias']):
+            out[f'{name}/{nm}'] = ins[i]
+        out[f'{name}/cfg'] = np.array([int(demod), int(up), k])
+        out.update({f'{name}/{kk}': vv for kk, vv in rec.items()})
+    # --- EqualConv2d: s1 p1 / s2 p0 / 1x1 s2 / 1x1 s1 with bias ------------------------------------
+    for name, (b, ic, oc, k, h, stride, padding, bias) in {
+        'conv_s1p1': (2, 5, 7, 3, 9, 1, 1, False),
+        'conv_s2p0': (2, 5, 7, 3, 11, 2, 0, False),
+        'conv_1x1s2': (2, 6, 4, 1, 9, 2, 0, False),
+        'conv_1x1_bias': (2, 3, 8, 1, 10, 1, 0, True),
+        'conv_s1p1_wide': (1, 40, 36, 3, 20, 1, 1, False),
+        'conv_s2p0_wide': (1, 36, 40, 3, 21, 2, 0, False),
+    }.items():
+        m = ref_gm.EqualConv2d(ic, oc, k, stride=stride, padding=padding, bias=bias)
+        w = torch.randn(oc, ic, k, k, generator=gen)
+        bb = torch.randn(oc, generator=gen) if bias else None
+        x = torch.randn(b, ic, h, h, generator=gen)
+
+        def ref_fn(x_, w_, *rest):
+            p = {'weight': w_}
+            if bias:
+                p['bias'] = rest[0]
+            return torch.func.functional_call(m, p, (x_,))
+
+        def ora_fn(x_, w_, *rest):
+            return ops.equal_conv2d(x_, w_, rest[0] if bias else None, stride=stride, padding=padding)
+
+        ins = [x, w] + ([bb] if bias else [])
+        close(ora_fn(*ins), ref_fn(*ins), 2e-6, f'conv/{name}')
+        rec = grads3(ref_fn, ins, gen)
+        for i, nm in enumerate(['x', 'weight', 'bias'][:len(ins)]):
+            out[f'{name}/{nm}'] = ins[i]
+        out[f'{name}/cfg'] = np.array([stride, padding, k])
+        out.update({f'{name}/{kk}': vv for kk, vv in rec.items()})
+    np.savez_compressed(os.path.join(GOLD, 'convs.npz'), **to_np(out))
+    print('convs ok')
+
+
+def golden_misc():
+    gen = torch.Generator().manual_seed(777)
+    out = {}
+    # EqualLinear with lr_mul = 0.01 (+ fused lrelu) and plain
+    for name, (n, i, o, lr_mul, act) in {'lin_map': (4, 32, 24, 0.01, 'fused_lrelu'), 'lin_plain': (3, 20, 1, 1.0, None)}.items():
+        m = ref_gm.EqualLinear(i, o, lr_mul=lr_mul, activation=act)
+        w = torch.randn(o, i, generator=gen) / lr_mul
+        b = torch.randn(o, generator=gen)
+        x = torch.randn(n, i, generator=gen)
+        ref = torch.func.functional_call(m, {'weight': w, 'bias': b}, (x,))
+        close(ops.equal_linear(x, w, b, lr_mul=lr_mul, activation=bool(act)), ref, 1e-6, name)
+        out.update({f'{name}/x': x, f'{name}/w': w, f'{name}/b': b, f'{name}/out': ref, f'{name}/lr_mul': lr_mul})
+    # PixelNorm
+    x = torch.randn(3, 16, generator=gen)
+    close(ops.pixel_norm(x), ref_gm.PixelNorm()(x), 1e-7, 'pixel_norm')
+    out.update({'pixel_norm/x': x, 'pixel_norm/out': ref_gm.PixelNorm()(x)})
+    # minibatch stddev, via the reference's _forward_split with identity tail
+    d = ref_gm.Discriminator(8)
+    for name, b in {'mbstd8': 8, 'mbstd2': 2, 'mbstd4': 4}.items():
+        x = torch.randn(b, 16, 4, 4, generator=gen)
+        grab = {}
+        d._forward_split(x, lambda t: grab.setdefault('cat', t), lambda t: t)
+        close(ops.minibatch_stddev(x), grab['cat'], 1e-6, name)
+        out.update({f'{name}/x': x, f'{name}/out': grab['cat']})
+    # losses, checked against the reference trainer's own methods
+    rp, fp = torch.randn(6, 1, generator=gen), torch.randn(6, 1, generator=gen)
+    close(step.d_logistic_loss(rp, fp), RT.d_logistic_loss(rp, fp), 1e-7, 'd_logistic_loss')
+    close(step.g_nonsaturating_loss(fp), RT.g_nonsaturating_loss(fp), 1e-7, 'g_nonsaturating_loss')
+    g = torch.randn(4, 10, 16, generator=gen)
+    a = step.path_lengths_and_penalty(g, 0)
+    r = RT.g_path_regularize_grad(g, 0)
+    for u, v in zip(a, r):
+        close(u, v, 1e-7, 'path penalty')
+    a = step.path_lengths_and_penalty(g, torch.tensor(0.37))
+    r = RT.g_path_regularize_grad(g, torch.tensor(0.37))
+    for u, v in zip(a, r):
+        close(u, v, 1e-7, 'path penalty (warm)')
+    out.update({'loss/real_pred': rp, 'loss/fake_pred': fp, 'loss/d_logistic': RT.d_logistic_loss(rp, fp),
+                'loss/g_nonsat': RT.g_nonsaturating_loss(fp), 'loss/path_grad': g,
+                'loss/path_penalty': r[0], 'loss/path_mean': r[1], 'loss/path_lengths': r[2]})
+    # Adam hyper-parameters (generator_trainer.py:161-173)
+    hp = step.adam_hparams(0.002, 4)
+    assert abs(hp['lr'] - 0.0016) < 1e-12 and hp['betas'][0] == 0.0 and abs(hp['betas'][1] - 0.99 ** 0.8) < 1e-15
+    np.savez_compressed(os.path.join(GOLD, 'misc.npz'), **to_np(out))
+    print('misc ok')
+
+
+# --------------------------------------------------------------------------------------
+def seeded_noise(size, batch, seed):
+    """Per-layer noise maps for explicit-noise parity runs (shapes as Generator.make_noise gan_model.py:683-696)."""
+    gen = torch.Generator().manual_seed(seed)
+    log_size = int(math.log2(size))
+    maps = [torch.randn(batch, 1, 4, 4, generator=gen)]
+    for i in range(3, log_size + 1):
+        maps += [torch.randn(batch, 1, 2 ** i, 2 ** i, generator=gen) for _ in range(2)]
+    return maps
+
+
+def thumb(img, n=16):
+    return F.adaptive_avg_pool2d(img, min(n, img.shape[-1]))
+
+
+def sample_pixels(img, count=64, seed=5):
+    gen = torch.Generator().manual_seed(seed)
+    idx = torch.randint(0, img.numel(), (count,), generator=gen)
+    return idx, img.reshape(-1)[idx]
+
+
+def build_ref(size, fc_config=None):
+    g = ref_gm.Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True,
+                         split_fc=fc_config is not None, fc_config=fc_config)
+    d = ref_gm.Discriminator(size, channel_multiplier=2)
+    g_sd = networks.procedural_fill_(g.state_dict())
+    d_sd = networks.procedural_fill_(d.state_dict())
+    g.load_state_dict(g_sd)
+    d.load_state_dict(d_sd)
+    # state_dict() aliases the live parameters: hand out snapshots
+    return g, d, {k: v.clone() for k, v in g_sd.items()}, {k: v.clone() for k, v in d_sd.items()}
+
+
+def golden_networks():
+    out = {}
+    for size, batch in [(32, 4), (64, 2), (256, 2), (1024, 1)]:
+        torch.manual_seed(0)
+        g, d, g_sd, d_sd = build_ref(size)
+        gen = torch.Generator().manual_seed(1000 + size)
+        z = torch.randn(batch, 512, generator=gen)
+        noise = seeded_noise(size, batch, 2000 + size)
+        with torch.no_grad():
+            img_ref, lat_ref = g([z], noise=noise, return_latents=True)
+            logit_ref, _ = d(img_ref)
+            img_o, lat_o = networks.generator_forward(g_sd, [z], size, noise=noise)
+            logit_o = networks.discriminator_forward(d_sd, img_ref)
+        e1 = close(img_o, img_ref, 1e-4, f'G({size})')
+        e2 = close(logit_o, logit_ref, 1e-4, f'D({size})')
+        close(lat_o, lat_ref, 1e-5, f'latent({size})')
+        idx, px = sample_pixels(img_ref)
+        tag = f's{size}'
+        out.update({f'{tag}/z': z, f'{tag}/batch': batch, f'{tag}/noise_seed': 2000 + size,
+                    f'{tag}/img_mean': img_ref.mean(), f'{tag}/img_std': img_ref.std(),
+                    f'{tag}/img_absmax': img_ref.abs().max(),
+                    f'{tag}/thumb': thumb(img_ref), f'{tag}/px_idx': idx, f'{tag}/px_val': px,
+                    f'{tag}/logits': logit_ref, f'{tag}/w0': lat_ref[:, 0, :16]})
+        if size <= 64:
+            out[f'{tag}/img'] = img_ref
+        print(f'network {size}: oracle-vs-reference rel err G {e1:.2e} D {e2:.2e}; img std {img_ref.std():.3f}')
+    # split_fc mapping network (ffhq.json groups: 128 + 6 x 64)
+    from gan_control.utils.mini_batch_multi_split_utils import MiniBatchUtils
+    names = ['id', 'expression', 'orientation', 'gamma', 'age', 'hair', 'other']
+    bounds = [0, 128, 192, 256, 320, 384, 448, 512]
+    groups = {n: {'count_in_mini_bach': [2, 12], 'place_in_mini_batch': [2 * i if i else 0, 2 * i + 2 if i else 2],
+                  'place_in_latent': [bounds[i], bounds[i + 1]]} for i, n in enumerate(names)}
+    mb = MiniBatchUtils(14, groups, total_batch=14)
+    fc = mb.get_fc_config()
+    g, d, g_sd, d_sd = build_ref(32, fc_config=fc)
+    gen = torch.Generator().manual_seed(31337)
+    z = torch.randn(2, 512, generator=gen)
+    noise = seeded_noise(32, 2, 4242)
+    with torch.no_grad():
+        img_ref, _ = g([z], noise=noise)
+        fc_groups = [(n, tuple(fc.groups[n]['latent_place'])) for n in fc.in_order_group_names]
+        img_o, _ = networks.generator_forward(g_sd, [z], 32, noise=noise, fc_groups=fc_groups)
+    close(img_o, img_ref, 1e-4, 'G(32, split_fc)')
+    out.update({'split32/z': z, 'split32/noise_seed': 4242, 'split32/img': img_ref,
+                'split32/group_names': np.array([n for n, _ in fc_groups]),
+                'split32/group_bounds': np.array([b for _, b in fc_groups])})
+    # style mixing + truncation at 32
+    g, d, g_sd, d_sd = build_ref(32)
+    z2 = torch.randn(2, 512, generator=gen)
+    with torch.no_grad():
+        mean_w = g.style(torch.randn(64, 512, generator=gen)).mean(0, keepdim=True)
+        img_ref, _ = g([z, z2], noise=noise, inject_index=3, truncation=0.7, truncation_latent=mean_w)
+        img_o, _ = networks.generator_forward(g_sd, [z, z2], 32, noise=noise, inject_index=3, truncation=0.7,
+                                              truncation_latent=mean_w)
+    close(img_o, img_ref, 1e-4, 'G(32, mixing+truncation)')
+    out.update({'mix32/z': z, 'mix32/z2': z2, 'mix32/mean_w': mean_w, 'mix32/noise_seed': 4242, 'mix32/img': img_ref})
+    np.savez_compressed(os.path.join(GOLD, 'networks.npz'), **to_np(out))
+    print('networks ok')
+
+
+def golden_step():
+    """One full iteration (i = 0: D step, R1, G step, path-length, EMA) at 32x32, batch 4.
+
+    The reference side is driven with the reference's own modules, helper functions
+    (trainers/utils.py) and trainer maths (GeneratorTrainer static methods), following
+    generator_trainer.py:301-369, 407-436, 568-599, 645-711 with batch == mini_batch.
+    """
+    size, batch = 32, 4
+    g, d, g_sd, d_sd = build_ref(size)
+    g_ema = ref_gm.Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True)
+    g_ema.load_state_dict(g_sd)
+    ref_tu.accumulate(g_ema, g, 0)
+    gen = torch.Generator().manual_seed(2024)
+    real = torch.rand(batch, 3, size, size, generator=gen) * 2 - 1
+    z_d, z_g = torch.randn(batch, 512, generator=gen), torch.randn(batch, 512, generator=gen)
+    z_pl = torch.randn(batch // 2, 512, generator=gen)
+    pl_noise = torch.randn(batch // 2, 3, size, size, generator=gen)
+    noise_d, noise_g = seeded_noise(size, batch, 11), seeded_noise(size, batch, 12)
+    noise_pl = seeded_noise(size, batch // 2, 13)
+    cfg = dict(r1=1, g_reg_every=4, d_reg_every=16, lr=0.002, path_regularize=2, g_moving_average=10000)
+
+    # --- dry_run (generator_trainer.py:301-327): which parameters end up with grad None ------------
+    fake, latent = g([torch.randn(1, 512, generator=gen)], return_latents=True)
+    RT.g_path_regularize(fake, latent, 0)[0].backward()
+    none_g = sorted(n for n, p in g.named_parameters() if p.grad is None)
+    g.zero_grad()
+    t_in = torch.randn(1, 3, size, size, generator=gen).requires_grad_(True)
+    pred, _ = d(t_in)
+    RT.d_r1_loss(None, pred, t_in).backward()
+    none_d = sorted(n for n, p in d.named_parameters() if p.grad is None)
+    zero_d = sorted(n for n, p in d.named_parameters() if p.grad is not None and float(p.grad.abs().max()) == 0.0)
+    d.zero_grad()
+
+    gr, dr = cfg['g_reg_every'] / (cfg['g_reg_every'] + 1), cfg['d_reg_every'] / (cfg['d_reg_every'] + 1)
+    g_optim = torch.optim.Adam(g.parameters(), lr=cfg['lr'] * gr, betas=(0 ** gr, 0.99 ** gr))
+    d_optim = torch.optim.Adam(d.parameters(), lr=cfg['lr'] * dr, betas=(0 ** dr, 0.99 ** dr))
+    stats = {}
+    # D step
+    ref_tu.requires_grad(g, False); ref_tu.requires_grad(d, True)
+    d.zero_grad()
+    fake, _ = g([z_d], noise=noise_d)
+    fake_pred, _ = d(fake)
+    real_pred, _ = d(real)
+    d_loss = RT.d_logistic_loss(real_pred, fake_pred)
+    d_loss.div_(len(real))
+    d_loss.backward(retain_graph=True)
+    stats['d_grad_norm'] = torch.stack([p.grad.norm() for p in d.parameters()]).norm()
+    d_optim.step()
+    stats['d_loss'] = d_loss.detach()
+    stats['real_pred_d'] = real_pred.detach()
+    # R1
+    d.zero_grad()
+    real_r = real.clone().requires_grad_(True)
+    real_pred, _ = d(real_r)
+    r1 = RT.d_r1_loss(None, real_pred, real_r)
+    (cfg['r1'] / 2 * r1 * cfg['d_reg_every'] + 0 * real_pred[0]).backward()
+    ref_tu.set_grad_none(d, none_d)
+    stats['r1_grad_norm'] = torch.stack([p.grad.norm() for p in d.parameters() if p.grad is not None]).norm()
+    d_optim.step()
+    stats['d_r1_loss'] = r1.detach()
+    # G step
+    ref_tu.requires_grad(g, True); ref_tu.requires_grad(d, False)
+    g.zero_grad()
+    fake, _ = g([z_g], noise=noise_g)
+    fake_pred, _ = d(fake)
+    g_loss = RT.g_nonsaturating_loss(fake_pred)
+    g_loss.backward()
+    stats['g_grad_norm'] = torch.stack([p.grad.norm() for p in g.parameters()]).norm()
+    g_optim.step()
+    stats['g_adv_loss'] = g_loss.detach()
+    # path-length regulariser with an injected pl_noise (Generator.g_path_regularize_grad gan_model.py:803-811)
+    g.zero_grad()
+    fake, latent = g([z_pl], noise=noise_pl, return_latents=True)
+    with mock.patch.object(torch, 'randn_like', lambda t: pl_noise):
+        grad = ref_gm.Generator.g_path_regularize_grad(fake, latent)
+    path_loss, mean_path, lengths = RT.g_path_regularize_grad(grad, 0)
+    (cfg['path_regularize'] * cfg['g_reg_every'] * path_loss + 0 * fake[0, 0, 0, 0]).backward()
+    ref_tu.set_grad_none(g, none_g)
+    stats['pl_grad_norm'] = torch.stack([p.grad.norm() for p in g.parameters() if p.grad is not None]).norm()
+    g_optim.step()
+    stats.update(g_path_loss=path_loss.detach(), g_mean_path_length=mean_path, path_lengths=lengths.detach())
+    ref_tu.accumulate(g_ema, g, 0.5 ** (batch / cfg['g_moving_average']))
+
+    # --- the oracle's own step must reproduce all of it -------------------------------------------
+    o = step.OracleStep(g_sd, d_sd, size, batch, none_g=none_g, none_d=none_d)
+    o.iteration(0, real, z_d, z_g, z_pl=z_pl, noise_d=noise_d, noise_g=noise_g, noise_pl=noise_pl, pl_noise=pl_noise)
+    for k in ['d_loss', 'd_r1_loss', 'g_adv_loss', 'g_path_loss', 'g_mean_path_length']:
+        close(torch.tensor(o.stats[k]), stats[k], 2e-4, f'step/{k}')
+    close(o.stats['path_lengths'], stats['path_lengths'], 2e-4, 'step/path_lengths')
+    worst = 0.0
+    for n, p in g.named_parameters():
+        worst = max(worst, (o.g_params[n] - p).abs().max().item())
+    for n, p in d.named_parameters():
+        worst = max(worst, (o.d_params[n] - p).abs().max().item())
+    print('step: max |param_oracle - param_ref| after the iteration = %.3e' % worst)
+    assert worst < 5e-4     # Adam's first steps are +-lr regardless of gradient scale; sign flips only at ~0 grads
+
+    out = {'real': real, 'z_d': z_d, 'z_g': z_g, 'z_pl': z_pl, 'pl_noise': pl_noise,
+           'noise_seeds': np.array([11, 12, 13]), 'none_g': np.array(none_g), 'none_d': np.array(none_d),
+           'zero_d_r1': np.array(zero_d)}
+    out.update({f'stat/{k}': v for k, v in stats.items()})
+    gen2 = torch.Generator().manual_seed(8)
+    for tag, mod in (('g', g), ('d', d), ('g_ema', g_ema)):
+        names, vals = [], []
+        for n, p in mod.named_parameters():
+            idx = torch.randint(0, p.numel(), (2,), generator=gen2)
+            for j in idx.tolist():
+                names.append(f'{n}#{j}')
+                vals.append(p.detach().reshape(-1)[j])
+        out[f'param/{tag}/names'] = np.array(names)
+        out[f'param/{tag}/vals'] = torch.stack(vals)
+    np.savez_compressed(os.path.join(GOLD, 'step.npz'), **to_np(out))
+    print('step ok; none_g =', none_g, '; none_d =', none_d, '; zero-grad-under-R1 D params:', len(zero_d))
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    golden_upfirdn2d()
+    golden_bias_act()
+    golden_convs()
+    golden_misc()
+    golden_networks()
+    golden_step()
+    total = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
+    print('fixtures written to %s (%.1f KiB)' % (GOLD, total / 1024))
+
+
+if __name__ == '__main__':
+    main()
