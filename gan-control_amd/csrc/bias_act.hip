@@ -1,0 +1,203 @@
+// K2  fused (noise +) bias + leaky-ReLU * gain, its masked adjoint, and the per-channel sum that
+// yields the bias gradient.  HBM-bound: one read + one write per element (plus the noise plane,
+// which is re-read once per channel from L2).  See include/gancontrol_hip.h for the contract.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ float lrelu_gain(float v, float slope, float gain) {
+    return (v > 0.f ? v : v * slope) * gain;
+}
+
+// One (b, c) plane per blockIdx.y; float4 path when `inner` is a multiple of 4 and bases are aligned.
+template <bool VEC, bool NOISE>
+__global__ __launch_bounds__(256) void bias_act_plane_kernel(
+    const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ noise,
+    const float* __restrict__ noise_w, float* __restrict__ y, int channels, int64_t inner, float slope, float gain) {
+    const int plane = blockIdx.y;
+    const int c = plane % channels, b = plane / channels;
+    const float bv = bias ? bias[c] : 0.f;
+    const float nw = NOISE ? noise_w[0] : 0.f;
+    const float* xp = x + (size_t)plane * inner;
+    float* yp = y + (size_t)plane * inner;
+    const float* np = NOISE ? noise + (size_t)b * inner : nullptr;
+    if (VEC) {
+        const int64_t n4 = inner >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            float4 v = reinterpret_cast<const float4*>(xp)[i];
+            if (NOISE) {
+                const float4 nz = reinterpret_cast<const float4*>(np)[i];
+                v.x = fmaf(nw, nz.x, v.x); v.y = fmaf(nw, nz.y, v.y); v.z = fmaf(nw, nz.z, v.z); v.w = fmaf(nw, nz.w, v.w);
+            }
+            v.x = lrelu_gain(v.x + bv, slope, gain); v.y = lrelu_gain(v.y + bv, slope, gain);
+            v.z = lrelu_gain(v.z + bv, slope, gain); v.w = lrelu_gain(v.w + bv, slope, gain);
+            reinterpret_cast<float4*>(yp)[i] = v;
+        }
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < inner; i += (int64_t)gridDim.x * 256) {
+            float v = xp[i];
+            if (NOISE) v = fmaf(nw, np[i], v);
+            yp[i] = lrelu_gain(v + bv, slope, gain);
+        }
+    }
+}
+
+// Flat variant for small `inner` (mapping network / D head: inner = 1, and the 4x4..16x16 layers).
+template <bool NOISE>
+__global__ __launch_bounds__(256) void bias_act_flat_kernel(
+    const float* __restrict__ x, const float* __restrict__ bias, const float* __restrict__ noise,
+    const float* __restrict__ noise_w, float* __restrict__ y, int channels, int inner, int64_t total, float slope, float gain) {
+    const float nw = NOISE ? noise_w[0] : 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t plane = i / inner;
+        const int p = (int)(i - plane * inner);
+        const int c = (int)(plane % channels);
+        float v = x[i];
+        if (NOISE) v = fmaf(nw, noise[(plane / channels) * inner + p], v);
+        y[i] = lrelu_gain(v + (bias ? bias[c] : 0.f), slope, gain);
+    }
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void bias_act_bwd_kernel(
+    const float* __restrict__ dy, const float* __restrict__ yref, float* __restrict__ dx, int64_t count, float pos, float neg) {
+    if (VEC) {
+        const int64_t n4 = count >> 2;
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+            const float4 g = reinterpret_cast<const float4*>(dy)[i];
+            const float4 r = reinterpret_cast<const float4*>(yref)[i];
+            float4 o;
+            o.x = g.x * (r.x > 0.f ? pos : neg); o.y = g.y * (r.y > 0.f ? pos : neg);
+            o.z = g.z * (r.z > 0.f ? pos : neg); o.w = g.w * (r.w > 0.f ? pos : neg);
+            reinterpret_cast<float4*>(dx)[i] = o;
+        }
+        for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+            dx[i] = dy[i] * (yref[i] > 0.f ? pos : neg);
+    } else {
+        for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (int64_t)gridDim.x * 256)
+            dx[i] = dy[i] * (yref[i] > 0.f ? pos : neg);
+    }
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* lds) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) lds[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    if (threadIdx.x == 0) r = lds[0] + lds[1] + lds[2] + lds[3];
+    __syncthreads();
+    return r;
+}
+
+// stage 1: partial[c][b * chunks + j] = sum over chunk j of plane (b, c); fixed summation order
+__global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ x, float* __restrict__ partial,
+                                                          int batch, int channels, int64_t inner, int chunks, int64_t chunk_len) {
+    __shared__ float lds[4];
+    const int plane = blockIdx.y, j = blockIdx.x;
+    const int c = plane % channels, b = plane / channels;
+    const float* xp = x + (size_t)plane * inner;
+    const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
+    float acc = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += xp[i];
+    const float r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partial[((size_t)c * batch + b) * chunks + j] = r;
+}
+
+// stage 2: out[c] = sum of partial[c][0..n)
+__global__ __launch_bounds__(256) void channel_sum_stage2(const float* __restrict__ partial, float* __restrict__ out, int n) {
+    __shared__ float lds[4];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) acc += partial[(size_t)c * n + i];
+    const float r = block_sum(acc, lds);
+    if (threadIdx.x == 0) out[c] = r;
+}
+
+inline void channel_sum_plan(int64_t inner, int* chunks, int64_t* chunk_len) {
+    // 16K elements per block keeps the grid >> 256 CUs on the large layers
+    int64_t len = 16384;
+    int n = (int)gc::ceil_div64(inner, len);
+    if (n < 1) n = 1;
+    *chunks = n;
+    *chunk_len = len;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int gc_bias_act_f32(const float* x, const float* bias, const float* noise, const float* noise_w,
+                               float* y, int batch, int channels, int64_t inner, float slope, float gain, gc_stream_t stream) {
+    if (!x || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_f32: null pointer");
+    if ((noise == nullptr) != (noise_w == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_f32: noise and noise_w must both be set or both be null");
+    if (batch < 0 || channels <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_f32: bad extents");
+    if (batch == 0) return GC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const int64_t planes = (int64_t)batch * channels;
+    if (inner >= 1024 && planes <= 65535) {
+        const bool vec = (inner % 4 == 0) && aligned16(x) && aligned16(y) && (!noise || aligned16(noise));
+        const int64_t work = vec ? inner / 4 : inner;
+        dim3 grid((unsigned)std::min<int64_t>(gc::ceil_div64(work, 256 * 4), 1024), (unsigned)planes);
+#define GC_LAUNCH(V, N) hipLaunchKernelGGL((bias_act_plane_kernel<V, N>), grid, dim3(256), 0, s, x, bias, noise, noise_w, y, channels, inner, slope, gain)
+        if (vec) { if (noise) GC_LAUNCH(true, true); else GC_LAUNCH(true, false); }
+        else     { if (noise) GC_LAUNCH(false, true); else GC_LAUNCH(false, false); }
+#undef GC_LAUNCH
+        return gc::check_launch("gc_bias_act_f32(plane)");
+    }
+    if (inner > INT32_MAX) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_f32: inner too large for the flat path");
+    const int64_t total = planes * inner;
+    const int blocks = (int)std::min<int64_t>(gc::ceil_div64(total, 256), 4096);
+    if (noise)
+        hipLaunchKernelGGL(bias_act_flat_kernel<true>, dim3(blocks), dim3(256), 0, s, x, bias, noise, noise_w, y, channels, (int)inner, total, slope, gain);
+    else
+        hipLaunchKernelGGL(bias_act_flat_kernel<false>, dim3(blocks), dim3(256), 0, s, x, bias, noise, noise_w, y, channels, (int)inner, total, slope, gain);
+    return gc::check_launch("gc_bias_act_f32(flat)");
+}
+
+extern "C" int gc_bias_act_bwd_f32(const float* dy, const float* y_ref, float* dx, int64_t count,
+                                   float slope, float gain, gc_stream_t stream) {
+    if (!dy || !y_ref || !dx) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_f32: null pointer");
+    if (count < 0) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_f32: negative count");
+    if (count == 0) return GC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool vec = aligned16(dy) && aligned16(y_ref) && aligned16(dx);
+    const int64_t work = vec ? (count + 3) / 4 : count;
+    const int blocks = (int)std::min<int64_t>(gc::ceil_div64(work, 256), 8192);
+    if (vec)
+        hipLaunchKernelGGL(bias_act_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, y_ref, dx, count, gain, gain * slope);
+    else
+        hipLaunchKernelGGL(bias_act_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, y_ref, dx, count, gain, gain * slope);
+    return gc::check_launch("gc_bias_act_bwd_f32");
+}
+
+extern "C" size_t gc_channel_sum_workspace(int batch, int channels, int64_t inner) {
+    if (batch <= 0 || channels <= 0 || inner <= 0) return 0;
+    int chunks; int64_t len;
+    channel_sum_plan(inner, &chunks, &len);
+    return (size_t)batch * channels * chunks * sizeof(float);
+}
+
+extern "C" int gc_channel_sum_f32(const float* x, float* out, int batch, int channels, int64_t inner,
+                                  void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    if (!x || !out) return gc::fail(GC_ERR_BAD_ARG, "gc_channel_sum_f32: null pointer");
+    if (batch <= 0 || channels <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_channel_sum_f32: bad extents");
+    if ((int64_t)batch * channels > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_channel_sum_f32: more than 65535 planes");
+    const size_t need = gc_channel_sum_workspace(batch, channels, inner);
+    if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_channel_sum_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    int chunks; int64_t len;
+    channel_sum_plan(inner, &chunks, &len);
+    float* partial = static_cast<float*>(workspace);
+    hipLaunchKernelGGL(channel_sum_stage1, dim3(chunks, batch * channels), dim3(256), 0, s, x, partial, batch, channels, inner, chunks, len);
+    int rc = gc::check_launch("gc_channel_sum_f32(stage1)");
+    if (rc) return rc;
+    hipLaunchKernelGGL(channel_sum_stage2, dim3(channels), dim3(256), 0, s, partial, out, batch * chunks);
+    return gc::check_launch("gc_channel_sum_f32(stage2)");
+}

@@ -1,0 +1,34 @@
+// Shared helpers for the gfx950 kernels: error plumbing and launch checks.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "gancontrol_hip.h"
+
+namespace gc {
+
+// thread-local error text behind gc_last_error()
+char* err_buf();
+int fail(int code, const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(GC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
+    return GC_OK;
+}
+
+inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+// floor division / modulo for possibly negative numerators
+__host__ __device__ inline int floor_div(int a, int b) {
+    int q = a / b;
+    return (a % b != 0 && ((a < 0) != (b < 0))) ? q - 1 : q;
+}
+__host__ __device__ inline int pos_mod(int a, int b) {
+    int m = a % b;
+    return m < 0 ? m + b : m;
+}
+
+}  // namespace gc

@@ -1,0 +1,157 @@
+// K1  upfirdn2d for gfx950.  See include/gancontrol_hip.h for the contract and the reference lines.
+//
+// Two kernels:
+//  * fir44_tile_kernel   -- the hot case (up = down = 1, 4x4 taps: every Blur in G and D and their
+//    adjoints).  A 256-thread workgroup produces a 32x128 output tile of one plane: the (35 x 131)
+//    input patch is staged in LDS with coalesced dword loads (input rows are 1025/513/... floats
+//    wide, so wider global loads cannot be aligned), then each lane produces a 4x4 micro-tile from
+//    a 7x7 register window read with one ds_read_b128 + one ds_read_b96 per row -- 14 LDS
+//    instructions and 256 FMAs per 16 outputs -- and stores four float4 rows.  HBM-bound:
+//    algorithmic bytes = (in + out) * 4.
+//  * generic_kernel      -- any up/down/taps (ToRGB skip up-sampling, Downsample, the 12x12 ADA
+//    filters, tiny planes): one output per lane, taps cached in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int TH = 32, TW = 128;          // output tile of the fast kernel
+constexpr int PH = TH + 3, PW = TW + 3;   // input patch (4x4 taps)
+constexpr int PITCH = 132;                // patch row pitch in floats (multiple of 4: 16-B aligned rows)
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void fir44_tile_kernel(
+    const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
+    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip) {
+    __shared__ __attribute__((aligned(16))) float patch[PH * PITCH];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const size_t plane = blockIdx.z;
+    const float* xp = x + plane * (size_t)in_h * in_w;
+    float* yp = y + plane * (size_t)out_h * out_w;
+
+    // taps -> registers (uniform address: scalar loads); T[a][b] multiplies U[oy + a - pad][ox + b - pad]
+    float T[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) T[a][b] = flip ? taps[(3 - a) * 4 + (3 - b)] : taps[a * 4 + b];
+
+    // stage the patch: consecutive lanes -> consecutive floats of one input row
+    const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
+    for (int idx = tid; idx < PH * PITCH; idx += 256) {
+        const int r = idx / PITCH, c = idx - r * PITCH;
+        const int iy = iy0 + r, ix = ix0 + c;
+        float v = 0.f;
+        if (c < PW && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(size_t)iy * in_w + ix];
+        patch[idx] = v;
+    }
+    __syncthreads();
+
+    const int cg = tid & 31, rg = tid >> 5;   // 32 column groups x 8 row groups of 4x4 outputs
+    float acc[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
+
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+        const float* row = &patch[(rg * 4 + i) * PITCH + cg * 4];
+        const float4 lo = *reinterpret_cast<const float4*>(row);
+        const float v4 = row[4], v5 = row[5], v6 = row[6];
+        const float v[7] = {lo.x, lo.y, lo.z, lo.w, v4, v5, v6};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int a = i - r;
+            if (a < 0 || a > 3) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[r][j] = fmaf(T[a][b], v[j + b], acc[r][j]);
+        }
+    }
+
+    const int ox = ox0 + cg * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int oy = oy0 + rg * 4 + r;
+        if (oy >= out_h) break;
+        float* dst = yp + (size_t)oy * out_w + ox;
+        if (VEC) {
+            if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ox + j < out_w) dst[j] = acc[r][j];
+        }
+    }
+}
+
+constexpr int MAX_GENERIC_TAPS = 1024;
+
+__global__ __launch_bounds__(256) void generic_kernel(
+    const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
+    int planes, int in_h, int in_w, int out_h, int out_w, int kh, int kw,
+    int up_x, int up_y, int down_x, int down_y, int pad_x0, int pad_y0, int flip) {
+    __shared__ float T[MAX_GENERIC_TAPS];
+    const int nt = kh * kw;
+    for (int i = threadIdx.x; i < nt; i += 256) T[i] = flip ? taps[nt - 1 - i] : taps[i];
+    __syncthreads();
+    const size_t total = (size_t)planes * out_h * out_w;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int ox = (int)(idx % out_w);
+        const size_t t = idx / out_w;
+        const int oy = (int)(t % out_h);
+        const size_t plane = t / out_h;
+        const float* xp = x + plane * (size_t)in_h * in_w;
+        // first tap whose zero-stuffed coordinate is a multiple of `up`, then step by `up`
+        const int uy0 = oy * down_y - pad_y0, ux0 = ox * down_x - pad_x0;
+        const int a0 = gc::pos_mod(-uy0, up_y), b0 = gc::pos_mod(-ux0, up_x);
+        float acc = 0.f;
+        for (int a = a0; a < kh; a += up_y) {
+            const int uy = uy0 + a;
+            if (uy < 0) continue;
+            const int iy = uy / up_y;
+            if (iy >= in_h) break;
+            for (int b = b0; b < kw; b += up_x) {
+                const int ux = ux0 + b;
+                if (ux < 0) continue;
+                const int ix = ux / up_x;
+                if (ix >= in_w) break;
+                acc = fmaf(T[a * kw + b], xp[(size_t)iy * in_w + ix], acc);
+            }
+        }
+        y[idx] = acc;
+    }
+}
+
+}  // namespace
+
+extern "C" int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
+                                int planes, int in_h, int in_w, int out_h, int out_w,
+                                int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                int pad_x0, int pad_y0, int flip_taps, gc_stream_t stream) {
+    if (!x || !taps || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: null pointer");
+    if (planes < 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0 || up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
+        return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: non-positive extent or factor");
+    if (out_h <= 0 || out_w <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: empty output (%d x %d)", out_h, out_w);
+    if (planes == 0) return GC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const bool fast = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 &&
+                      out_w >= 64 && out_h >= 16 && planes <= 65535;
+    if (fast) {
+        dim3 grid(gc::ceil_div(out_w, TW), gc::ceil_div(out_h, TH), planes);
+        const bool vec = (out_w % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+        if (vec)
+            hipLaunchKernelGGL(fir44_tile_kernel<true>, grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps);
+        else
+            hipLaunchKernelGGL(fir44_tile_kernel<false>, grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps);
+        return gc::check_launch("gc_upfirdn2d_f32(fir44_tile)");
+    }
+    if (kh * kw > MAX_GENERIC_TAPS) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_f32: %d x %d taps exceed %d", kh, kw, MAX_GENERIC_TAPS);
+    const size_t total = (size_t)planes * out_h * out_w;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(generic_kernel, dim3(blocks), dim3(256), 0, s, x, taps, y, planes, in_h, in_w, out_h, out_w, kh, kw,
+                       up_x, up_y, down_x, down_y, pad_x0, pad_y0, flip_taps);
+    return gc::check_launch("gc_upfirdn2d_f32(generic)");
+}

@@ -1,0 +1,105 @@
+"""ctypes binding of the C-ABI library declared in include/gancontrol_hip.h.
+
+The product path has NO fallback: if ``libgancontrol_hip.so`` is missing or a kernel call
+fails, a RuntimeError is raised.  PyTorch is only the memory/stream substrate here: tensors
+provide device pointers, ``torch.cuda.current_stream`` provides the hipStream_t.
+"""
+import ctypes
+import os
+
+import torch  # noqa: F401  (must be imported first: it loads the HIP runtime the library binds to)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT = os.path.normpath(os.path.join(_HERE, '..', 'csrc', 'libgancontrol_hip.so'))
+
+ABI_VERSION = 1
+
+_c_float_p = ctypes.c_void_p
+_i32, _i64, _f32, _vp, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
+
+
+class ConvDesc(ctypes.Structure):
+    """Mirror of ``gc_conv_desc``."""
+    _fields_ = [(n, _i32) for n in ('batch', 'in_ch', 'out_ch', 'in_h', 'in_w', 'out_h', 'out_w',
+                                    'kh', 'kw', 'up', 'down', 'pad_y', 'pad_x')]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check every exported symbol
+SIGNATURES = {
+    'gc_abi_version': (_i32, []),
+    'gc_last_error': (ctypes.c_char_p, []),
+    'gc_upfirdn2d_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 14 + [_vp]),
+    'gc_bias_act_f32': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _f32, _f32, _vp]),
+    'gc_bias_act_bwd_f32': (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
+    'gc_channel_sum_workspace': (_sz, [_i32, _i32, _i64]),
+    'gc_channel_sum_f32': (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _sz, _vp]),
+    'gc_conv2d_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gc_conv2d_wgrad_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
+    'gc_conv2d_wgrad_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def library_path():
+    return os.environ.get('GANCONTROL_HIP_LIB', _DEFAULT)
+
+
+def load():
+    """Load (once) and return the ctypes handle; raise RuntimeError if the library is unusable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            f'gan_control_amd: HIP kernel library not found at {path}. Build it with '
+            f'`make -C gan-control_amd/csrc` (or `python -c "import __graft_entry__ as g; g.build()"`). '
+            f'There is no CPU or PyTorch fallback for the hot path.')
+    try:
+        lib = ctypes.CDLL(path)
+    except OSError as e:
+        raise RuntimeError(f'gan_control_amd: cannot load {path}: {e}') from e
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise RuntimeError(f'gan_control_amd: {path} does not export {name}') from e
+        fn.restype, fn.argtypes = res, args
+    if lib.gc_abi_version() != ABI_VERSION:
+        raise RuntimeError(f'gan_control_amd: ABI version {lib.gc_abi_version()} != {ABI_VERSION}; rebuild the library')
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().gc_last_error()
+        raise RuntimeError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+
+
+def ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_cuda_f32(*tensors):
+    """The kernels take contiguous float32 device memory; anything else is a caller error."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError('gan_control_amd: the HIP hot path needs tensors on a GPU (got %s); there is no CPU fallback' % t.device)
+        if t.dtype != torch.float32:
+            raise RuntimeError('gan_control_amd: float32 tensors expected, got %s' % t.dtype)
+        if not t.is_contiguous():
+            raise RuntimeError('gan_control_amd: internal error: non-contiguous tensor reached the kernel boundary')
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise RuntimeError('gan_control_amd: tensors on different devices (%s vs %s)' % (dev, t.device))
+    return dev

@@ -1,0 +1,428 @@
+"""StyleGAN2 Generator / Discriminator of gan-control on the gfx950 operator socket.
+
+Mirrors the module API of the reference's src/gan_control/models/gan_model.py for everything the
+trainer can reach: same constructor arguments, forward signatures, return tuples and
+state_dict keys, so reference checkpoints load unchanged.  Every tensor
+operation on the hot path goes through ``gan_control_amd.models.op`` (HIP kernels); there is no
+ATen convolution, no materialised per-sample weight and no CPU fallback in here.
+
+Unreachable reference features (VAE mapping, model_mode='896', verification head, Downsample
+branch of ModulatedConv2d, ScaledLeakyReLU) are not built.
+"""
+import math
+import random
+
+import torch
+from torch import nn, autograd
+from torch.nn import functional as F
+
+from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix, modulated_conv2d
+
+CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
+
+
+def channel_table(channel_multiplier):
+    """Reference: gan_model.py:552-563 and :931-941."""
+    t = dict(CHANNELS)
+    for res, base in ((64, 256), (128, 128), (256, 64), (512, 32), (1024, 16)):
+        t[res] = int(base * channel_multiplier)
+    return t
+
+
+def make_kernel(k):
+    """Reference: gan_model.py:60-68."""
+    k = torch.as_tensor(k, dtype=torch.float32)
+    if k.ndim == 1:
+        k = torch.outer(k, k)
+    return k / k.sum()
+
+
+class PixelNorm(nn.Module):
+    def forward(self, input):
+        return input * torch.rsqrt(input.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+
+
+class _Fir(nn.Module):
+    """Common base of Upsample / Downsample / Blur: owns the ``kernel`` buffer (gan_model.py:77,98,122)."""
+
+    def __init__(self, kernel, gain, up, down, pad):
+        super().__init__()
+        self.register_buffer('kernel', make_kernel(kernel) * gain)
+        self.up, self.down, self.pad = up, down, pad
+
+    def forward(self, input):
+        return upfirdn2d(input, self.kernel, up=self.up, down=self.down, pad=self.pad)
+
+
+class Upsample(_Fir):
+    def __init__(self, kernel, factor=2):
+        p = len(kernel) - factor
+        super().__init__(kernel, factor ** 2, factor, 1, ((p + 1) // 2 + factor - 1, p // 2))
+        self.factor = factor
+
+
+class Downsample(_Fir):
+    def __init__(self, kernel, factor=2):
+        p = len(kernel) - factor
+        super().__init__(kernel, 1, 1, factor, ((p + 1) // 2, p // 2))
+        self.factor = factor
+
+
+class Blur(_Fir):
+    def __init__(self, kernel, pad, upsample_factor=1):
+        super().__init__(kernel, upsample_factor ** 2 if upsample_factor > 1 else 1, 1, 1, pad)
+
+
+class EqualConv2d(nn.Module):
+    """Reference: gan_model.py:132-168.  Runs on conv2d_gradfix (MFMA implicit GEMM)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, stride=1, padding=0, bias=True):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.stride, self.padding = stride, padding
+        self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
+
+    def forward(self, input):
+        return conv2d_gradfix.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
+
+    def __repr__(self):
+        oc, ic, k, _ = self.weight.shape
+        return f'{self.__class__.__name__}({ic}, {oc}, {k}, stride={self.stride}, padding={self.padding})'
+
+
+class EqualLinear(nn.Module):
+    """Reference: gan_model.py:171-202.  The GEMM is a plain library GEMM (rocBLAS via F.linear)."""
+
+    def __init__(self, in_dim, out_dim, bias=True, bias_init=0, lr_mul=1, activation=None):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.full((out_dim,), float(bias_init))) if bias else None
+        self.activation = activation
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul = lr_mul
+
+    def forward(self, input):
+        if self.activation:
+            return fused_leaky_relu(F.linear(input, self.weight * self.scale), self.bias * self.lr_mul)
+        return F.linear(input, self.weight * self.scale, bias=self.bias * self.lr_mul)
+
+    def __repr__(self):
+        return f'{self.__class__.__name__}({self.weight.shape[1]}, {self.weight.shape[0]})'
+
+
+class ModulatedConv2d(nn.Module):
+    """Reference: gan_model.py:217-331 (plain and conv_transpose up-sampling branches)."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True, upsample=False,
+                 downsample=False, blur_kernel=[1, 3, 3, 1], conv_transpose=False, overwrite_padding=None):
+        super().__init__()
+        if not conv_transpose:
+            raise ValueError('conv_transpose is %s' % str(conv_transpose))
+        if downsample or overwrite_padding is not None:
+            raise NotImplementedError('ModulatedConv2d: downsample / overwrite_padding are unreachable from the trainer and not built')
+        self.eps = 1e-8
+        self.kernel_size, self.in_channel, self.out_channel = kernel_size, in_channel, out_channel
+        self.upsample, self.downsample, self.conv_transpose = upsample, downsample, conv_transpose
+        if upsample:
+            factor = 2
+            p = (len(blur_kernel) - factor) - (kernel_size - 1)
+            self.blur = Blur(blur_kernel, pad=((p + 1) // 2 + factor - 1, p // 2 + 1), upsample_factor=factor)
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.padding = kernel_size // 2
+        self.weight = nn.Parameter(torch.randn(1, out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1)
+        self.demodulate = demodulate
+
+    def __repr__(self):
+        return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
+                f'upsample={self.upsample}, downsample={self.downsample})')
+
+    def forward(self, input, style):
+        s = self.modulation(style)
+        if self.upsample:
+            return modulated_conv2d(input, self.weight, s, demodulate=self.demodulate, upsample=True,
+                                    blur_kernel=self.blur.kernel, blur_pad=self.blur.pad)
+        return modulated_conv2d(input, self.weight, s, demodulate=self.demodulate, padding=self.padding)
+
+
+class NoiseInjection(nn.Module):
+    """Owns the noise strength (gan_model.py:334-345); the add itself is fused into the activation kernel."""
+
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+    def forward(self, image, noise=None):
+        if noise is None:
+            b, _, h, w = image.shape
+            noise = image.new_empty(b, 1, h, w).normal_()
+        return image + self.weight * noise
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+    def forward(self, input):
+        return self.input.repeat(input.shape[0], 1, 1, 1)
+
+
+class StyledConv(nn.Module):
+    """Reference: gan_model.py:361-408.  conv -> (noise + bias + leaky-ReLU) in one fused pass."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1],
+                 demodulate=True, conv_transpose=False, overwrite_padding=None, noise_mode='normal'):
+        super().__init__()
+        if noise_mode not in ('normal', 'same_for_same_id'):
+            raise NotImplementedError(f'noise_mode {noise_mode!r} is not built on the HIP path')
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
+                                    blur_kernel=blur_kernel, demodulate=demodulate, conv_transpose=conv_transpose,
+                                    overwrite_padding=overwrite_padding)
+        self.noise_mode = noise_mode
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, input, style, noise=None):
+        out = self.conv(input, style)
+        if noise is None:
+            b, _, h, w = out.shape
+            noise = out.new_empty(b, 1, h, w).normal_()
+        return self.activate(out, noise, self.noise.weight)
+
+
+class ToRGB(nn.Module):
+    """Reference: gan_model.py:411-435."""
+
+    def __init__(self, in_channel, style_dim, upsample=True, blur_kernel=[1, 3, 3, 1], out_channels=3,
+                 conv_transpose=False, overwrite_negative_padding=None):
+        super().__init__()
+        if overwrite_negative_padding is not None:
+            raise NotImplementedError('ToRGB: overwrite_negative_padding (model_mode 896) is not built')
+        if upsample:
+            self.upsample = Upsample(blur_kernel)
+        self.conv = ModulatedConv2d(in_channel, out_channels, 1, style_dim, demodulate=False, conv_transpose=conv_transpose)
+        self.bias = nn.Parameter(torch.zeros(1, out_channels, 1, 1))
+
+    def forward(self, input, style, skip=None):
+        out = self.conv(input, style) + self.bias
+        if skip is not None:
+            out = out + self.upsample(skip)
+        return out
+
+
+class MultiFcStack(nn.Module):
+    """Per-group mapping networks (gan_model.py:489-502); groups come from FcConfig."""
+
+    def __init__(self, fc_dict, fc_config):
+        super().__init__()
+        self.fc_config = fc_config
+        for name in fc_config.in_order_group_names:
+            setattr(self, name, fc_dict[name])
+
+    def forward(self, x):
+        parts = []
+        for name in self.fc_config.in_order_group_names:
+            lo, hi = self.fc_config.groups[name]['latent_place']
+            parts.append(getattr(self, name)(x[:, lo:hi]))
+        return torch.cat(parts, dim=1)
+
+
+class Generator(nn.Module):
+    """Reference: gan_model.py:505-811."""
+
+    def __init__(self, size, style_dim, n_mlp, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], lr_mlp=0.01,
+                 out_channels=3, vae=False, bottleneck_size=256, split_fc=False, marge_fc=False, fc_config=None,
+                 conv_transpose=False, model_mode='normal', noise_mode='normal'):
+        super().__init__()
+        if vae or model_mode != 'normal':
+            raise NotImplementedError('Generator: vae / model_mode != "normal" are unreachable from the trainer and not built')
+        self.noise_mode, self.model_mode, self.size, self.vae = noise_mode, model_mode, size, vae
+        self.out_channels, self.fc_config, self.style_dim = out_channels, fc_config, style_dim
+
+        if split_fc:
+            self.style = self.make_fc_stacks_using_fc_config(fc_config, lr_mlp, n_mlp)
+        elif marge_fc:
+            self.style = nn.Sequential(self.make_fc_stacks_using_fc_config(fc_config, lr_mlp, int(math.ceil(n_mlp / 2))),
+                                       self.create_regular_fc_stack(lr_mlp, int(math.floor(n_mlp / 2)), style_dim))
+        else:
+            self.style = self.create_regular_fc_stack(lr_mlp, n_mlp, style_dim)
+
+        self.channels = channel_table(channel_multiplier)
+        self.log_size = int(math.log(size, 2))
+        self.num_layers = (self.log_size - 2) * 2 + 1
+        self.n_latent = self.log_size * 2 - 2
+
+        ch4 = self.channels[4]
+        self.input = ConstantInput(ch4)
+        self.conv1 = StyledConv(ch4, ch4, 3, style_dim, blur_kernel=blur_kernel, conv_transpose=conv_transpose, noise_mode=noise_mode)
+        self.to_rgb1 = ToRGB(ch4, style_dim, upsample=False, out_channels=out_channels, conv_transpose=conv_transpose)
+        self.convs, self.upsamples, self.to_rgbs, self.noises = nn.ModuleList(), nn.ModuleList(), nn.ModuleList(), nn.Module()
+        for layer_idx in range(self.num_layers):
+            res = (layer_idx + 5) // 2
+            self.noises.register_buffer(f'noise_{layer_idx}', torch.randn(1, 1, 2 ** res, 2 ** res))
+        in_ch = ch4
+        for i in range(3, self.log_size + 1):
+            out_ch = self.channels[2 ** i]
+            self.convs.append(StyledConv(in_ch, out_ch, 3, style_dim, upsample=True, blur_kernel=blur_kernel,
+                                         conv_transpose=conv_transpose, noise_mode=noise_mode))
+            self.convs.append(StyledConv(out_ch, out_ch, 3, style_dim, blur_kernel=blur_kernel, conv_transpose=conv_transpose))
+            self.to_rgbs.append(ToRGB(out_ch, style_dim, out_channels=out_channels, conv_transpose=conv_transpose))
+            in_ch = out_ch
+
+    # -- mapping networks ---------------------------------------------------------------------
+    @staticmethod
+    def create_fc_stack(lr_mlp, n_mlp, style_dim, mid_dim=None):
+        dims = [style_dim] + [mid_dim if mid_dim is not None else style_dim] * (n_mlp - 1) + [style_dim]
+        return nn.Sequential(PixelNorm(), *[EqualLinear(dims[i], dims[i + 1], lr_mul=lr_mlp, activation='fused_lrelu')
+                                            for i in range(n_mlp)])
+
+    def create_regular_fc_stack(self, lr_mlp, n_mlp, style_dim):
+        return self.create_fc_stack(lr_mlp, n_mlp, style_dim)
+
+    def make_fc_stacks_using_fc_config(self, fc_config, lr_mlp, n_mlp):
+        stacks = {name: self.create_fc_stack(lr_mlp, n_mlp, fc_config.groups[name]['latent_size'], mid_dim=256)
+                  for name in fc_config.in_order_group_names}
+        return MultiFcStack(stacks, fc_config)
+
+    def load_transfer_learning_model(self, transfer_learning_model, load_only_main=True):
+        """Reference: gan_model.py:645-656 -- only the mapping network may differ."""
+        missing, unexpected = self.load_state_dict(transfer_learning_model.state_dict(), strict=False)
+        if (missing or unexpected) and not load_only_main:
+            self.load_state_dict(transfer_learning_model.state_dict())
+        for key in list(missing) + list(unexpected):
+            if key.split('.')[0] != 'style':
+                raise ValueError('key %s is part of the main network' % key)
+
+    # -- helpers --------------------------------------------------------------------------------
+    def make_noise(self, batch_size=1, device=None):
+        device = device if device is not None else self.input.input.device
+        noises = [torch.randn(batch_size, 1, 4, 4, device=device)]
+        for i in range(3, self.log_size + 1):
+            noises += [torch.randn(batch_size, 1, 2 ** i, 2 ** i, device=device) for _ in range(2)]
+        return noises
+
+    def mean_latent(self, n_latent):
+        z = torch.randn(n_latent, self.style_dim, device=self.input.input.device)
+        return self.style(z).mean(0, keepdim=True)
+
+    def get_latent(self, input):
+        return self.style(input)
+
+    # -- forward --------------------------------------------------------------------------------
+    def forward(self, styles, return_latents=False, inject_index=None, truncation=1, truncation_latent=None,
+                input_is_latent=False, noise=None, randomize_noise=True, return_grad=False):
+        if not input_is_latent:
+            styles = [self.style(s) for s in styles]
+        if noise is None:
+            noise = [None] * self.num_layers if randomize_noise else \
+                [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
+        if truncation < 1:
+            styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
+        if len(styles) < 2:
+            latent = styles[0].unsqueeze(1).repeat(1, self.n_latent, 1) if styles[0].ndim < 3 else styles[0]
+        else:
+            if inject_index is None:
+                inject_index = random.randint(1, self.n_latent - 1)
+            latent = torch.cat([styles[0].unsqueeze(1).repeat(1, inject_index, 1),
+                                styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
+
+        out = self.input(latent)
+        out = self.conv1(out, latent[:, 0], noise=noise[0])
+        skip = self.to_rgb1(out, latent[:, 1])
+        i = 1
+        for up_conv, conv, n1, n2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2], self.to_rgbs):
+            out = up_conv(out, latent[:, i], noise=n1)
+            out = conv(out, latent[:, i + 1], noise=n2)
+            skip = to_rgb(out, latent[:, i + 2], skip)
+            i += 2
+        image = skip
+        if return_grad:
+            return image, self.g_path_regularize_grad(image, latent)
+        return image, (latent if return_latents else None)
+
+    @staticmethod
+    def g_path_regularize_grad(fake_img, latents, dim_1_shape=1, pl_noise=None):
+        """Reference: gan_model.py:803-811.  ``pl_noise`` (optional) makes the draw reproducible."""
+        if pl_noise is None:
+            pl_noise = torch.randn_like(fake_img)
+        pl_noise = pl_noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3] * dim_1_shape)
+        grad, = autograd.grad(outputs=(fake_img * pl_noise).sum(), inputs=latents, create_graph=True)
+        return grad
+
+
+class ConvLayer(nn.Sequential):
+    """[Blur] -> EqualConv2d -> [FusedLeakyReLU]  (gan_model.py:844-890); child indices fix the state_dict keys."""
+
+    def __init__(self, in_channel, out_channel, kernel_size, downsample=False, blur_kernel=[1, 3, 3, 1], bias=True, activate=True):
+        layers = []
+        if downsample:
+            p = (len(blur_kernel) - 2) + (kernel_size - 1)
+            layers.append(Blur(blur_kernel, pad=((p + 1) // 2, p // 2)))
+        self.padding = 0 if downsample else kernel_size // 2
+        layers.append(EqualConv2d(in_channel, out_channel, kernel_size, padding=self.padding,
+                                  stride=2 if downsample else 1, bias=bias and not activate))
+        if activate:
+            if not bias:
+                raise NotImplementedError('ConvLayer: activation without bias (ScaledLeakyReLU) is not built')
+            layers.append(FusedLeakyReLU(out_channel))
+        super().__init__(*layers)
+
+
+class ResBlock(nn.Module):
+    """Reference: gan_model.py:893-922."""
+
+    def __init__(self, in_channel, out_channel, blur_kernel=[1, 3, 3, 1], overwrite_padding=None):
+        super().__init__()
+        if overwrite_padding is not None:
+            raise NotImplementedError('ResBlock: overwrite_padding (model_mode 896) is not built')
+        self.conv1 = ConvLayer(in_channel, in_channel, 3)
+        self.conv2 = ConvLayer(in_channel, out_channel, 3, downsample=True)
+        self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
+
+    def forward(self, input):
+        out = self.conv2(self.conv1(input))
+        return (out + self.skip(input)) / math.sqrt(2)
+
+
+def minibatch_stddev(x, group_size=4, feat=1):
+    """Reference: gan_model.py:1003-1012 (group members are strided by B / group)."""
+    b, c, h, w = x.shape
+    g = min(b, group_size)
+    s = x.view(g, -1, feat, c // feat, h, w)
+    s = torch.sqrt(s.var(0, unbiased=False) + 1e-8)
+    s = s.mean([2, 3, 4], keepdims=True).squeeze(2)
+    return torch.cat([x, s.repeat(g, 1, h, w)], 1)
+
+
+class Discriminator(nn.Module):
+    """Reference: gan_model.py:925-1016 (adversarial head only)."""
+
+    def __init__(self, size, channel_multiplier=2, blur_kernel=[1, 3, 3, 1], in_channels=3,
+                 verification=False, verification_res_split=None, model_mode=None):
+        super().__init__()
+        if verification or model_mode == '896':
+            raise NotImplementedError('Discriminator: verification head / model_mode 896 are never enabled by the trainer and not built')
+        self.model_mode, self.verification = model_mode, verification
+        channels = channel_table(channel_multiplier)
+        log_size = int(math.log(size, 2))
+        blocks = [ConvLayer(in_channels, channels[size], 1)]
+        in_ch = channels[size]
+        for i in range(log_size, 2, -1):
+            out_ch = channels[2 ** (i - 1)]
+            blocks.append(ResBlock(in_ch, out_ch, blur_kernel))
+            in_ch = out_ch
+        self.convs = nn.Sequential(*blocks)
+        self.convs_adv = nn.Sequential()
+        self.convs_verification = nn.Sequential()
+        self.stddev_group, self.stddev_feat = 4, 1
+        self.final_conv = ConvLayer(in_ch + 1, channels[4], 3)
+        self.final_linear = nn.Sequential(EqualLinear(channels[4] * 4 * 4, channels[4], activation='fused_lrelu'),
+                                          EqualLinear(channels[4], 1))
+
+    def forward(self, input):
+        out = self.convs(input)
+        out = minibatch_stddev(out, self.stddev_group, self.stddev_feat)
+        out = self.final_conv(out)
+        return self.final_linear(out.view(out.shape[0], -1)), None

@@ -1,0 +1,152 @@
+"""Raw (non-differentiable) primitives: one Python function per C-ABI entry point.
+
+The autograd layer in this package is written against the ``Backend`` interface.  The only
+implementation shipped is ``HipBackend`` (ctypes -> libgancontrol_hip.so).  Tests install an
+emulation of the same interface to validate the autograd wiring on machines without a GPU;
+the product never does.
+"""
+from collections import namedtuple
+
+import torch
+
+from ... import _lib
+
+# Geometry of the generalised convolution (gc_conv_desc minus batch/channels/in-size, which come from tensors)
+ConvGeom = namedtuple('ConvGeom', 'kh kw up down pad_y pad_x out_h out_w')
+
+
+class HipBackend:
+    name = 'hip'
+
+    @staticmethod
+    def _guard(dev):
+        idx = dev.index if dev.index is not None else torch.cuda.current_device()
+        return torch.cuda.device(idx) if idx != torch.cuda.current_device() else None
+
+    def upfirdn2d(self, x, taps, up, down, pad_x0, pad_y0, out_h, out_w, flip):
+        """x [N,C,H,W] -> [N,C,out_h,out_w]; see gc_upfirdn2d_f32."""
+        dev = _lib.require_cuda_f32(x, taps)
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, out_h, out_w), dtype=x.dtype, device=dev)
+        if y.numel() == 0:
+            return y
+        lib = _lib.load()
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_upfirdn2d_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n * c, h, w, out_h, out_w,
+                                      taps.shape[0], taps.shape[1], up, up, down, down, pad_x0, pad_y0, int(flip), _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_upfirdn2d_f32')
+        return y
+
+    def bias_act(self, x, bias, noise, noise_w, slope, gain):
+        """y = gain * lrelu(x + bias[c] + noise_w * noise[b, :]); x is [B, C, *]."""
+        dev = _lib.require_cuda_f32(x, bias, noise, noise_w)
+        y = torch.empty_like(x)
+        if x.numel() == 0:
+            return y
+        batch, ch = x.shape[0], x.shape[1]
+        inner = x.numel() // (batch * ch)
+        lib = _lib.load()
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_bias_act_f32(_lib.ptr(x), _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(y),
+                                     batch, ch, inner, slope, gain, _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_bias_act_f32')
+        return y
+
+    def bias_act_bwd(self, dy, y_ref, slope, gain):
+        dev = _lib.require_cuda_f32(dy, y_ref)
+        dx = torch.empty_like(dy)
+        if dy.numel() == 0:
+            return dx
+        lib = _lib.load()
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_bias_act_bwd_f32(_lib.ptr(dy), _lib.ptr(y_ref), _lib.ptr(dx), dy.numel(), slope, gain, _lib.stream_of(dy))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_bias_act_bwd_f32')
+        return dx
+
+    def channel_sum(self, x):
+        """[B, C, *] -> [C]: sum over every dim but 1."""
+        dev = _lib.require_cuda_f32(x)
+        batch, ch = x.shape[0], x.shape[1]
+        out = torch.empty(ch, dtype=x.dtype, device=dev)
+        if x.numel() == 0:
+            return out.zero_()
+        inner = x.numel() // (batch * ch)
+        lib = _lib.load()
+        nbytes = lib.gc_channel_sum_workspace(batch, ch, inner)
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_channel_sum_f32(_lib.ptr(x), _lib.ptr(out), batch, ch, inner, _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_channel_sum_f32')
+        return out
+
+    @staticmethod
+    def _desc(x, n_out, geom):
+        b, k, h, w = x.shape
+        return _lib.ConvDesc(b, k, n_out, h, w, geom.out_h, geom.out_w, geom.kh, geom.kw, geom.up, geom.down, geom.pad_y, geom.pad_x)
+
+    def conv2d(self, x, w_t, in_scale, out_scale, geom):
+        """x [B,K,H,W], w_t [kh,kw,K,N] -> [B,N,out_h,out_w]; see gc_conv2d_f32."""
+        dev = _lib.require_cuda_f32(x, w_t, in_scale, out_scale)
+        n_out = w_t.shape[3]
+        y = torch.empty((x.shape[0], n_out, geom.out_h, geom.out_w), dtype=x.dtype, device=dev)
+        if y.numel() == 0:
+            return y
+        desc = self._desc(x, n_out, geom)
+        lib = _lib.load()
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_conv2d_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(y), _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_conv2d_f32')
+        return y
+
+    def conv2d_wgrad(self, x, dy, in_scale, out_scale, geom):
+        """x [B,K,H,W], dy [B,N,out_h,out_w] -> dw [kh,kw,K,N]; see gc_conv2d_wgrad_f32."""
+        dev = _lib.require_cuda_f32(x, dy, in_scale, out_scale)
+        n_out = dy.shape[1]
+        dw = torch.empty((geom.kh, geom.kw, x.shape[1], n_out), dtype=x.dtype, device=dev)
+        desc = self._desc(x, n_out, geom)
+        lib = _lib.load()
+        nbytes = lib.gc_conv2d_wgrad_workspace(desc)
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_conv2d_wgrad_f32(desc, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(dw),
+                                         _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_conv2d_wgrad_f32')
+        return dw
+
+
+_active = HipBackend()
+
+
+def get():
+    return _active
+
+
+def _install_for_tests(backend):
+    """Swap the primitive implementation (tests only: CPU emulation of the C ABI)."""
+    global _active
+    prev, _active = _active, backend
+    return prev

@@ -1,0 +1,129 @@
+"""conv2d / conv_transpose2d with arbitrary-order gradients on the MFMA kernels
+gc_conv2d_f32 / gc_conv2d_wgrad_f32.
+
+The reference calls plain ATen (F.conv2d gan_model.py:154,327; F.conv_transpose2d gan_model.py:304)
+and relies on ATen being infinitely differentiable for R1 (generator_trainer.py:713-719) and
+path-length regularisation (gan_model.py:803-811).  Here the same closure is obtained with two
+autograd Functions that are each other's derivatives:
+
+  _GConv(x, w_t)   y[b,n,o]    = sum_{t,k} w_t[t,k,n] * U_up(x)[b,k, o*down + t - pad]
+  _WGrad(x, gy)    g[t,k,n]    = sum_{b,o} x[b,k, o*down + t - pad] * gy[b,n,o]
+
+d_GConv/dx is a _GConv with (up <-> down, flipped taps, swapped channel axes); d_GConv/dw is a
+_WGrad; both derivatives of _WGrad are _GConv's.  Weights travel as w_t = [kh, kw, K, N]
+(correlation order, N contiguous); the layout changes are ordinary differentiable torch ops.
+"""
+import torch
+from torch.autograd import Function
+
+from . import _backend
+from ._backend import ConvGeom
+
+
+def _adjoint_geom(g, in_h, in_w):
+    """Geometry of d/dx: swaps up/down, mirrors the pad, and produces the input extent."""
+    return ConvGeom(g.kh, g.kw, g.down, g.up, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x, in_h, in_w)
+
+
+def _adjoint_weight(w_t):
+    """[kh,kw,K,N] -> [kh,kw,N,K] with flipped taps."""
+    return w_t.flip(0, 1).transpose(2, 3).contiguous()
+
+
+class _GConv(Function):
+    @staticmethod
+    def forward(ctx, x, w_t, geom):
+        ctx.geom = geom
+        ctx.in_hw = (x.shape[2], x.shape[3])
+        ctx.save_for_backward(x, w_t)
+        return _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None, None, geom)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_t = ctx.saved_tensors
+        g = ctx.geom
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _GConv.apply(gy, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw))
+        if ctx.needs_input_grad[1]:
+            gw = _weight_grad(x, gy, g)
+        return gx, gw, None
+
+
+def _weight_grad(x, gy, g):
+    if g.up == 1:
+        return _WGrad.apply(x, gy, g)
+    # transposed conv: correlate gy (as the "input", decimated by `up`) with x (as the "output gradient")
+    swapped = ConvGeom(g.kh, g.kw, 1, g.up, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x, x.shape[2], x.shape[3])
+    return _WGrad.apply(gy, x, swapped).flip(0, 1).transpose(2, 3)
+
+
+class _WGrad(Function):
+    @staticmethod
+    def forward(ctx, x, gy, geom):
+        ctx.geom = geom
+        ctx.in_hw = (x.shape[2], x.shape[3])
+        ctx.save_for_backward(x, gy)
+        return _backend.get().conv2d_wgrad(x.contiguous(), gy.contiguous(), None, None, geom)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        g = ctx.geom
+        gx = ggy = None
+        if ctx.needs_input_grad[0]:
+            gx = _GConv.apply(gy, _adjoint_weight(ggw), _adjoint_geom(g, *ctx.in_hw))
+        if ctx.needs_input_grad[1]:
+            ggy = _GConv.apply(x, ggw.contiguous(), g)
+        return gx, ggy, None
+
+
+def _pair(v):
+    return (int(v), int(v)) if not isinstance(v, (tuple, list)) else (int(v[0]), int(v[1]))
+
+
+def _check(input, weight, stride, padding, dilation, groups):
+    if dilation not in (1, (1, 1)) or groups != 1:
+        raise ValueError('conv2d_gradfix: only dilation=1, groups=1 are implemented on the HIP path')
+    s, p = _pair(stride), _pair(padding)
+    if s[0] != s[1] or p[0] != p[1]:
+        raise ValueError('conv2d_gradfix: stride and padding must be square')
+    if input.ndim != 4 or weight.ndim != 4:
+        raise ValueError('conv2d_gradfix: 4-D input and weight expected')
+    return s[0], p[0]
+
+
+def conv2d_t(x, w_t, stride=1, padding=0):
+    """conv2d with the weight already in [kh, kw, IC, OC] layout."""
+    kh, kw = w_t.shape[0], w_t.shape[1]
+    oh = (x.shape[2] + 2 * padding - kh) // stride + 1
+    ow = (x.shape[3] + 2 * padding - kw) // stride + 1
+    return _GConv.apply(x, w_t, ConvGeom(kh, kw, 1, stride, padding, padding, oh, ow))
+
+
+def conv_transpose2d_t(x, w_t, stride=1, padding=0):
+    """conv_transpose2d with the weight already in CORRELATION form [kh, kw, IC, OC] (taps flipped)."""
+    kh, kw = w_t.shape[0], w_t.shape[1]
+    oh = (x.shape[2] - 1) * stride - 2 * padding + kh
+    ow = (x.shape[3] - 1) * stride - 2 * padding + kw
+    return _GConv.apply(x, w_t, ConvGeom(kh, kw, stride, 1, kh - 1 - padding, kw - 1 - padding, oh, ow))
+
+
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
+    """Same call signature as torch.nn.functional.conv2d (weight [OC, IC, kh, kw])."""
+    s, p = _check(input, weight, stride, padding, dilation, groups)
+    if weight.shape[1] != input.shape[1]:
+        raise ValueError(f'conv2d: weight expects {weight.shape[1]} input channels, got {input.shape[1]}')
+    y = conv2d_t(input, weight.permute(2, 3, 1, 0).contiguous(), s, p)
+    return y if bias is None else y + bias.reshape(1, -1, 1, 1)
+
+
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
+    """Same call signature as torch.nn.functional.conv_transpose2d (weight [IC, OC, kh, kw])."""
+    s, p = _check(input, weight, stride, padding, dilation, groups)
+    if output_padding not in (0, (0, 0)):
+        raise ValueError('conv_transpose2d: output_padding is not implemented on the HIP path')
+    if weight.shape[0] != input.shape[1]:
+        raise ValueError(f'conv_transpose2d: weight expects {weight.shape[0]} input channels, got {input.shape[1]}')
+    y = conv_transpose2d_t(input, weight.flip(2, 3).permute(2, 3, 0, 1).contiguous(), s, p)
+    return y if bias is None else y + bias.reshape(1, -1, 1, 1)

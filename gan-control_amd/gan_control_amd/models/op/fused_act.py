@@ -1,0 +1,107 @@
+"""Fused (noise +) bias + leaky-ReLU * gain with first- and second-order gradients.
+
+Socket: ``FusedLeakyReLU(channel, negative_slope=0.2, scale=2 ** 0.5)`` and
+``fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5)`` -- names, signatures and
+defaults of gan_model.py:25-41.  ``fused_noise_bias_act`` additionally folds the NoiseInjection
+add that precedes every activation in StyledConv (gan_model.py:340-345, 402-408) into the same pass.
+"""
+import torch
+from torch import nn
+from torch.autograd import Function
+
+from . import _backend
+
+
+def _channel_sum(t):
+    return _ChannelSum.apply(t)
+
+
+class _ChannelSum(Function):
+    """[B, C, *] -> [C] on gc_channel_sum_f32 (deterministic); differentiable (broadcast back)."""
+
+    @staticmethod
+    def forward(ctx, t):
+        ctx.shape = t.shape
+        return _backend.get().channel_sum(t.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        shape = ctx.shape
+        return g.reshape([1, -1] + [1] * (len(shape) - 2)).expand(shape)
+
+
+class _BiasAct(Function):
+    @staticmethod
+    def forward(ctx, x, bias, noise, noise_w, slope, gain):
+        y = _backend.get().bias_act(x.contiguous(), bias, None if noise is None else noise.contiguous(), noise_w, slope, gain)
+        ctx.cfg = (slope, gain)
+        ctx.has_bias, ctx.has_noise = bias is not None, noise is not None
+        ctx.save_for_backward(y, noise if noise is not None else y.new_empty(0), noise_w if noise_w is not None else y.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        y, noise, noise_w = ctx.saved_tensors
+        slope, gain = ctx.cfg
+        gx = gb = gn = gnw = None
+        if any(ctx.needs_input_grad[:4]):
+            gx = _BiasActGrad.apply(gy, y, slope, gain)
+            if ctx.has_bias and ctx.needs_input_grad[1]:
+                gb = _channel_sum(gx)
+            if ctx.has_noise and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+                per_px = gx.sum(1, keepdim=True)                   # [B, 1, *]
+                if ctx.needs_input_grad[2]:
+                    gn = per_px * noise_w
+                if ctx.needs_input_grad[3]:
+                    gnw = (per_px * noise).sum().reshape(noise_w.shape)
+            if not ctx.needs_input_grad[0]:
+                gx = None
+        return gx, gb, gn, gnw, None, None
+
+
+class _BiasActGrad(Function):
+    """gx = gy * (y > 0 ? gain : gain * slope); linear in gy, so it is its own adjoint."""
+
+    @staticmethod
+    def forward(ctx, gy, y, slope, gain):
+        ctx.save_for_backward(y)
+        ctx.cfg = (slope, gain)
+        return _backend.get().bias_act_bwd(gy.contiguous(), y, slope, gain)
+
+    @staticmethod
+    def backward(ctx, ggx):
+        y, = ctx.saved_tensors
+        slope, gain = ctx.cfg
+        ggy = _BiasActGrad.apply(ggx, y, slope, gain) if ctx.needs_input_grad[0] else None
+        # d/dy of the mask is zero almost everywhere: no gradient flows to the forward output
+        return ggy, None, None, None
+
+
+def fused_noise_bias_act(input, bias=None, noise=None, noise_weight=None, negative_slope=0.2, scale=2 ** 0.5):
+    """scale * lrelu(input + bias[c] + noise_weight * noise[b, 0]); bias broadcasts over dim 1."""
+    if (noise is None) != (noise_weight is None):
+        raise ValueError('noise and noise_weight go together')
+    if bias is not None and bias.numel() != input.shape[1]:
+        raise ValueError(f'bias has {bias.numel()} elements, input has {input.shape[1]} channels')
+    if bias is not None:
+        bias = bias.reshape(-1).contiguous()
+    if noise is not None:
+        if noise.shape[0] != input.shape[0] or noise.numel() * input.shape[1] != input.numel():
+            raise ValueError(f'noise shape {tuple(noise.shape)} does not match input {tuple(input.shape)}')
+        noise_weight = noise_weight.reshape(-1).contiguous()
+    return _BiasAct.apply(input, bias, noise, noise_weight, float(negative_slope), float(scale))
+
+
+def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):
+    return fused_noise_bias_act(input, bias, None, None, negative_slope, scale)
+
+
+class FusedLeakyReLU(nn.Module):
+    def __init__(self, channel, negative_slope=0.2, scale=2 ** 0.5):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+        self.negative_slope = negative_slope
+        self.scale = scale
+
+    def forward(self, input, noise=None, noise_weight=None):
+        return fused_noise_bias_act(input, self.bias, noise, noise_weight, self.negative_slope, self.scale)

@@ -1,0 +1,138 @@
+/*
+ * gancontrol_hip.h -- C ABI of the MI355X (gfx950) StyleGAN2 hot-path kernels for gan-control.
+ *
+ * This is the drop-in boundary.  Every entry point takes raw device pointers, explicit
+ * extents and a HIP stream (as void*); the library never allocates or frees memory the
+ * caller can see, keeps no mutable global state, launches asynchronously on the stream it is
+ * given and never synchronises.  All tensors are contiguous NCHW float32 unless stated.
+ *
+ * Return value: 0 on success, negative on failure (GC_ERR_*).  gc_last_error() returns a
+ * thread-local, human-readable description of the last failure on the calling thread.
+ *
+ * The reference (amazon-science/gan-control) ships no native code: its operator socket is the
+ * module-level "if FUSED:" block of src/gan_control/models/gan_model.py:19-50, which binds the
+ * names FusedLeakyReLU / fused_leaky_relu / upfirdn2d, and falls back to ATen calls
+ * (F.conv2d, F.conv_transpose2d, F.pad, F.leaky_relu).  Each function below cites the reference
+ * lines whose arithmetic it replaces.  INTEGRATION.md shows the binding a maintainer adds.
+ */
+#ifndef GANCONTROL_HIP_H
+#define GANCONTROL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GC_ABI_VERSION 1
+
+#define GC_OK 0
+#define GC_ERR_BAD_ARG (-1)      /* null pointer, non-positive extent, inconsistent geometry */
+#define GC_ERR_UNSUPPORTED (-2)  /* legal request outside what the kernels implement */
+#define GC_ERR_HIP (-3)          /* the HIP runtime reported a launch error */
+#define GC_ERR_WORKSPACE (-4)    /* workspace too small */
+
+typedef void* gc_stream_t; /* hipStream_t */
+
+int gc_abi_version(void);
+const char* gc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * K1  upfirdn2d: zero-stuff by (up) -> pad / crop -> 2-D FIR -> decimate by (down).
+ *
+ * Replaces upfirdn2d() gan_model.py:45-50 -> upfirdn2d_native() pytorch_upfirdn2d.py:9-51
+ * (callers: Blur gan_model.py:126-129, Upsample :86-89, Downsample :107-110,
+ * non_leaking.py:338,359).
+ *
+ *   y[p,oy,ox] = sum_{a<kh, b<kw} T[a][b] * U[oy*down_y + a - pad_y0][ox*down_x + b - pad_x0]
+ *   U[v][u]    = x[p][v/up_y][u/up_x] if up_y | v, up_x | u and the source is inside, else 0
+ *   T[a][b]    = taps[kh-1-a][kw-1-b] if flip_taps (the forward op: a true convolution)
+ *              = taps[a][b]           otherwise   (the adjoint uses the un-flipped kernel)
+ *
+ * planes = N*C.  taps is a DEVICE pointer to kh*kw floats (the module's `kernel` buffer).
+ * out_h/out_w are the caller's: (in*up + pad0 + pad1 - k)/down + 1; negative pads crop.
+ * The gradient w.r.t. x is the same call with up<->down, flip_taps toggled and
+ * pad0' = k - 1 - pad0; the double-backward is the forward call again.
+ */
+int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
+                     int planes, int in_h, int in_w, int out_h, int out_w,
+                     int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                     int pad_x0, int pad_y0, int flip_taps, gc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K2  fused (noise +) bias + leaky-ReLU * gain.
+ *
+ * Replaces FusedLeakyReLU.forward gan_model.py:32-35, fused_leaky_relu gan_model.py:39-41 and,
+ * when `noise` is given, the NoiseInjection add that always precedes it
+ * (gan_model.py:340-345, 402-408).
+ *
+ *   y[b,c,i] = gain * lrelu(x[b,c,i] + bias[c] + noise_w[0] * noise[b,i], slope)
+ *
+ * inner = product of the dims after the channel dim (1 for [B,F] inputs).  bias may be null;
+ * noise ([batch, inner]) and noise_w (DEVICE scalar) are both null or both set.
+ */
+int gc_bias_act_f32(const float* x, const float* bias, const float* noise, const float* noise_w,
+                    float* y, int batch, int channels, int64_t inner,
+                    float slope, float gain, gc_stream_t stream);
+
+/* Gradient (and, being linear in dy, also the double-backward) of K2 through the activation,
+ * masked by the sign of the forward OUTPUT:
+ *   dx[i] = dy[i] * (y_ref[i] > 0 ? gain : gain * slope)
+ */
+int gc_bias_act_bwd_f32(const float* dy, const float* y_ref, float* dx, int64_t count,
+                        float slope, float gain, gc_stream_t stream);
+
+/* Per-channel sum over batch and inner dims: out[c] = sum_{b,i} x[b,c,i]  (bias gradient).
+ * Deterministic two-stage reduction; workspace must hold gc_channel_sum_workspace() bytes. */
+size_t gc_channel_sum_workspace(int batch, int channels, int64_t inner);
+int gc_channel_sum_f32(const float* x, float* out, int batch, int channels, int64_t inner,
+                       void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * K3/K4  generalised 2-D convolution on the matrix cores (v_mfma_f32_32x32x2_f32, exact fp32).
+ *
+ * One contraction covers F.conv2d (EqualConv2d.forward gan_model.py:154-160 and the plain
+ * ModulatedConv2d branch gan_model.py:325-329: up = 1, down = stride), F.conv_transpose2d
+ * (ModulatedConv2d up-sampling branch gan_model.py:295-306 and every input-gradient:
+ * up = stride, down = 1) and, through in_scale / out_scale, StyleGAN2 weight (de)modulation
+ * WITHOUT materialising per-sample weights (gan_model.py:284-293):
+ *
+ *   y[b,n,oy,ox] = out_scale[b,n] * sum_{ty,tx,k} w[ty,tx,k,n] * in_scale[b,k]
+ *                                   * U(x)[b,k, oy*down + ty - pad_y, ox*down + tx - pad_x]
+ *
+ * U zero-stuffs x by `up` as in K1.  w is [kh, kw, in_ch, out_ch] (out_ch contiguous) in
+ * CORRELATION order; in_scale [batch, in_ch] and out_scale [batch, out_ch] may be null (= 1).
+ * Supported: kh = kw in {1, 3}; (up, down) in {(1,1), (1,2), (2,1)}.
+ */
+typedef struct gc_conv_desc {
+    int32_t batch;
+    int32_t in_ch, out_ch;
+    int32_t in_h, in_w;
+    int32_t out_h, out_w;
+    int32_t kh, kw;
+    int32_t up, down;
+    int32_t pad_y, pad_x;
+} gc_conv_desc;
+
+int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,
+                  const float* in_scale, const float* out_scale, float* y, gc_stream_t stream);
+
+/* Weight gradient of the same contraction (up must be 1):
+ *
+ *   dw[ty,tx,k,n] = sum_{b,oy,ox} in_scale[b,k] * x[b,k, oy*down + ty - pad_y, ox*down + tx - pad_x]
+ *                                 * out_scale[b,n] * dy[b,n,oy,ox]
+ *
+ * Replaces the weight half of aten::convolution_backward reached from gan_model.py:154,304,327.
+ * Deterministic: partial sums go to `workspace` (gc_conv2d_wgrad_workspace() bytes) and are
+ * reduced in a fixed order.
+ */
+size_t gc_conv2d_wgrad_workspace(const gc_conv_desc* d);
+int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const float* dy,
+                        const float* in_scale, const float* out_scale, float* dw,
+                        void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GANCONTROL_HIP_H */

@@ -1,0 +1,115 @@
+"""Test configuration: import paths, the ``gpu`` marker and the CPU emulation of the C ABI.
+
+``-m "not gpu"`` runs here (no GPU): oracle vs golden vectors, host logic, the autograd wiring
+over an emulated backend, ABI symbol checks and gloo world_size-2 runs.  ``-m gpu`` runs on the
+MI355X box and calls the HIP kernels through the C ABI.  Nothing here reads /root/reference.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (REPO, os.path.join(REPO, 'gan-control_amd')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+GOLDEN = os.path.join(REPO, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    with np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def group(gold, prefix):
+    """Entries 'prefix/key' of a fixture as torch tensors keyed by 'key'."""
+    out = {}
+    for k, v in gold.items():
+        if k.startswith(prefix + '/'):
+            out[k[len(prefix) + 1:]] = torch.from_numpy(v) if v.dtype.kind in 'fiu' else v
+    return out
+
+
+def rel_err(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-30)
+
+
+class EmulatedBackend:
+    """CPU stand-in for libgancontrol_hip.so with the SAME primitive interface (tests only).
+
+    Written from the formulas in include/gancontrol_hip.h with ATen ops, independently of both
+    the oracle and the kernels, so the autograd layer can be validated without a GPU.
+    """
+    name = 'emulated'
+
+    @staticmethod
+    def _stuff_pad(x, up, pad_y0, pad_x0, ext_h, ext_w):
+        n, c, h, w = x.shape
+        u = x.new_zeros(n, c, h * up, w * up)
+        u[:, :, ::up, ::up] = x
+        u = F.pad(u, [pad_x0, 0, pad_y0, 0])
+        u = F.pad(u, [0, ext_w - u.shape[3], 0, ext_h - u.shape[2]])
+        return u
+
+    def upfirdn2d(self, x, taps, up, down, pad_x0, pad_y0, out_h, out_w, flip):
+        kh, kw = taps.shape
+        u = self._stuff_pad(x, up, pad_y0, pad_x0, (out_h - 1) * down + kh, (out_w - 1) * down + kw)
+        t = (torch.flip(taps, [0, 1]) if flip else taps).to(x.dtype)
+        n, c = x.shape[:2]
+        y = F.conv2d(u.reshape(n * c, 1, u.shape[2], u.shape[3]), t.reshape(1, 1, kh, kw), stride=down)
+        return y.reshape(n, c, out_h, out_w)
+
+    def bias_act(self, x, bias, noise, noise_w, slope, gain):
+        shape = [1, -1] + [1] * (x.ndim - 2)
+        v = x
+        if noise is not None:
+            v = v + noise_w.reshape(-1)[0] * noise.reshape([x.shape[0], 1] + list(x.shape[2:]))
+        if bias is not None:
+            v = v + bias.reshape(shape)
+        return F.leaky_relu(v, slope) * gain
+
+    def bias_act_bwd(self, dy, y_ref, slope, gain):
+        return dy * torch.where(y_ref > 0, torch.full_like(dy, gain), torch.full_like(dy, gain * slope))
+
+    def channel_sum(self, x):
+        return x.sum([d for d in range(x.ndim) if d != 1])
+
+    def conv2d(self, x, w_t, in_scale, out_scale, geom):
+        if in_scale is not None:
+            x = x * in_scale[:, :, None, None]
+        u = self._stuff_pad(x, geom.up, geom.pad_y, geom.pad_x, (geom.out_h - 1) * geom.down + geom.kh,
+                            (geom.out_w - 1) * geom.down + geom.kw)
+        y = F.conv2d(u, w_t.permute(3, 2, 0, 1), stride=geom.down)
+        assert y.shape[2:] == (geom.out_h, geom.out_w)
+        if out_scale is not None:
+            y = y * out_scale[:, :, None, None]
+        return y
+
+    def conv2d_wgrad(self, x, dy, in_scale, out_scale, geom):
+        assert geom.up == 1
+        w = torch.zeros(geom.kh, geom.kw, x.shape[1], dy.shape[1], dtype=x.dtype, requires_grad=True)
+        with torch.enable_grad():
+            y = self.conv2d(x.detach(), w, in_scale, out_scale, geom)
+            g, = torch.autograd.grad(y, w, dy.detach())
+        return g
+
+
+@pytest.fixture
+def emu_backend():
+    from gan_control_amd.models.op import _backend
+    prev = _backend._install_for_tests(EmulatedBackend())
+    yield
+    _backend._install_for_tests(prev)
+
+
+def have_gpu():
+    return torch.cuda.is_available()

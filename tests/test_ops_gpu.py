@@ -1,0 +1,181 @@
+"""Parity of the HIP kernels (through the C ABI) with the golden vectors and with the emulated
+reference formulas at shapes that cross every tile boundary.  Needs an MI355X: ``-m gpu``."""
+import pytest
+import torch
+
+import op_checks as oc
+from conftest import EmulatedBackend, rel_err
+
+pytestmark = pytest.mark.gpu
+DEV = 'cuda'
+
+
+@pytest.fixture(scope='module', autouse=True)
+def _native_loaded():
+    from gan_control_amd import _lib
+    _lib.load()          # fail loudly if the HIP library is missing: there is no fallback to hide behind
+    assert torch.cuda.is_available()
+
+
+@pytest.mark.parametrize('case', oc.names(oc.UPF))
+def test_upfirdn2d_golden(case):
+    oc.check_upfirdn2d(case, DEV)
+
+
+@pytest.mark.parametrize('case', oc.names(oc.BA))
+def test_bias_act_golden(case):
+    oc.check_bias_act(case, DEV)
+
+
+def test_noise_bias_act():
+    oc.check_noise_bias_act(DEV)
+
+
+@pytest.mark.parametrize('case', oc.names(oc.CV, 'conv_'))
+def test_equal_conv_golden(case):
+    oc.check_equal_conv(case, DEV)
+
+
+@pytest.mark.parametrize('case', oc.names(oc.CV, 'mod_'))
+def test_modulated_conv_golden(case):
+    oc.check_modulated_conv(case, DEV)
+
+
+def test_conv_functional():
+    oc.conv_functional_checks(DEV)
+
+
+def _be():
+    from gan_control_amd.models.op import _backend
+    assert _backend.get().name == 'hip'
+    return _backend.get(), EmulatedBackend()
+
+
+@pytest.mark.parametrize('shape,pad,flip', [
+    ((2, 3, 65, 130), (1, 1), True), ((1, 2, 257, 257), (1, 1), True), ((1, 4, 128, 128), (2, 2), True),
+    ((1, 4, 128, 128), (1, 1), False), ((3, 1, 33, 100), (2, 1), False), ((1, 1, 513, 513), (1, 1), True),
+    ((1, 2, 64, 64), (2, 2), True), ((2, 2, 17, 64), (1, 1), True), ((1, 1, 1025, 67), (1, 1), True)])
+def test_upfirdn2d_fast_path_shapes(shape, pad, flip):
+    hip, emu = _be()
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=gen)
+    k = torch.randn(4, 4, generator=gen)
+    oh, ow = shape[2] + pad[0] + pad[1] - 3, shape[3] + pad[0] + pad[1] - 3
+    ref = emu.upfirdn2d(x.double(), k.double(), 1, 1, pad[0], pad[0], oh, ow, flip)
+    out = hip.upfirdn2d(x.to(DEV), k.to(DEV), 1, 1, pad[0], pad[0], oh, ow, flip)
+    assert rel_err(out, ref) < 2e-6
+    # a non-16-byte-aligned output base takes the scalar-store variant
+    buf = torch.empty(out.numel() + 1, device=DEV)
+    xs = torch.empty(x.numel() + 1, device=DEV)[1:].view_as(x).copy_(x)
+    out2 = hip.upfirdn2d(xs, k.to(DEV), 1, 1, pad[0], pad[0], oh, ow, flip)
+    assert torch.equal(out2, out)
+
+
+@pytest.mark.parametrize('up,down,ksz', [(2, 1, 4), (1, 2, 4), (2, 1, 12), (1, 2, 12), (3, 2, 5), (1, 1, 3), (1, 1, 1)])
+def test_upfirdn2d_generic_shapes(up, down, ksz):
+    hip, emu = _be()
+    gen = torch.Generator().manual_seed(up * 100 + down * 10 + ksz)
+    x = torch.randn(2, 3, 37, 41, generator=gen)
+    k = torch.randn(ksz, ksz, generator=gen)
+    for p0, p1 in [(0, 0), (ksz // 2, ksz // 2), (ksz - 1, 1), (-1, 2)]:
+        oh, ow = (37 * up + p0 + p1 - ksz) // down + 1, (41 * up + p0 + p1 - ksz) // down + 1
+        if oh < 1 or ow < 1:
+            continue
+        for flip in (True, False):
+            ref = emu.upfirdn2d(x.double(), k.double(), up, down, p0, p0, oh, ow, flip)
+            out = hip.upfirdn2d(x.to(DEV), k.to(DEV), up, down, p0, p0, oh, ow, flip)
+            assert rel_err(out, ref) < 2e-6, (p0, p1, flip)
+
+
+CONV_CASES = [
+    # b, K, N, h, w, k, up, down, pad
+    (2, 8, 8, 4, 4, 3, 1, 1, 1), (2, 16, 130, 8, 8, 3, 1, 1, 1), (1, 40, 64, 16, 16, 3, 1, 1, 1),
+    (2, 32, 32, 40, 70, 3, 1, 1, 1), (1, 64, 64, 33, 65, 3, 1, 1, 1), (1, 130, 140, 20, 36, 3, 1, 1, 1),
+    (2, 3, 32, 64, 64, 1, 1, 1, 0), (2, 32, 3, 50, 50, 1, 1, 1, 0), (1, 513, 40, 4, 4, 3, 1, 1, 1),
+    (2, 24, 40, 33, 33, 3, 1, 2, 0), (1, 64, 130, 65, 129, 3, 1, 2, 0), (2, 16, 24, 31, 31, 1, 1, 2, 0),
+    (2, 9, 70, 9, 9, 3, 1, 2, 0), (1, 8, 8, 17, 17, 3, 1, 2, 0),
+    (2, 16, 24, 4, 4, 3, 2, 1, 2), (1, 40, 33, 8, 8, 3, 2, 1, 2), (2, 32, 32, 16, 16, 3, 2, 1, 2),
+    (1, 64, 40, 32, 48, 3, 2, 1, 2), (1, 12, 70, 65, 40, 3, 2, 1, 2), (2, 6, 5, 16, 16, 1, 2, 1, 0),
+    (1, 8, 8, 30, 30, 3, 2, 1, 0), (1, 8, 8, 30, 30, 3, 1, 1, 0), (1, 8, 8, 30, 30, 3, 1, 1, 2),
+]
+
+
+def _out_size(n, k, up, down, pad, transposed):
+    if up > 1:
+        return (n - 1) * up + k - 2 * (k - 1 - pad)
+    return (n + 2 * pad - k) // down + 1
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv2d_kernel(case):
+    from gan_control_amd.models.op._backend import ConvGeom
+    hip, emu = _be()
+    b, K, N, h, w, k, up, down, pad = case
+    gen = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(b, K, h, w, generator=gen)
+    wt = torch.randn(k, k, K, N, generator=gen)
+    si = torch.randn(b, K, generator=gen)
+    so = torch.rand(b, N, generator=gen) + 0.5
+    oh, ow = _out_size(h, k, up, down, pad, up > 1), _out_size(w, k, up, down, pad, up > 1)
+    geom = ConvGeom(k, k, up, down, pad, pad, oh, ow)
+    for use_scales in (False, True):
+        a = (si, so) if use_scales else (None, None)
+        ref = emu.conv2d(x.double(), wt.double(), *[None if t is None else t.double() for t in a], geom)
+        out = hip.conv2d(x.to(DEV), wt.to(DEV), *[None if t is None else t.to(DEV) for t in a], geom)
+        assert rel_err(out, ref) < 5e-6, use_scales
+    if up == 1:
+        dy = torch.randn(b, N, oh, ow, generator=gen)
+        for use_scales in (False, True):
+            a = (si, so) if use_scales else (None, None)
+            ref = emu.conv2d_wgrad(x.double(), dy.double(), *[None if t is None else t.double() for t in a], geom)
+            out = hip.conv2d_wgrad(x.to(DEV), dy.to(DEV), *[None if t is None else t.to(DEV) for t in a], geom)
+            assert rel_err(out, ref) < 5e-6, ('wgrad', use_scales)
+
+
+def test_conv2d_large_wgrad_splits():
+    """Many pixel tiles per split and several splits: the deterministic two-stage reduction."""
+    from gan_control_amd.models.op._backend import ConvGeom
+    hip, emu = _be()
+    gen = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 64, 96, 96, generator=gen)
+    dy = torch.randn(3, 64, 96, 96, generator=gen)
+    geom = ConvGeom(3, 3, 1, 1, 1, 1, 96, 96)
+    ref = emu.conv2d_wgrad(x.double(), dy.double(), None, None, geom)
+    out = hip.conv2d_wgrad(x.to(DEV), dy.to(DEV), None, None, geom)
+    assert rel_err(out, ref) < 5e-6
+    assert torch.equal(out, hip.conv2d_wgrad(x.to(DEV), dy.to(DEV), None, None, geom)), 'wgrad must be run-to-run deterministic'
+
+
+@pytest.mark.parametrize('shape', [(2, 6, 5, 7), (3, 10), (2, 3, 64, 64), (1, 5, 33, 31), (4, 512, 4, 4), (2, 32, 128, 128)])
+def test_bias_act_and_channel_sum_kernels(shape):
+    hip, emu = _be()
+    gen = torch.Generator().manual_seed(len(shape) + shape[1])
+    x = torch.randn(*shape, generator=gen)
+    b = torch.randn(shape[1], generator=gen)
+    for noise in (False, True):
+        if noise and len(shape) != 4:
+            continue
+        nz = torch.randn(shape[0], 1, *shape[2:], generator=gen) if noise else None
+        nw = torch.randn(1, generator=gen) if noise else None
+        ref = emu.bias_act(x.double(), b.double(), None if nz is None else nz.double(), None if nw is None else nw.double(), 0.2, 2 ** 0.5)
+        out = hip.bias_act(x.to(DEV), b.to(DEV), None if nz is None else nz.to(DEV), None if nw is None else nw.to(DEV), 0.2, 2 ** 0.5)
+        assert rel_err(out, ref) < 2e-6
+    y = emu.bias_act(x, b, None, None, 0.2, 2 ** 0.5)
+    dy = torch.randn(*shape, generator=gen)
+    assert rel_err(hip.bias_act_bwd(dy.to(DEV), y.to(DEV), 0.2, 2 ** 0.5), emu.bias_act_bwd(dy, y, 0.2, 2 ** 0.5)) < 2e-6
+    assert rel_err(hip.channel_sum(x.to(DEV)), emu.channel_sum(x.double())) < 1e-5
+
+
+@pytest.mark.parametrize('size', [32, 64, 256])
+def test_network_golden(size):
+    oc.check_network(size, DEV)
+
+
+def test_error_reporting():
+    from gan_control_amd.models.op._backend import ConvGeom
+    hip, _ = _be()
+    x = torch.zeros(1, 4, 8, 8, device=DEV)
+    with pytest.raises(RuntimeError, match='taps'):
+        hip.conv2d(x, torch.zeros(5, 5, 4, 4, device=DEV), None, None, ConvGeom(5, 5, 1, 1, 2, 2, 8, 8))
+    with pytest.raises(RuntimeError):
+        hip.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2), 1, 1, 0, 0, 3, 3, True)   # CPU tensor: refused
