@@ -1,0 +1,181 @@
+#!/usr/bin/env python3
+"""bench.py -- images/sec of the full G+D training step on synthetic FFHQ-shaped batches.
+
+One process per GPU.  ``python bench.py`` runs N=1; for N>1 the driver launches it with
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (RCCL).
+
+A "step" is one iteration of the reference loop (generator_trainer.py:351-353):
+discriminator_update + generator_update with d_every=1, g_reg_every=4, d_reg_every=16,
+path_batch_shrink=2 (ffhq.json:74-81), vanilla semantics, lazy regularisers included at their
+cadence (the iteration counter keeps running through warm-up so i % 4 / i % 16 line up).
+
+Workload (BASELINE.json): FFHQ 1024x1024, 4 images per GPU -- config[2]'s "batch=32 DDP on 8 GPUs"
+at N=8, the same per-GPU work at N=1/2/4 (weak scaling).  ``--size 512 --batch-per-gpu 16`` gives
+config[1].  Everything inside the timed region is real: G and D forward/backward through the HIP
+kernels, R1 / path-length double-backward, Adam steps, EMA, gradient all-reduce.
+
+Rank 0 prints ONE JSON line with the contract fields plus
+  "roofline":      the dominant kernel's achieved TFLOP/s (algorithmic flops / HIP-event time on the
+                   launch stream, measured inside the timed region) against the fp32 MFMA peak,
+  "cpu_baseline":  the oracle (CPU restatement of the reference FUSED=False path) timed on the
+                   host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, 'gan-control_amd'))
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=32)
+    ap.add_argument('--warmup', type=int, default=16)
+    ap.add_argument('--size', type=int, default=1024)
+    ap.add_argument('--batch-per-gpu', type=int, default=4)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--cpu-baseline-size', type=int, default=None, help='resolution of the CPU sample (default: --size)')
+    return ap.parse_args()
+
+
+def cpu_baseline(size):
+    """Time the oracle's D step + G step at batch 1 on the host cores (kind = "port")."""
+    from gan_control_amd.models.gan_model import Generator, Discriminator
+    from oracle.step import OracleStep
+    import warnings
+    warnings.filterwarnings('ignore')
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    g = Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True)
+    d = Discriminator(size, channel_multiplier=2)
+    o = OracleStep(g.state_dict(), d.state_dict(), size, 1)
+    gen = torch.Generator().manual_seed(0)
+    real = torch.rand(1, 3, size, size, generator=gen) * 2 - 1
+    reps, t0 = 0, time.perf_counter()
+    while True:
+        o.d_step(real, torch.randn(1, 512, generator=gen))
+        o.g_step(torch.randn(1, 512, generator=gen))
+        reps += 1
+        el = time.perf_counter() - t0
+        if el >= 10.0 or reps >= 3:
+            break
+    return {'value': reps / el, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
+            'sample': f'{reps} x (D step + G step, no lazy regularisers) at {size}x{size}, batch 1, fp32, '
+                      f'oracle/step.py OracleStep on {cores} host threads, {el:.1f} s'}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)')
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+
+    from gan_control_amd import _lib
+    _lib.load()                                   # fail loudly without the HIP library
+    from gan_control_amd.models.op import _backend
+    from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
+    from gan_control_amd.utils.profiling import KernelTimer
+
+    cfg = default_config(args.size, args.batch_per_gpu * world)
+    trainer = GeneratorTrainer(cfg, device=f'cuda:{local_rank}', seed=0)
+    real = trainer.synthetic_batch()              # resident in HBM before the timed region
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    it = 0
+    for _ in range(args.warmup):
+        trainer.train_iteration(it, real)
+        it += 1
+    timer = None
+    if rank == 0 and not args.no_kernel_timer:
+        timer = KernelTimer()
+        _backend.get().timer = timer
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        trainer.train_iteration(it, real)
+        it += 1
+    barrier()
+    elapsed = time.perf_counter() - t0
+    _backend.get().timer = None
+
+    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    stats = trainer.reduced_stats()
+
+    if rank == 0:
+        images = args.steps * args.batch_per_gpu * world
+        out = {
+            'metric': 'images/sec G+D step FFHQ-%d' % args.size, 'value': images / elapsed, 'unit': 'images/sec',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': 'FFHQ %dx%d full G+D train step (D step, G step, lazy R1 every 16 and path-length every 4, '
+                                   'Adam, EMA), %d images/GPU, fp32 storage and fp32 MFMA' % (args.size, args.size, args.batch_per_gpu),
+                       'global_batch': args.batch_per_gpu * world, 'parallelism': 'dp%d' % world},
+            'losses': {k: round(v, 5) for k, v in stats.items()},
+        }
+        if timer is not None:
+            summ = timer.summary()
+            convs = {k: v for k, v in summ.items() if k.startswith('conv_mfma_kernel')}
+            kernels = {}
+            for k, v in summ.items():
+                unit_tf = k.startswith('conv_mfma') or k.startswith('wgrad')
+                rate = v['work'] / (v['total_ms'] * 1e-3) / (1e12 if unit_tf else 1e9)
+                kernels[k] = {'launches': v['launches'], 'avg_us': round(v['avg_us'], 2), 'total_ms': round(v['total_ms'], 2),
+                              'achieved': round(rate, 2), 'unit': 'TFLOP/s' if unit_tf else 'GB/s'}
+            out['kernels'] = kernels
+            if convs:
+                name, dom = max(convs.items(), key=lambda kv: kv[1]['total_ms'])
+                ach = dom['work'] / (dom['total_ms'] * 1e-3) / 1e12
+                out['roofline'] = {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': PEAK_FP32_MFMA_TFLOPS, 'unit': 'TFLOP/s',
+                                   'frac': ach / PEAK_FP32_MFMA_TFLOPS, 'traffic': None,
+                                   'launches': dom['launches'], 'avg_launch_us': dom['avg_us'],
+                                   'gpu_time_share': dom['total_ms'] / (1e3 * elapsed)}
+            fir = summ.get('fir44_tile_kernel')
+            if fir:
+                ach = fir['work'] / (fir['total_ms'] * 1e-3) / 1e9
+                out['roofline_hbm'] = {'bound': 'hbm', 'kernel': 'fir44_tile_kernel', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
+                                       'frac': ach / PEAK_HBM_GBS, 'traffic': None, 'launches': fir['launches'], 'avg_launch_us': fir['avg_us']}
+        if not args.no_cpu_baseline and world == 1:
+            out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_size or args.size)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -17,6 +17,7 @@ ConvGeom = namedtuple('ConvGeom', 'kh kw up down pad_y pad_x out_h out_w')
 
 class HipBackend:
     name = 'hip'
+    timer = None          # optional utils.profiling.KernelTimer (bench.py); None in normal operation
 
     @staticmethod
     def _guard(dev):
@@ -32,6 +33,7 @@ class HipBackend:
             return y
         lib = _lib.load()
         g = self._guard(dev)
+        t0 = self.timer.start() if self.timer else None
         if g: g.__enter__()
         try:
             rc = lib.gc_upfirdn2d_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n * c, h, w, out_h, out_w,
@@ -39,6 +41,9 @@ class HipBackend:
         finally:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_upfirdn2d_f32')
+        if t0 is not None:
+            fast = up == 1 and down == 1 and tuple(taps.shape) == (4, 4) and out_w >= 64 and out_h >= 16
+            self.timer.stop('fir44_tile_kernel' if fast else 'upfirdn2d_generic_kernel', t0, 4.0 * (x.numel() + y.numel()))
         return y
 
     def bias_act(self, x, bias, noise, noise_w, slope, gain):
@@ -51,6 +56,7 @@ class HipBackend:
         inner = x.numel() // (batch * ch)
         lib = _lib.load()
         g = self._guard(dev)
+        t0 = self.timer.start() if self.timer else None
         if g: g.__enter__()
         try:
             rc = lib.gc_bias_act_f32(_lib.ptr(x), _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(y),
@@ -58,6 +64,8 @@ class HipBackend:
         finally:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_bias_act_f32')
+        if t0 is not None:
+            self.timer.stop('bias_act_kernel', t0, 4.0 * (2 * x.numel() + ch + (noise.numel() if noise is not None else 0)))
         return y
 
     def bias_act_bwd(self, dy, y_ref, slope, gain):
@@ -110,12 +118,16 @@ class HipBackend:
         desc = self._desc(x, n_out, geom)
         lib = _lib.load()
         g = self._guard(dev)
+        t0 = self.timer.start() if self.timer else None
         if g: g.__enter__()
         try:
             rc = lib.gc_conv2d_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(y), _lib.stream_of(x))
         finally:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_conv2d_f32')
+        if t0 is not None:
+            from ...utils.profiling import conv_variant, conv_flops
+            self.timer.stop(conv_variant(geom, n_out), t0, conv_flops(x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom))
         return y
 
     def conv2d_wgrad(self, x, dy, in_scale, out_scale, geom):
@@ -128,6 +140,7 @@ class HipBackend:
         nbytes = lib.gc_conv2d_wgrad_workspace(desc)
         ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
         g = self._guard(dev)
+        t0 = self.timer.start() if self.timer else None
         if g: g.__enter__()
         try:
             rc = lib.gc_conv2d_wgrad_f32(desc, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(dw),
@@ -135,6 +148,9 @@ class HipBackend:
         finally:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_conv2d_wgrad_f32')
+        if t0 is not None:
+            from ...utils.profiling import conv_flops
+            self.timer.stop('wgrad_mfma_kernel(+reduce)', t0, conv_flops(x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom))
         return dw
 
 

@@ -1,0 +1,295 @@
+"""The G+D training step of gan-control, data-parallel over the GPUs of one node.
+
+Reproduces the step maths of the reference's GeneratorTrainer
+(src/gan_control/trainers/generator_trainer.py) with ``vanilla`` semantics (no predictor
+losses -- those need pretrained networks that are not part of the hot path):
+
+  train loop          :329-355      discriminator_update :626-643   generator_update :357-369
+  discriminator_step  :645-688      discriminator_regularize_step :697-711   d_r1_loss :713-719
+  generator_step      :407-436      generator_regularize_step :568-599
+  g_path_regularize_grad :617-624   Adam set-up :161-173            dry_run :301-327
+
+including the quirks listed in SURVEY.md Appendix C (D loss divided by the mini-batch image
+count, regularisers firing at i = 0, ``+ 0 * pred[0]`` terms, name sets for set_grad_none).
+Multi-GPU is one process per GPU with RCCL gradient all-reduce (trainers/ddp.py) instead of
+nn.DataParallel; the config dictionary keeps the reference's JSON schema (configs/ffhq.json).
+"""
+import copy
+import math
+
+import torch
+from torch import autograd, optim
+from torch.nn import functional as F
+
+from ..models.gan_model import Generator, Discriminator
+from ..utils.fc_config import fc_config_from_sub_groups
+from . import ddp
+from .utils import accumulate, requires_grad, mixing_noise, make_mini_batch_from_noise, set_grad_none
+
+
+def default_config(size=512, batch=16):
+    """The hot-path fields of configs/ffhq.json:5-84 (vanilla, regular mapping network)."""
+    return {
+        'model_config': {'vanilla': True, 'img_channels': 3, 'split_fc': False, 'marge_fc': False, 'latent_size': 512,
+                         'size': size, 'n_mlp': 8, 'channel_multiplier': 2.0, 'conv_transpose': True, 'g_noise_mode': 'normal'},
+        'training_config': {'parallel_grad_regularize_step': True, 'iter': 800000, 'start_iter': 0, 'batch': batch,
+                            'mini_batch': batch, 'augment': {'enabled': False, 'ada_target': 0.6, 'ada_length': 500000, 'p': 0},
+                            'r1': 1, 'd_every': 1, 'g_reg_every': 4, 'd_reg_every': 16, 'lr_g': 0.002, 'lr_d': 0.002,
+                            'g_moving_average': 10000, 'path_regularize': 2, 'path_batch_shrink': 2, 'mixing': 0,
+                            'parallel': True, 'sub_groups_dict': None},
+    }
+
+
+def none_grad_names(generator, discriminator):
+    """Parameters the reference's dry_run (:301-327) finds with ``grad is None`` under the regularisers.
+
+    They are exactly the parameters that enter the output additively (no second-order path):
+    every ToRGB bias of G and the last linear bias of D (pinned by
+    tests/golden/step.npz).
+    """
+    none_g = {n for n, _ in generator.named_parameters() if n.split('.')[-1] == 'bias' and n.startswith('to_rgb') and '.conv.' not in n}
+    none_d = {n for n, _ in discriminator.named_parameters() if n == 'final_linear.1.bias'}
+    return none_g, none_d
+
+
+class GeneratorTrainer:
+    def __init__(self, config, device='cuda', seed=0, fused_adam=None):
+        self.config = config
+        self.model_config = config['model_config']
+        self.training_config = config['training_config']
+        self.device = torch.device(device)
+        self.world = ddp.world_size()
+        self.rank = ddp.rank()
+        tc = self.training_config
+        if tc['batch'] % self.world != 0:
+            raise ValueError('global batch %d is not divisible by the world size %d' % (tc['batch'], self.world))
+        self.local_batch = tc['batch'] // self.world
+        # the reference chunks the global batch into mini-batches on ONE process; here each rank
+        # takes its shard of every mini-batch
+        if tc['mini_batch'] % self.world != 0:
+            raise ValueError('mini_batch %d is not divisible by the world size %d' % (tc['mini_batch'], self.world))
+        self.local_mini_batch = tc['mini_batch'] // self.world
+        if self.local_mini_batch >= 4 and self.local_mini_batch % 4 != 0:
+            raise ValueError('per-GPU mini-batch must be a multiple of 4 (minibatch-stddev groups, gan_model.py:1005-1011)')
+        self.gen = torch.Generator(device=self.device)
+        self.gen.manual_seed(seed * 1000 + self.rank)
+        torch.manual_seed(seed)          # identical initial weights on every rank
+        self.init_models_and_optim(fused_adam)
+        self.dry_run()
+        self.mean_path_length = 0
+        self.accum = 0.5 ** (tc['batch'] / tc['g_moving_average'])
+        self.stats = {}
+
+    # -- set-up ---------------------------------------------------------------------------------
+    def init_models_and_optim(self, fused_adam=None):
+        mc, tc = self.model_config, self.training_config
+        fc = None
+        if mc['split_fc'] or mc['marge_fc']:
+            fc = fc_config_from_sub_groups(tc['sub_groups_dict'], mc['latent_size'])
+        kw = dict(channel_multiplier=mc['channel_multiplier'], out_channels=mc['img_channels'], split_fc=mc['split_fc'],
+                  marge_fc=mc['marge_fc'], fc_config=fc, conv_transpose=mc['conv_transpose'], noise_mode=mc['g_noise_mode'])
+        self.generator = Generator(mc['size'], mc['latent_size'], mc['n_mlp'], **kw).to(self.device)
+        self.g_ema = Generator(mc['size'], mc['latent_size'], mc['n_mlp'], **kw).to(self.device)
+        self.discriminator = Discriminator(mc['size'], channel_multiplier=mc['channel_multiplier'], in_channels=mc['img_channels']).to(self.device)
+        self.g_ema.eval()
+        for m in (self.generator, self.g_ema, self.discriminator):
+            ddp.broadcast_module(m)
+        accumulate(self.g_ema, self.generator, 0)
+        g_ratio = tc['g_reg_every'] / (tc['g_reg_every'] + 1)
+        d_ratio = tc['d_reg_every'] / (tc['d_reg_every'] + 1)
+        if fused_adam is None:
+            fused_adam = self.device.type == 'cuda'
+        extra = {'fused': True} if fused_adam else {}
+        self.g_optim = optim.Adam(self.generator.parameters(), lr=tc['lr_g'] * g_ratio, betas=(0 ** g_ratio, 0.99 ** g_ratio), **extra)
+        self.d_optim = optim.Adam(self.discriminator.parameters(), lr=tc['lr_d'] * d_ratio, betas=(0 ** d_ratio, 0.99 ** d_ratio), **extra)
+        self.g_module, self.d_module, self.g_ema_module = self.generator, self.discriminator, self.g_ema
+        self.g_reducer = ddp.GradientReducer(self.generator)
+        self.d_reducer = ddp.GradientReducer(self.discriminator)
+
+    def dry_run(self):
+        self.none_g_grads, self.none_d_grads = none_grad_names(self.generator, self.discriminator)
+
+    def state_dict(self):
+        """Checkpoint layout of save_nets (:852-865) plus the state the reference forgets (Appendix C #4)."""
+        return {'g': self.generator.state_dict(), 'd': self.discriminator.state_dict(), 'g_ema': self.g_ema.state_dict(),
+                'g_optim': self.g_optim.state_dict(), 'd_optim': self.d_optim.state_dict(),
+                'mean_path_length': float(self.mean_path_length)}
+
+    def load_state_dict(self, ckpt):
+        self.generator.load_state_dict(ckpt['g'])
+        self.discriminator.load_state_dict(ckpt['d'])
+        self.g_ema.load_state_dict(ckpt['g_ema'])
+        self.g_optim.load_state_dict(ckpt['g_optim'])
+        self.d_optim.load_state_dict(ckpt['d_optim'])
+        if 'mean_path_length' in ckpt:
+            self.mean_path_length = torch.tensor(ckpt['mean_path_length'], device=self.device)
+
+    # -- losses (names and maths of the reference's static methods) ------------------------------
+    @staticmethod
+    def d_logistic_loss(real_pred, fake_pred):
+        return F.softplus(-real_pred).mean() + F.softplus(fake_pred).mean()
+
+    @staticmethod
+    def g_nonsaturating_loss(fake_pred):
+        return F.softplus(-fake_pred).mean()
+
+    @staticmethod
+    def d_r1_loss(real_pred, real_img):
+        grad_real, = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+        return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
+
+    @staticmethod
+    def g_path_regularize_grad(grad, mean_path_length, decay=0.01, reduce_mean=None):
+        """Path-length penalty (:617-624).  With ``reduce_mean`` (an in-place mean all-reduce) the running
+        mean uses the GLOBAL batch mean and the returned penalty carries exactly the gradient the
+        single-process formula has on the global batch: the (small) term that flows through
+        ``path_lengths.mean()`` is re-expressed with the all-reduced mean as a constant."""
+        path_lengths = torch.sqrt(grad.pow(2).sum(2).mean(1))
+        if reduce_mean is None:
+            path_mean = mean_path_length + decay * (path_lengths.mean() - mean_path_length)
+            path_penalty = (path_lengths - path_mean).pow(2).mean()
+            return path_penalty, path_mean.detach(), path_lengths
+        global_mean = reduce_mean(path_lengths.detach().mean())
+        path_mean = mean_path_length + decay * (global_mean - mean_path_length)
+        path_penalty = (path_lengths - path_mean).pow(2).mean()
+        through_mean = 2 * decay * (global_mean - path_mean) * path_lengths.mean()
+        path_penalty = path_penalty - (through_mean - through_mean.detach())
+        return path_penalty, path_mean.detach(), path_lengths
+
+    # -- helpers --------------------------------------------------------------------------------
+    def sample_z(self, batch):
+        tc = self.training_config
+        return mixing_noise(batch, self.model_config['latent_size'], tc['mixing'], self.device, self.gen)
+
+    @staticmethod
+    def _fill_missing_grads(module, none_names):
+        """Reference autograd yields ZERO (not None) gradients for parameters that only reach a
+        regulariser through an activation mask (Appendix C #6), so Adam still steps them on
+        momentum.  The fused ops cut those dead paths; restore the zeros here."""
+        for n, p in module.named_parameters():
+            if p.requires_grad and p.grad is None and n not in none_names:
+                p.grad = torch.zeros_like(p)
+
+    # -- discriminator ----------------------------------------------------------------------------
+    def discriminator_step(self, mini_noise_inputs, mini_real_inputs, noise=None):
+        self.stats['d_loss'] = 0
+        self.discriminator.zero_grad(set_to_none=True)
+        n = len(mini_real_inputs)
+        for k, (real, z) in enumerate(zip(mini_real_inputs, mini_noise_inputs)):
+            self.d_reducer.begin(sync=(k == n - 1))
+            fake_img, _ = self.generator(z, noise=noise)
+            fake_pred, _ = self.discriminator(fake_img)
+            real_pred, _ = self.discriminator(real)
+            d_loss = self.d_logistic_loss(real_pred, fake_pred)
+            # reference divides by the number of IMAGES in the (global) mini-batch (:658)
+            d_loss = d_loss / (len(real) * self.world)
+            self.stats['d_loss'] = self.stats['d_loss'] + d_loss.detach()
+            d_loss.backward()
+        self._fill_missing_grads(self.discriminator, ())
+        self.d_reducer.finish()
+        self.d_optim.step()
+        self.last_real_pred = real_pred.detach()
+
+    def discriminator_regularize_step(self, mini_real_inputs):
+        tc = self.training_config
+        self.stats['d_r1_loss'] = 0
+        self.discriminator.zero_grad(set_to_none=True)
+        n = len(mini_real_inputs)
+        for k, real in enumerate(mini_real_inputs):
+            self.d_reducer.begin(sync=(k == n - 1))
+            real = real.detach().requires_grad_(True)
+            real_pred, _ = self.discriminator(real)
+            r1_loss = self.d_r1_loss(real_pred, real) / n
+            self.stats['d_r1_loss'] = self.stats['d_r1_loss'] + r1_loss.detach()
+            (tc['r1'] / 2 * r1_loss * tc['d_reg_every'] + 0 * real_pred[0]).backward()
+            set_grad_none(self.discriminator, self.none_d_grads)
+        self._fill_missing_grads(self.discriminator, self.none_d_grads)
+        self.d_reducer.finish()
+        self.d_optim.step()
+
+    def discriminator_update(self, i, real_img, noise=None):
+        tc = self.training_config
+        mini_real = real_img.chunk(max(1, self.local_batch // self.local_mini_batch))
+        requires_grad(self.generator, False)
+        requires_grad(self.discriminator, True)
+        mini_z = make_mini_batch_from_noise(self.sample_z(self.local_batch), self.local_batch, self.local_mini_batch)
+        if i % tc['d_every'] == 0:
+            self.discriminator_step(mini_z, mini_real, noise=noise)
+        if i % tc['d_reg_every'] == 0:
+            self.discriminator_regularize_step(mini_real)
+
+    # -- generator ----------------------------------------------------------------------------------
+    def generator_step(self, mini_noise_inputs, noise=None):
+        self.stats['g_adv_loss'] = 0
+        self.generator.zero_grad(set_to_none=True)
+        n = len(mini_noise_inputs)
+        for k, z in enumerate(mini_noise_inputs):
+            self.g_reducer.begin(sync=(k == n - 1))
+            fake_img, _ = self.generator(z, noise=noise)
+            fake_pred, _ = self.discriminator(fake_img)
+            g_loss = self.g_nonsaturating_loss(fake_pred) / n
+            self.stats['g_adv_loss'] = self.stats['g_adv_loss'] + g_loss.detach()
+            g_loss.backward()
+        self._fill_missing_grads(self.generator, ())
+        self.g_reducer.finish()
+        self.g_optim.step()
+
+    def generator_regularize_step(self, noise=None, pl_noise=None, z=None):
+        tc = self.training_config
+        path_batch = max(1, self.local_batch // tc['path_batch_shrink'])
+        if z is None:
+            z = self.sample_z(path_batch)
+        # the reference chunks the path batch with the full-batch chunk count (:574-575)
+        mini_z = make_mini_batch_from_noise(z, self.local_batch, self.local_mini_batch)
+        self.generator.zero_grad(set_to_none=True)
+        n = len(mini_z)
+        reduce_mean = ddp.all_reduce_mean_ if ddp.is_dist() else None
+        for k, zk in enumerate(mini_z):
+            self.g_reducer.begin(sync=(k == n - 1))
+            fake_img, latent = self.generator(zk, noise=noise, return_latents=True)
+            grad = Generator.g_path_regularize_grad(fake_img, latent, pl_noise=pl_noise)
+            path_loss, self.mean_path_length, path_lengths = self.g_path_regularize_grad(grad, self.mean_path_length, reduce_mean=reduce_mean)
+            path_loss = path_loss / n
+            weighted = tc['path_regularize'] * tc['g_reg_every'] * path_loss
+            if tc['path_batch_shrink']:
+                weighted = weighted + 0 * fake_img[0, 0, 0, 0]
+            weighted.backward()
+            set_grad_none(self.generator, self.none_g_grads)
+            self.stats['g_path_loss'] = path_loss.detach()
+            self.stats['g_path_length'] = path_lengths.detach().mean()
+            self.stats['g_mean_path_length'] = self.mean_path_length
+            self.stats['path_lengths'] = path_lengths.detach()
+        self._fill_missing_grads(self.generator, self.none_g_grads)
+        self.g_reducer.finish()
+        self.g_optim.step()
+
+    def generator_update(self, i, noise=None):
+        tc = self.training_config
+        requires_grad(self.generator, True)
+        requires_grad(self.discriminator, False)
+        mini_z = make_mini_batch_from_noise(self.sample_z(self.local_batch), self.local_batch, self.local_mini_batch)
+        self.generator_step(mini_z, noise=noise)
+        if i % tc['g_reg_every'] == 0:
+            self.generator_regularize_step(noise=noise)
+        accumulate(self.g_ema_module, self.g_module, self.accum)
+
+    # -- one iteration ------------------------------------------------------------------------------
+    def train_iteration(self, i, real_img):
+        """discriminator_update -> generator_update (EMA inside), as the loop at :351-353."""
+        self.discriminator_update(i, real_img)
+        self.generator_update(i)
+
+    def reduced_stats(self):
+        """Scalar statistics averaged over ranks (what the reference logs from its single process)."""
+        out = {}
+        for k, v in self.stats.items():
+            if torch.is_tensor(v) and v.numel() == 1:
+                out[k] = float(ddp.all_reduce_mean_(v.detach().clone().float()))
+            elif not torch.is_tensor(v):
+                out[k] = float(v)
+        return out
+
+    def synthetic_batch(self):
+        """FFHQ-shaped stand-in for the data loader: float32 NCHW uniform in [-1, 1] (ffhq_dataset.py:62-63)."""
+        mc = self.model_config
+        return torch.rand(self.local_batch, mc['img_channels'], mc['size'], mc['size'], device=self.device, generator=self.gen) * 2 - 1

@@ -1,0 +1,66 @@
+"""Per-launch timing of the hot kernels with HIP events on the launch stream.
+
+bench.py installs a KernelTimer on the HIP backend; every conv / wgrad / upfirdn2d / bias_act
+launch is then bracketed by two events recorded on the stream the kernel is launched on
+(torch's current stream), and its ALGORITHMIC work is tallied next to it:
+
+  conv / wgrad   flops = 2 * B * OC * IC * kh * kw * H_out * W_out   (transposed: ... * H_in * W_in)
+  upfirdn2d      bytes = (numel_in + numel_out) * 4
+  bias_act       bytes = (numel_in + numel_out) * 4 + C * 4 (+ B * inner * 4 with noise)
+"""
+import collections
+
+import torch
+
+
+def conv_variant(geom, n_out):
+    """Name of the conv_mfma_kernel instantiation gc_conv2d_f32 selects (csrc/conv.hip, gc_conv2d_f32)."""
+    qw = -(-geom.out_w // geom.up)
+    if qw <= 4:
+        return 'conv_mfma_kernel<4,1,1,1,4>'
+    if qw <= 8:
+        return 'conv_mfma_kernel<4,1,1,1,8>'
+    if qw <= 16:
+        return 'conv_mfma_kernel<2,2,2,2,16>'
+    if n_out <= 32:
+        return 'conv_mfma_kernel<1,4,1,4,32>'
+    if n_out <= 64:
+        return 'conv_mfma_kernel<1,4,2,2,32>'
+    return 'conv_mfma_kernel<2,2,2,2,32>'
+
+
+def conv_flops(batch, k_in, n_out, in_h, in_w, geom):
+    px = in_h * in_w if geom.up > 1 else geom.out_h * geom.out_w
+    return 2.0 * batch * k_in * n_out * geom.kh * geom.kw * px
+
+
+class KernelTimer:
+    def __init__(self):
+        self.records = []          # (name, start_event, end_event, work)
+        self.enabled = True
+
+    def start(self):
+        if not self.enabled:
+            return None
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, name, start, work):
+        if start is None:
+            return
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.records.append((name, start, e, work))
+
+    def summary(self):
+        """name -> dict(launches, total_ms, avg_us, work) ; call after torch.cuda.synchronize()."""
+        acc = collections.OrderedDict()
+        for name, s, e, work in self.records:
+            d = acc.setdefault(name, {'launches': 0, 'total_ms': 0.0, 'work': 0.0})
+            d['launches'] += 1
+            d['total_ms'] += s.elapsed_time(e)
+            d['work'] += work
+        for d in acc.values():
+            d['avg_us'] = 1e3 * d['total_ms'] / max(d['launches'], 1)
+        return acc

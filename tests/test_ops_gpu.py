@@ -179,3 +179,8 @@ def test_error_reporting():
         hip.conv2d(x, torch.zeros(5, 5, 4, 4, device=DEV), None, None, ConvGeom(5, 5, 1, 1, 2, 2, 8, 8))
     with pytest.raises(RuntimeError):
         hip.upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2), 1, 1, 0, 0, 3, 3, True)   # CPU tensor: refused
+
+
+def test_step_golden():
+    import step_checks
+    step_checks.check_step(DEV)
