@@ -14,19 +14,24 @@
 //   im2col duplication -- plus the [taps][KC][OCT] weight slab.  Per-sample modulation is applied
 //   while staging (x * in_scale[b,k]) and in the epilogue (* out_scale[b,oc]); the per-sample
 //   [B*OC, IC, k, k] weight tensor of the reference is never formed.
+//   Software pipeline: the global loads of chunk c+1 are issued into registers BEFORE the MFMA
+//   block of chunk c and written to LDS after it, so HBM/L2 latency hides under the matrix work
+//   (64 cycles per MFMA) even with one workgroup per CU.  Geometry (taps, up, down) is a template
+//   parameter: every staging index is a compile-time division.
 //   up = 2 (transposed conv) is decomposed into its up*up output phases: each workgroup handles
 //   one phase, whose taps are the subset {ty : (phase + ty - pad) % up == 0} -- no multiplies by
 //   stuffed zeros.
+//   Small planes (<= 16 px wide) use KSPLIT = 4: one 32oc x 32px tile per workgroup, the four
+//   waves split the channel pairs of every chunk and are summed through LDS at the end.
 //
 // wgrad_mfma_kernel (weight gradient)
 //   dW[tap][k][n] = sum_px X[k][px + tap] * dY[n][px]: A = input patch (lane -> channel k),
 //   B = dY tile (lane -> channel n), reduction over pixels.  Each wave owns a 32x32 (k, n) block
 //   for ALL taps (<= 9 accumulators = 144 registers), so dY is read from LDS once per pixel pair.
-//   The pixel space is split across workgroups; partial sums are written to a workspace and
-//   reduced in fixed order by wgrad_reduce_kernel (deterministic, no atomics).
+//   Same register-prefetch pipeline over pixel tiles.  The pixel space is split across
+//   workgroups; partial sums go to a workspace and are reduced in fixed order by
+//   wgrad_reduce_kernel (deterministic, no atomics).
 #include "common.h"
-
-#include <mutex>
 
 namespace {
 
@@ -36,57 +41,88 @@ constexpr int KC = 8;  // input channels staged per LDS chunk (forward kernel)
 
 struct ConvArgs {
     const float* x; const float* w; const float* si; const float* so; float* y;
-    int B, K, N, in_h, in_w, out_h, out_w, kh, kw, up, down, pad_y, pad_x;
+    int B, K, N, in_h, in_w, out_h, out_w, pad_y, pad_x;
     int tiles_x, tiles_y;     // pixel tiles per phase sub-grid (sized for phase 0, the largest)
-    int pp;                   // patch row pitch (floats)
-    int ph_max;               // patch rows allocated
 };
 
 // Taps of one output phase along one axis: tap index t0 + j*up, source offset d0 + j, j < n.
 struct AxisTaps { int t0, n, d0; };
-__device__ __forceinline__ AxisTaps axis_taps(int phase, int k, int up, int pad) {
+template <int UP, int KS>
+__device__ __forceinline__ AxisTaps axis_taps(int phase, int pad) {
     AxisTaps a;
-    a.t0 = gc::pos_mod(pad - phase, up);
-    a.n = a.t0 < k ? (k - a.t0 + up - 1) / up : 0;
-    a.d0 = gc::floor_div(phase + a.t0 - pad, up);
+    if (UP == 1) { a.t0 = 0; a.n = KS; a.d0 = -pad; return a; }
+    a.t0 = gc::pos_mod(pad - phase, UP);
+    a.n = a.t0 < KS ? (KS - a.t0 + UP - 1) / UP : 0;
+    a.d0 = gc::floor_div(phase + a.t0 - pad, UP);
     return a;
 }
 
-template <int WG_OC, int WG_PX, int WOC, int WPX, int TPW>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
-    constexpr int OCT = WG_OC * WOC * 32;      // output channels per workgroup
-    constexpr int RPB = 32 / TPW;              // tile rows covered by one 32-pixel MFMA column block
-    constexpr int TPH = WG_PX * WPX * RPB;     // tile rows per workgroup
-    static_assert(WG_OC * WG_PX == 4, "4 waves per workgroup");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int patch_pitch(int width, int tpw) {
+    // distinct LDS banks for the (32/tpw) rows one MFMA column block touches: pitch == tpw (mod 32)
+    if (tpw == 32) return width | 1;
+    int pp = width;
+    while (pp % 32 != tpw) ++pp;
+    return pp;
+}
+
+template <int WG_OC, int WG_PX, int KSPLIT, int WOC, int WPX, int TPW, int UP, int DOWN, int KS>
+struct ConvCfg {
+    static constexpr int OCT = WG_OC * WOC * 32;           // output channels per workgroup
+    static constexpr int RPB = 32 / TPW;                   // tile rows covered by one 32-pixel MFMA column block
+    static constexpr int TPH = WG_PX * WPX * RPB;          // tile rows per workgroup
+    static constexpr int NT1 = UP == 1 ? KS : (KS + UP - 1) / UP;   // max taps per axis in one phase
+    static constexpr int PH = (TPH - 1) * DOWN + NT1;      // patch rows
+    static constexpr int PWD = (TPW - 1) * DOWN + NT1;     // patch columns
+    static constexpr int PP = patch_pitch(PWD, TPW);       // patch row pitch
+    static constexpr int PLANE = PH * PP;
+    static constexpr int WL = NT1 * NT1 * KC * OCT;        // weight slab floats
+    static constexpr int PATCH = KC * PLANE;
+    static constexpr int RED = KSPLIT > 1 ? 4 * WOC * WPX * 16 * 64 : 0;
+    static constexpr int SMEM = cmax(WL + PATCH, RED);
+    static constexpr int NPE = (KC * PH * PWD + 255) / 256;   // patch elements prefetched per thread
+    static constexpr int F4 = OCT / 4;                        // float4 per weight row
+    static constexpr int RPI = 256 / F4;                      // weight rows per staging iteration
+    static constexpr int NWI = (NT1 * NT1 * KC + RPI - 1) / RPI;
+};
+
+// Fresh, optimiser-opaque copy of a lane value: staging index arithmetic written in terms of it is
+// recomputed where it is used (a few dozen VALU ops per chunk) instead of being hoisted out of the
+// K loop into dozens of live registers, which would cost a wave of occupancy.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+template <int WG_OC, int WG_PX, int KSPLIT, int WOC, int WPX, int TPW, int UP, int DOWN, int KS>
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
+    using C = ConvCfg<WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW, UP, DOWN, KS>;
+    static_assert(WG_OC * WG_PX * KSPLIT == 4, "4 waves per workgroup");
+    static_assert(UP == 1 || DOWN == 1, "up and down are exclusive");
+    constexpr int OCT = C::OCT, RPB = C::RPB, TPH = C::TPH, PH = C::PH, PWD = C::PWD, PP = C::PP, PLANE = C::PLANE;
+    __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
+    float* wl = smem;                 // [tap][KC][OCT]
+    float* patch = smem + C::WL;      // [KC][PH][PP]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wave_oc = wave / WG_PX, wave_px = wave % WG_PX;
+    const int wave_k = wave % KSPLIT, wave_px = (wave / KSPLIT) % WG_PX, wave_oc = wave / (KSPLIT * WG_PX);
 
     // ---- decode the workgroup: (tile_x, tile_y, phase, sample) x n-tile ----
     int bid = blockIdx.x;
     const int tile_x = bid % p.tiles_x; bid /= p.tiles_x;
     const int tile_y = bid % p.tiles_y; bid /= p.tiles_y;
-    const int nph = p.up * p.up;
-    const int phase = bid % nph;
-    const int b = bid / nph;
-    const int phy = phase / p.up, phx = phase % p.up;
+    const int phase = bid % (UP * UP);
+    const int b = bid / (UP * UP);
+    const int phy = phase / UP, phx = phase % UP;
     const int n0 = blockIdx.y * OCT;
-    const int qh = (p.out_h - phy + p.up - 1) / p.up, qw = (p.out_w - phx + p.up - 1) / p.up;
+    const int qh = (p.out_h - phy + UP - 1) / UP, qw = (p.out_w - phx + UP - 1) / UP;
     const int qy0 = tile_y * TPH, qx0 = tile_x * TPW;
     if (qy0 >= qh || qx0 >= qw) return;
 
-    const AxisTaps ay = axis_taps(phy, p.kh, p.up, p.pad_y), ax = axis_taps(phx, p.kw, p.up, p.pad_x);
+    const AxisTaps ay = axis_taps<UP, KS>(phy, p.pad_y), ax = axis_taps<UP, KS>(phx, p.pad_x);
     const int ntaps = ay.n * ax.n;
-    const int PH = (TPH - 1) * p.down + (ay.n > 0 ? ay.n : 1);
-    const int PWd = (TPW - 1) * p.down + (ax.n > 0 ? ax.n : 1);
-    const int PP = p.pp;
-    const int iy0 = qy0 * p.down + ay.d0, ix0 = qx0 * p.down + ax.d0;
-
-    float* wl = smem;                                   // [ntaps][KC][OCT]
-    float* patch = smem + p.kh * p.kw * KC * OCT;       // [KC][PH][PP]
-    const int plane = p.ph_max * PP;
+    const int iy0 = qy0 * DOWN + ay.d0, ix0 = qx0 * DOWN + ax.d0;
 
     f32x16 acc[WOC][WPX];
 #pragma unroll
@@ -101,78 +137,134 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         const int row = (wave_px * WPX + j) * RPB + l31 / TPW, col = l31 % TPW;
-        boff[j] = hi * plane + row * p.down * PP + col * p.down;
+        boff[j] = hi * PLANE + row * DOWN * PP + col * DOWN;
     }
     const int aoff = hi * OCT + wave_oc * WOC * 32 + l31;
 
     const float* xb = p.x + (size_t)b * p.K * p.in_h * p.in_w;
     const float* sib = p.si ? p.si + (size_t)b * p.K : nullptr;
     const bool wvec = (p.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0);
+    const int chan = p.in_h * p.in_w;          // host guarantees K * H * W < 2^31
 
-    for (int k0 = 0; k0 < p.K && ntaps > 0; k0 += KC) {
-        // ---- stage weights: wl[t][kk][nn] = w[ty][tx][k0+kk][n0+nn] ----
-        if (wvec) {
-            const int total4 = ntaps * KC * (OCT / 4);
-            for (int idx = tid; idx < total4; idx += 256) {
-                const int nn4 = idx % (OCT / 4);
-                const int rest = idx / (OCT / 4);
-                const int kk = rest % KC, t = rest / KC;
-                const int ty = ay.t0 + (t / ax.n) * p.up, tx = ax.t0 + (t % ax.n) * p.up;
-                const int k = k0 + kk, n = n0 + nn4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < p.K && n < p.N) v = *reinterpret_cast<const float4*>(p.w + ((size_t)(ty * p.kw + tx) * p.K + k) * p.N + n);
-                *reinterpret_cast<float4*>(wl + (t * KC + kk) * OCT + nn4 * 4) = v;
-            }
-        } else {
-            const int total = ntaps * KC * OCT;
-            for (int idx = tid; idx < total; idx += 256) {
-                const int nn = idx % OCT;
-                const int rest = idx / OCT;
-                const int kk = rest % KC, t = rest / KC;
-                const int ty = ay.t0 + (t / ax.n) * p.up, tx = ax.t0 + (t % ax.n) * p.up;
-                const int k = k0 + kk, n = n0 + nn;
-                float v = 0.f;
-                if (k < p.K && n < p.N) v = p.w[((size_t)(ty * p.kw + tx) * p.K + k) * p.N + n];
-                wl[idx] = v;
-            }
-        }
-        // ---- stage the input patch (zero outside the image), modulated by in_scale ----
-        for (int rowid = wave; rowid < KC * PH; rowid += 4) {
-            const int kk = rowid / PH, r = rowid - kk * PH;
-            const int k = k0 + kk, iy = iy0 + r;
-            const bool rowok = k < p.K && iy >= 0 && iy < p.in_h;
-            const float sc = (rowok && sib) ? sib[k] : 1.f;
-            const float* src = xb + ((size_t)k * p.in_h + iy) * p.in_w;
-            float* dst = patch + kk * plane + r * PP;
-            for (int c = lane; c < PWd; c += 64) {
-                const int ix = ix0 + c;
-                float v = 0.f;
-                if (rowok && ix >= 0 && ix < p.in_w) v = src[ix] * sc;
-                dst[c] = v;
-            }
-        }
-        __syncthreads();
-        // ---- MFMA over taps x channel pairs ----
-        for (int jy = 0; jy < ay.n; ++jy) {
-            for (int jx = 0; jx < ax.n; ++jx) {
-                const float* wt = wl + (jy * ax.n + jx) * KC * OCT + aoff;
-                const float* pt = patch + jy * PP + jx;
+    float4 wreg[C::NWI];
+    float preg[C::NPE], sreg[C::NPE];   // raw patch values and their in_scale factors (multiplied at commit time)
+
+    auto prefetch = [&](int k0) {
+        const int t_ = opaque(tid);
+        const int wcol = (t_ % C::F4) * 4, wrow0 = t_ / C::F4;
+        // weights: row = (tap, kk), F4 float4 per row
 #pragma unroll
-                for (int kp = 0; kp < KC / 2; ++kp) {
-                    float a[WOC], bv[WPX];
-#pragma unroll
-                    for (int i = 0; i < WOC; ++i) a[i] = wt[kp * 2 * OCT + i * 32];
-#pragma unroll
-                    for (int j = 0; j < WPX; ++j) bv[j] = pt[kp * 2 * plane + boff[j]];
-#pragma unroll
-                    for (int i = 0; i < WOC; ++i)
-#pragma unroll
-                        for (int j = 0; j < WPX; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < C::NWI; ++j) {
+            const int row = wrow0 + C::RPI * j;
+            const int t = row / KC, kk = row % KC;
+            const int jy = UP == 1 ? t / KS : (ax.n == 2 ? t >> 1 : t), jx = UP == 1 ? t % KS : (ax.n == 2 ? t & 1 : 0);
+            const int ty = ay.t0 + jy * UP, tx = ax.t0 + jx * UP;
+            const int k = k0 + kk, n = n0 + wcol;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (t < ntaps && k < p.K) {
+                const float* src = p.w + ((ty * KS + tx) * p.K + k) * p.N + n;
+                if (wvec) {
+                    if (n < p.N) v = *reinterpret_cast<const float4*>(src);
+                } else {
+                    if (n < p.N) v.x = src[0];
+                    if (n + 1 < p.N) v.y = src[1];
+                    if (n + 2 < p.N) v.z = src[2];
+                    if (n + 3 < p.N) v.w = src[3];
                 }
             }
+            wreg[j] = v;
         }
+        // input patch: element e = tid + 256 j -> (kk, r, c), zero outside the image
+#pragma unroll
+        for (int j = 0; j < C::NPE; ++j) {
+            const int e = t_ + 256 * j;
+            const int kk = e / (PH * PWD), pos = e % (PH * PWD);
+            const int r = pos / PWD, c = pos % PWD;
+            const int k = k0 + kk, iy = iy0 + r, ix = ix0 + c;
+            float v = 0.f, sc = 1.f;
+            if (e < KC * PH * PWD && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
+                v = xb[k * chan + iy * p.in_w + ix];
+                if (sib) sc = sib[k];
+            }
+            preg[j] = v;
+            sreg[j] = sc;
+        }
+    };
+    auto commit = [&]() {
+        const int t_ = opaque(tid);
+        const int wcol = (t_ % C::F4) * 4, wrow0 = t_ / C::F4;
+#pragma unroll
+        for (int j = 0; j < C::NWI; ++j) {
+            const int row = wrow0 + C::RPI * j;
+            if (row < C::NT1 * C::NT1 * KC) *reinterpret_cast<float4*>(wl + row * OCT + wcol) = wreg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < C::NPE; ++j) {
+            const int e = t_ + 256 * j;
+            const int kk = e / (PH * PWD), pos = e % (PH * PWD);
+            const int r = pos / PWD, c = pos % PWD;
+            if (e < KC * PH * PWD) patch[kk * PLANE + r * PP + c] = preg[j] * sreg[j];
+        }
+    };
+
+    if (ntaps > 0) {
+        prefetch(0);
+        commit();
         __syncthreads();
+        for (int k0 = 0; k0 < p.K; k0 += KC) {
+            const bool more = k0 + KC < p.K;
+            if (more) prefetch(k0 + KC);
+            // ---- MFMA over taps x channel pairs ----
+            const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
+            for (int jy = 0; jy < nty; ++jy) {
+                for (int jx = 0; jx < ntx; ++jx) {
+                    const float* wt = wl + (jy * ntx + jx) * KC * OCT + aoff;
+                    const float* pt = patch + jy * PP + jx;
+#pragma unroll
+                    for (int kp = wave_k; kp < KC / 2; kp += KSPLIT) {
+                        float a[WOC], bv[WPX];
+#pragma unroll
+                        for (int i = 0; i < WOC; ++i) a[i] = wt[kp * 2 * OCT + i * 32];
+#pragma unroll
+                        for (int j = 0; j < WPX; ++j) bv[j] = pt[kp * 2 * PLANE + boff[j]];
+#pragma unroll
+                        for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                            for (int j = 0; j < WPX; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+                    }
+                }
+            }
+            __syncthreads();
+            if (more) {
+                commit();
+                __syncthreads();
+            }
+        }
+    }
+
+    if (KSPLIT > 1) {
+        // sum the channel-pair partitions of the four waves through LDS
+        float* red = smem;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < WOC; ++i)
+#pragma unroll
+            for (int j = 0; j < WPX; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wave * WOC * WPX + i * WPX + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+        __syncthreads();
+        if (wave_k != 0) return;
+#pragma unroll
+        for (int i = 0; i < WOC; ++i)
+#pragma unroll
+            for (int j = 0; j < WPX; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = acc[i][j][r];
+                    for (int o = 1; o < KSPLIT; ++o) s += red[(((wave + o) * WOC * WPX + i * WPX + j) * 16 + r) * 64 + lane];
+                    acc[i][j][r] = s;
+                }
     }
 
     // ---- epilogue: demodulate and store; lanes 0..31 of a register are consecutive pixels ----
@@ -182,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
     for (int j = 0; j < WPX; ++j) {
         const int qy = qy0 + (wave_px * WPX + j) * RPB + l31 / TPW, qx = qx0 + l31 % TPW;
         if (qy >= qh || qx >= qw) continue;
-        const int oy = qy * p.up + phy, ox = qx * p.up + phx;
+        const int oy = qy * UP + phy, ox = qx * UP + phx;
 #pragma unroll
         for (int i = 0; i < WOC; ++i) {
 #pragma unroll
@@ -201,28 +293,42 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs p) {
 // --------------------------------------------------------------------------------------------
 struct WgradArgs {
     const float* x; const float* dy; const float* si; const float* so; float* ws;
-    int B, K, N, in_h, in_w, out_h, out_w, kh, kw, down, pad_y, pad_x;
+    int B, K, N, in_h, in_w, out_h, out_w, pad_y, pad_x;
     int tiles_x, tiles_y;     // pixel tiles per sample
-    int splits;               // workgroups along the pixel axis
     int tiles_per_split;
-    int pp, csx, csy;         // patch row pitch, channel strides of the two LDS tiles (odd: conflict-free)
 };
 
-template <int WK, int WN, int WP, int TR, int NT>
-__global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs p) {
-    constexpr int KT = WK * 32, NTL = WN * 32;   // channel tiles of the workgroup
-    constexpr int TPW = 32;                      // pixel tile: TR rows x 32 columns
+constexpr int wgrad_tile_w(int down, int ks) { return ks == 3 ? 30 : 32; }   // patch row = 32 (down 1) / <= 64 (down 2) floats
+
+template <int WK, int WN, int WP, int TR, int DOWN, int KS>
+struct WgradCfg {
+    static constexpr int KT = WK * 32, NTL = WN * 32;    // channel tiles of the workgroup
+    static constexpr int TPW = wgrad_tile_w(DOWN, KS);   // pixel tile: TR rows x TPW columns (even)
+    static constexpr int PH = (TR - 1) * DOWN + KS, PWD = (TPW - 1) * DOWN + KS;
+    static constexpr int PWL = PWD <= 32 ? 32 : 64;      // patch row pitch: power of two -> shift/mask staging indices
+    static constexpr int CSX = (PH * PWL) | 1;           // odd channel strides: conflict-free lane -> channel reads
+    static constexpr int CSY = (TR * 32) | 1;
+    static constexpr int NX = KT * PH * PWL, NY = NTL * TR * 32;
+    static constexpr int NPX = NX / 256, NPY = NY / 256;
+    static constexpr int SMEM = KT * CSX + NTL * CSY;
+    static constexpr int NT = KS * KS;
+};
+
+template <int WK, int WN, int WP, int TR, int DOWN, int KS>
+__global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
+    using C = WgradCfg<WK, WN, WP, TR, DOWN, KS>;
+    constexpr int KT = C::KT, NTL = C::NTL, TPW = C::TPW, PH = C::PH, PWD = C::PWD, PWL = C::PWL, NT = C::NT;
     static_assert(WK * WN * WP == 4, "4 waves per workgroup");
     static_assert(TR % WP == 0, "rows split evenly over the pixel waves");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* xs = smem;                        // [KT][PH][PP]  (channel stride csx)
-    float* ds = smem + KT * p.csx;           // [NTL][TR*32]  (channel stride csy)
+    static_assert(C::NX % 256 == 0 && C::NY % 256 == 0, "staging loops are exact");
+    __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
+    float* xs = smem;                        // [KT][PH][PWL]  (channel stride CSX)
+    float* ds = smem + KT * C::CSX;          // [NTL][TR][32]  (channel stride CSY)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wp = wave % WP, wn = (wave / WP) % WN, wk = wave / (WP * WN);
     const int k0 = blockIdx.x * KT, n0 = blockIdx.y * NTL, split = blockIdx.z;
-    const int PH = (TR - 1) * p.down + p.kh, PWd = (TPW - 1) * p.down + p.kw;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -234,63 +340,93 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(WgradArgs p) {
     const int total_tiles = tiles_per_sample * p.B;
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
+    const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;   // host guarantees C * H * W < 2^31
 
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    float xreg[C::NPX], yreg[C::NPY];
+    auto prefetch = [&](int tile) {
+        const int t_ = opaque(tid);
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
         const int oy0 = (rem / p.tiles_x) * TR, ox0 = (rem % p.tiles_x) * TPW;
-        const int iy0 = oy0 * p.down - p.pad_y, ix0 = ox0 * p.down - p.pad_x;
-        // ---- stage x patch: xs[kk][r][c] = x[b, k0+kk, iy0+r, ix0+c] * si[b,k] ----
-        for (int rowid = wave; rowid < KT * PH; rowid += 4) {
-            const int kk = rowid / PH, r = rowid - kk * PH;
-            const int k = k0 + kk, iy = iy0 + r;
-            const bool rowok = k < p.K && iy >= 0 && iy < p.in_h;
-            const float sc = (rowok && p.si) ? p.si[(size_t)b * p.K + k] : 1.f;
-            const float* src = p.x + (((size_t)b * p.K + k) * p.in_h + iy) * p.in_w;
-            float* dst = xs + kk * p.csx + r * p.pp;
-            for (int c = lane; c < PWd; c += 64) {
-                const int ix = ix0 + c;
-                float v = 0.f;
-                if (rowok && ix >= 0 && ix < p.in_w) v = src[ix] * sc;
-                dst[c] = v;
-            }
-        }
-        // ---- stage dy tile: ds[nn][r*32 + c] = dy[b, n0+nn, oy0+r, ox0+c] * so[b,n] ----
-        for (int rowid = wave; rowid < NTL * TR; rowid += 4) {
-            const int nn = rowid / TR, r = rowid - nn * TR;
-            const int n = n0 + nn, oy = oy0 + r;
-            const bool rowok = n < p.N && oy < p.out_h;
-            const float sc = (rowok && p.so) ? p.so[(size_t)b * p.N + n] : 1.f;
-            const float* src = p.dy + (((size_t)b * p.N + n) * p.out_h + oy) * p.out_w;
-            float* dst = ds + nn * p.csy + r * TPW;
-            if (lane < TPW) {
-                const int ox = ox0 + lane;
-                dst[lane] = (rowok && ox < p.out_w) ? src[ox] * sc : 0.f;
-            }
-        }
-        __syncthreads();
-        // ---- MFMA: reduction over the pixels of this tile; this wave takes rows r = wp, wp+WP, ... ----
-        const float* xa = xs + (wk * 32 + l31) * p.csx;
-        const float* db = ds + (wn * 32 + l31) * p.csy;
-        for (int r = wp; r < TR; r += WP) {
-#pragma unroll 4
-            for (int c = 0; c < TPW; c += 2) {
-                const int col = c + hi;
-                const float bv = db[r * TPW + col];
-                const float* xr = xa + r * p.down * p.pp + col * p.down;
+        const int iy0 = oy0 * DOWN - p.pad_y, ix0 = ox0 * DOWN - p.pad_x;
+        const float* xb = p.x + (size_t)b * p.K * xchan;
+        const float* yb = p.dy + (size_t)b * p.N * ychan;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const int ty = t / (NT == 9 ? 3 : 1), tx = t % (NT == 9 ? 3 : 1);
-                    const float av = xr[ty * p.pp + tx];
-                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+        for (int j = 0; j < C::NPX; ++j) {
+            const int e = t_ + 256 * j;
+            const int c = e % PWL, row = e / PWL;
+            const int r = row % PH, kk = row / PH;
+            const int k = k0 + kk, iy = iy0 + r, ix = ix0 + c;
+            float v = 0.f;
+            if (c < PWD && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
+                v = xb[k * xchan + iy * p.in_w + ix];
+                if (p.si) v *= p.si[(size_t)b * p.K + k];
+            }
+            xreg[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < C::NPY; ++j) {
+            const int e = t_ + 256 * j;
+            const int c = e % 32, row = e / 32;
+            const int r = row % TR, nn = row / TR;
+            const int n = n0 + nn, oy = oy0 + r, ox = ox0 + c;
+            float v = 0.f;
+            if (c < TPW && n < p.N && oy < p.out_h && ox < p.out_w) {
+                v = yb[n * ychan + oy * p.out_w + ox];
+                if (p.so) v *= p.so[(size_t)b * p.N + n];
+            }
+            yreg[j] = v;
+        }
+    };
+    auto commit = [&]() {
+        const int t_ = opaque(tid);
+#pragma unroll
+        for (int j = 0; j < C::NPX; ++j) {
+            const int e = t_ + 256 * j;
+            const int kk = e / (PH * PWL);
+            xs[kk * C::CSX + e % (PH * PWL)] = xreg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < C::NPY; ++j) {
+            const int e = t_ + 256 * j;
+            const int nn = e / (TR * 32);
+            ds[nn * C::CSY + e % (TR * 32)] = yreg[j];
+        }
+    };
+
+    if (t_begin < t_end) {
+        prefetch(t_begin);
+        commit();
+        __syncthreads();
+        const float* xa = xs + (wk * 32 + l31) * C::CSX;
+        const float* db = ds + (wn * 32 + l31) * C::CSY;
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            const bool more = tile + 1 < t_end;
+            if (more) prefetch(tile + 1);
+            // ---- MFMA: reduction over the pixels of this tile; this wave takes rows r = wp, wp+WP, ... ----
+            for (int r = wp; r < TR; r += WP) {
+#pragma unroll 2
+                for (int c = 0; c < TPW; c += 2) {
+                    const int col = c + hi;
+                    const float bv = db[r * 32 + col];
+                    const float* xr = xa + r * DOWN * PWL + col * DOWN;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) {
+                        const float av = xr[(t / KS) * PWL + (t % KS)];
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
+                    }
                 }
             }
+            __syncthreads();
+            if (more) {
+                commit();
+                __syncthreads();
+            }
         }
-        __syncthreads();
     }
 
     // ---- partial result: ws[split*WP + wp][tap][k][n]; lanes 0..31 = consecutive n ----
-    float* out = p.ws + (size_t)(split * WP + wp) * p.kh * p.kw * p.K * p.N;
+    float* out = p.ws + (size_t)(split * WP + wp) * NT * p.K * p.N;
     const int n = n0 + wn * 32 + l31;
     if (n < p.N) {
 #pragma unroll
@@ -321,58 +457,57 @@ int validate(const gc_conv_desc* d, const char* who, bool wgrad) {
     const bool ok = (d->up == 1 && (d->down == 1 || d->down == 2)) || (d->up == 2 && d->down == 1);
     if (!ok) return gc::fail(GC_ERR_UNSUPPORTED, "%s: up=%d down=%d", who, d->up, d->down);
     if (wgrad && d->up != 1) return gc::fail(GC_ERR_UNSUPPORTED, "%s: up must be 1 (swap the operands for a transposed conv)", who);
+    const long long lim = 2147483647LL;
+    if ((long long)d->in_ch * d->in_h * d->in_w > lim || (long long)d->out_ch * d->out_h * d->out_w > lim ||
+        (long long)d->kh * d->kw * d->in_ch * d->out_ch > lim)
+        return gc::fail(GC_ERR_UNSUPPORTED, "%s: a per-sample plane set exceeds 2^31 elements", who);
     return GC_OK;
 }
 
-int patch_pitch(int width, int tpw) {
-    // distinct LDS banks for the (32/tpw) rows one MFMA column block touches: pitch == tpw (mod 32)
-    if (tpw == 32) return width | 1;
-    int pp = width;
-    while (pp % 32 != tpw) ++pp;
-    return pp;
-}
-
-template <typename K>
-int ensure_lds(K kernel, size_t bytes, const char* who) {
-    if (bytes > 160 * 1024) return gc::fail(GC_ERR_UNSUPPORTED, "%s: needs %zu bytes of LDS", who, bytes);
-    if (bytes > 48 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-        if (e != hipSuccess) return gc::fail(GC_ERR_HIP, "%s: hipFuncSetAttribute: %s", who, hipGetErrorString(e));
-    }
-    return GC_OK;
-}
-
-template <int WG_OC, int WG_PX, int WOC, int WPX, int TPW>
+template <int WG_OC, int WG_PX, int KSPLIT, int WOC, int WPX, int TPW, int UP, int DOWN, int KS>
 int launch_conv(ConvArgs a, hipStream_t s) {
-    constexpr int OCT = WG_OC * WOC * 32, RPB = 32 / TPW, TPH = WG_PX * WPX * RPB;
-    const int qh = gc::ceil_div(a.out_h, a.up), qw = gc::ceil_div(a.out_w, a.up);
-    a.tiles_y = gc::ceil_div(qh, TPH);
+    using C = ConvCfg<WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW, UP, DOWN, KS>;
+    const int qh = gc::ceil_div(a.out_h, UP), qw = gc::ceil_div(a.out_w, UP);
+    a.tiles_y = gc::ceil_div(qh, C::TPH);
     a.tiles_x = gc::ceil_div(qw, TPW);
-    const int ntx_max = a.up == 1 ? a.kw : gc::ceil_div(a.kw, a.up), nty_max = a.up == 1 ? a.kh : gc::ceil_div(a.kh, a.up);
-    a.ph_max = (TPH - 1) * a.down + nty_max;
-    a.pp = patch_pitch((TPW - 1) * a.down + ntx_max, TPW);
-    const size_t lds = ((size_t)a.kh * a.kw * KC * OCT + (size_t)KC * a.ph_max * a.pp) * sizeof(float);
-    auto kern = conv_mfma_kernel<WG_OC, WG_PX, WOC, WPX, TPW>;
-    int rc = ensure_lds(kern, lds, "gc_conv2d_f32");
-    if (rc) return rc;
-    const long long gx = (long long)a.tiles_x * a.tiles_y * a.up * a.up * a.B;
+    const long long gx = (long long)a.tiles_x * a.tiles_y * UP * UP * a.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_f32: grid too large");
-    dim3 grid((unsigned)gx, gc::ceil_div(a.N, OCT));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    dim3 grid((unsigned)gx, gc::ceil_div(a.N, C::OCT));
+    hipLaunchKernelGGL((conv_mfma_kernel<WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW, UP, DOWN, KS>), grid, dim3(256), 0, s, a);
     return gc::check_launch("gc_conv2d_f32");
 }
 
-struct WgradPlan { int wk, wn, wp, tr, splits, tiles_per_split, tiles_x, tiles_y, parts; };
+// tile configuration: by phase sub-grid width, output channels and how many workgroups result
+template <int UP, int DOWN, int KS>
+int dispatch_conv(const ConvArgs& a, hipStream_t s) {
+    const int qw = gc::ceil_div(a.out_w, UP), qh = gc::ceil_div(a.out_h, UP);
+    if (qw <= 4) return launch_conv<1, 1, 4, 1, 1, 4, UP, DOWN, KS>(a, s);
+    if (qw <= 8) return launch_conv<1, 1, 4, 1, 1, 8, UP, DOWN, KS>(a, s);
+    if (qw <= 16) return launch_conv<1, 1, 4, 1, 1, 16, UP, DOWN, KS>(a, s);
+    if constexpr (DOWN == 2) {
+        if (a.N <= 64) return launch_conv<2, 2, 1, 1, 1, 32, UP, DOWN, KS>(a, s);
+    } else {
+        if (a.N <= 32) return launch_conv<1, 4, 1, 1, 4, 32, UP, DOWN, KS>(a, s);
+        if (a.N <= 64) return launch_conv<1, 4, 1, 2, 2, 32, UP, DOWN, KS>(a, s);
+    }
+    // 128oc x (4 rows x 32 px) tiles unless that leaves most CUs idle
+    const long long big = (long long)gc::ceil_div(qw, 32) * gc::ceil_div(qh, 4) * UP * UP * a.B * gc::ceil_div(a.N, 128);
+    if (big < 512) return launch_conv<2, 2, 1, 1, 1, 32, UP, DOWN, KS>(a, s);
+    return launch_conv<2, 2, 1, 2, 2, 32, UP, DOWN, KS>(a, s);
+}
+
+struct WgradPlan { int cfg, kt, nt, wp, tr, splits, tiles_per_split, tiles_x, tiles_y, parts; };
 
 WgradPlan plan_wgrad(const gc_conv_desc* d) {
     WgradPlan pl;
-    const bool small = d->in_ch <= 32 && d->out_ch <= 32;
-    pl.wk = small ? 1 : 2; pl.wn = small ? 1 : 2; pl.wp = small ? 4 : 1;
-    pl.tr = small ? 4 : 2;
-    pl.tiles_x = gc::ceil_div(d->out_w, 32);
+    // cfg 0: 64k x 64n per workgroup; cfg 1: 32k x 32n with the four waves splitting the pixel rows
+    pl.cfg = (d->in_ch <= 32 && d->out_ch <= 32 && d->down == 1) ? 1 : 0;
+    pl.kt = pl.cfg ? 32 : 64; pl.nt = pl.cfg ? 32 : 64; pl.wp = pl.cfg ? 4 : 1;
+    pl.tr = pl.cfg ? 4 : ((d->down == 2 || d->kh == 3) ? 1 : 2);   // 64x64x9-tap tiles: one row keeps 144 accumulators + prefetch in 256 VGPRs
+    pl.tiles_x = gc::ceil_div(d->out_w, wgrad_tile_w(d->down, d->kh));
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
-    const int ctiles = gc::ceil_div(d->in_ch, pl.wk * 32) * gc::ceil_div(d->out_ch, pl.wn * 32);
+    const int ctiles = gc::ceil_div(d->in_ch, pl.kt) * gc::ceil_div(d->out_ch, pl.nt);
     int want = gc::ceil_div(1024, ctiles);          // ~4 workgroups per CU over the whole grid
     if (want > total) want = total;
     if (want < 1) want = 1;
@@ -380,6 +515,16 @@ WgradPlan plan_wgrad(const gc_conv_desc* d) {
     pl.splits = gc::ceil_div(total, pl.tiles_per_split);
     pl.parts = pl.splits * pl.wp;
     return pl;
+}
+
+template <int DOWN, int KS>
+int dispatch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
+    dim3 grid(gc::ceil_div(a.K, pl.kt), gc::ceil_div(a.N, pl.nt), pl.splits);
+    if (DOWN == 1 && pl.cfg == 1)
+        hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 4, 4, 1, KS>), grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL((wgrad_mfma_kernel<2, 2, 1, ((DOWN == 2 || KS == 3) ? 1 : 2), DOWN, KS>), grid, dim3(256), 0, s, a);
+    return gc::check_launch("gc_conv2d_wgrad_f32(mfma)");
 }
 
 }  // namespace
@@ -391,15 +536,14 @@ extern "C" int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float*
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_f32: null pointer");
     if (d->batch == 0) return GC_OK;
     ConvArgs a{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
-               d->kh, d->kw, d->up, d->down, d->pad_y, d->pad_x, 0, 0, 0, 0};
+               d->pad_y, d->pad_x, 0, 0};
     hipStream_t s = (hipStream_t)stream;
-    const int qw = gc::ceil_div(d->out_w, d->up);
-    if (qw <= 4) return launch_conv<4, 1, 1, 1, 4>(a, s);
-    if (qw <= 8) return launch_conv<4, 1, 1, 1, 8>(a, s);
-    if (qw <= 16) return launch_conv<2, 2, 2, 2, 16>(a, s);
-    if (d->out_ch <= 32) return launch_conv<1, 4, 1, 4, 32>(a, s);
-    if (d->out_ch <= 64) return launch_conv<1, 4, 2, 2, 32>(a, s);
-    return launch_conv<2, 2, 2, 2, 32>(a, s);
+    if (d->kh == 3) {
+        if (d->up == 2) return dispatch_conv<2, 1, 3>(a, s);
+        return d->down == 2 ? dispatch_conv<1, 2, 3>(a, s) : dispatch_conv<1, 1, 3>(a, s);
+    }
+    if (d->up == 2) return dispatch_conv<2, 1, 1>(a, s);
+    return d->down == 2 ? dispatch_conv<1, 2, 1>(a, s) : dispatch_conv<1, 1, 1>(a, s);
 }
 
 extern "C" size_t gc_conv2d_wgrad_workspace(const gc_conv_desc* d) {
@@ -424,26 +568,9 @@ extern "C" int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const 
     const size_t need = gc_conv2d_wgrad_workspace(d);
     if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_f32: workspace %zu < %zu bytes", workspace_bytes, need);
     WgradArgs a{x, dy, in_scale, out_scale, static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w,
-                d->out_h, d->out_w, d->kh, d->kw, d->down, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.splits, pl.tiles_per_split, 0, 0, 0};
-    const int PH = (pl.tr - 1) * d->down + d->kh, PWd = 31 * d->down + d->kw;
-    a.pp = PWd;
-    a.csx = (PH * a.pp) | 1;
-    a.csy = (pl.tr * 32) | 1;
-    const int KT = pl.wk * 32, NTL = pl.wn * 32;
-    const size_t lds = ((size_t)KT * a.csx + (size_t)NTL * a.csy) * sizeof(float);
-    dim3 grid(gc::ceil_div(d->in_ch, KT), gc::ceil_div(d->out_ch, NTL), pl.splits);
-#define GC_WGRAD(WK, WN, WP, TR, NT)                                                          \
-    do {                                                                                      \
-        auto kern = wgrad_mfma_kernel<WK, WN, WP, TR, NT>;                                    \
-        rc = ensure_lds(kern, lds, "gc_conv2d_wgrad_f32");                                    \
-        if (rc) return rc;                                                                    \
-        hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);                                 \
-    } while (0)
-    const bool small = pl.wp == 4;
-    if (d->kh == 3) { if (small) GC_WGRAD(1, 1, 4, 4, 9); else GC_WGRAD(2, 2, 1, 2, 9); }
-    else            { if (small) GC_WGRAD(1, 1, 4, 4, 1); else GC_WGRAD(2, 2, 1, 2, 1); }
-#undef GC_WGRAD
-    rc = gc::check_launch("gc_conv2d_wgrad_f32(mfma)");
+                d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
+    if (d->kh == 3) rc = d->down == 2 ? dispatch_wgrad<2, 3>(a, pl, s) : dispatch_wgrad<1, 3>(a, pl, s);
+    else            rc = d->down == 2 ? dispatch_wgrad<2, 1>(a, pl, s) : dispatch_wgrad<1, 1>(a, pl, s);
     if (rc) return rc;
     const int blocks = (int)std::min<size_t>((count + 255) / 256, 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(workspace), dw, count, pl.parts);

@@ -36,14 +36,24 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
 #pragma unroll
         for (int b = 0; b < 4; ++b) T[a][b] = flip ? taps[(3 - a) * 4 + (3 - b)] : taps[a * 4 + b];
 
-    // stage the patch: consecutive lanes -> consecutive floats of one input row
+    // stage the patch: consecutive lanes -> consecutive floats of one input row.  All loads are issued
+    // before the first LDS write so their latencies overlap (19 independent dword loads per lane).
     const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
-    for (int idx = tid; idx < PH * PITCH; idx += 256) {
+    constexpr int NLD = (PH * PITCH + 255) / 256;
+    float stage[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + 256 * j;
         const int r = idx / PITCH, c = idx - r * PITCH;
         const int iy = iy0 + r, ix = ix0 + c;
         float v = 0.f;
-        if (c < PW && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(size_t)iy * in_w + ix];
-        patch[idx] = v;
+        if (idx < PH * PITCH && c < PW && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(size_t)iy * in_w + ix];
+        stage[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < PH * PITCH) patch[idx] = stage[j];
     }
     __syncthreads();
 

@@ -13,20 +13,28 @@ import collections
 import torch
 
 
-def conv_variant(geom, n_out):
-    """Name of the conv_mfma_kernel instantiation gc_conv2d_f32 selects (csrc/conv.hip, gc_conv2d_f32)."""
-    qw = -(-geom.out_w // geom.up)
-    if qw <= 4:
-        return 'conv_mfma_kernel<4,1,1,1,4>'
-    if qw <= 8:
-        return 'conv_mfma_kernel<4,1,1,1,8>'
+def conv_variant(geom, n_out, batch=1):
+    """Name of the conv_mfma_kernel tile configuration gc_conv2d_f32 selects (csrc/conv.hip, dispatch_conv).
+
+    Template arguments: <WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW>; the (up, down, taps) triple follows.
+    """
+    qw, qh = -(-geom.out_w // geom.up), -(-geom.out_h // geom.up)
+    geo = '|up%d,down%d,k%d' % (geom.up, geom.down, geom.kh)
     if qw <= 16:
-        return 'conv_mfma_kernel<2,2,2,2,16>'
-    if n_out <= 32:
-        return 'conv_mfma_kernel<1,4,1,4,32>'
-    if n_out <= 64:
-        return 'conv_mfma_kernel<1,4,2,2,32>'
-    return 'conv_mfma_kernel<2,2,2,2,32>'
+        tpw = 4 if qw <= 4 else (8 if qw <= 8 else 16)
+        return 'conv_mfma_kernel<1,1,4,1,1,%d>' % tpw + geo
+    if geom.down == 2:
+        if n_out <= 64:
+            return 'conv_mfma_kernel<2,2,1,1,1,32>' + geo
+    else:
+        if n_out <= 32:
+            return 'conv_mfma_kernel<1,4,1,1,4,32>' + geo
+        if n_out <= 64:
+            return 'conv_mfma_kernel<1,4,1,2,2,32>' + geo
+    big = -(-qw // 32) * -(-qh // 4) * geom.up * geom.up * batch * -(-n_out // 128)
+    if big < 512:
+        return 'conv_mfma_kernel<2,2,1,1,1,32>' + geo
+    return 'conv_mfma_kernel<2,2,1,2,2,32>' + geo
 
 
 def conv_flops(batch, k_in, n_out, in_h, in_w, geom):
