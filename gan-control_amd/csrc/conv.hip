@@ -298,31 +298,33 @@ struct WgradArgs {
     int tiles_per_split;
 };
 
-constexpr int wgrad_tile_w(int down, int ks) { return ks == 3 ? 30 : 32; }   // patch row = 32 (down 1) / <= 64 (down 2) floats
-
 template <int WK, int WN, int WP, int TR, int DOWN, int KS>
 struct WgradCfg {
     static constexpr int KT = WK * 32, NTL = WN * 32;    // channel tiles of the workgroup
-    static constexpr int TPW = wgrad_tile_w(DOWN, KS);   // pixel tile: TR rows x TPW columns (even)
+    static constexpr int TPW = 32;                       // pixel tile: TR rows x 32 columns
     static constexpr int PH = (TR - 1) * DOWN + KS, PWD = (TPW - 1) * DOWN + KS;
-    static constexpr int PWL = PWD <= 32 ? 32 : 64;      // patch row pitch: power of two -> shift/mask staging indices
-    static constexpr int CSX = (PH * PWL) | 1;           // odd channel strides: conflict-free lane -> channel reads
+    static constexpr int PP = PWD;                       // patch row pitch
+    static constexpr int MAINW = 32 * DOWN;              // power-of-two part of a patch row (shift/mask staging indices)
+    static constexpr int TAILW = PWD > MAINW ? PWD - MAINW : 0;   // the 1-2 halo columns beyond it
+    static constexpr int CSX = (PH * PP) | 1;            // odd channel strides: conflict-free lane -> channel reads
     static constexpr int CSY = (TR * 32) | 1;
-    static constexpr int NX = KT * PH * PWL, NY = NTL * TR * 32;
-    static constexpr int NPX = NX / 256, NPY = NY / 256;
-    static constexpr int SMEM = KT * CSX + NTL * CSY;
+    static constexpr int RX = KT * PH;                   // patch rows staged per tile
+    static constexpr int NPXM = RX * MAINW / 256, NPXT = (RX * TAILW + 255) / 256, NPY = NTL * TR * 32 / 256;
+    static constexpr int RED = (WP - 1) * WK * WN * 16 * 64;
+    static constexpr int SMEM = cmax(KT * CSX + NTL * CSY, RED);
     static constexpr int NT = KS * KS;
 };
 
 template <int WK, int WN, int WP, int TR, int DOWN, int KS>
 __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
     using C = WgradCfg<WK, WN, WP, TR, DOWN, KS>;
-    constexpr int KT = C::KT, NTL = C::NTL, TPW = C::TPW, PH = C::PH, PWD = C::PWD, PWL = C::PWL, NT = C::NT;
+    constexpr int KT = C::KT, NTL = C::NTL, TPW = C::TPW, PH = C::PH, PWD = C::PWD, PP = C::PP, NT = C::NT;
+    constexpr int MAINW = C::MAINW, TAILW = C::TAILW;
     static_assert(WK * WN * WP == 4, "4 waves per workgroup");
     static_assert(TR % WP == 0, "rows split evenly over the pixel waves");
-    static_assert(C::NX % 256 == 0 && C::NY % 256 == 0, "staging loops are exact");
+    static_assert((C::RX * MAINW) % 256 == 0 && (NTL * TR * 32) % 256 == 0, "staging loops are exact");
     __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
-    float* xs = smem;                        // [KT][PH][PWL]  (channel stride CSX)
+    float* xs = smem;                        // [KT][PH][PP]   (channel stride CSX)
     float* ds = smem + KT * C::CSX;          // [NTL][TR][32]  (channel stride CSY)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -342,7 +344,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
     const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
     const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;   // host guarantees C * H * W < 2^31
 
-    float xreg[C::NPX], yreg[C::NPY];
+    float xreg[C::NPXM], treg[C::NPXT > 0 ? C::NPXT : 1], yreg[C::NPY];
+    auto load_x = [&](const float* xb, const float* sb, int row, int c, int iy0, int ix0) -> float {
+        const int r = row % PH, kk = row / PH;
+        const int k = k0 + kk, iy = iy0 + r, ix = ix0 + c;
+        float v = 0.f;
+        if (c < PWD && row < C::RX && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
+            v = xb[k * xchan + iy * p.in_w + ix];
+            if (sb) v *= sb[k];
+        }
+        return v;
+    };
     auto prefetch = [&](int tile) {
         const int t_ = opaque(tid);
         const int b = tile / tiles_per_sample;
@@ -351,18 +363,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
         const int iy0 = oy0 * DOWN - p.pad_y, ix0 = ox0 * DOWN - p.pad_x;
         const float* xb = p.x + (size_t)b * p.K * xchan;
         const float* yb = p.dy + (size_t)b * p.N * ychan;
+        const float* sib = p.si ? p.si + (size_t)b * p.K : nullptr;
 #pragma unroll
-        for (int j = 0; j < C::NPX; ++j) {
+        for (int j = 0; j < C::NPXM; ++j) {
             const int e = t_ + 256 * j;
-            const int c = e % PWL, row = e / PWL;
-            const int r = row % PH, kk = row / PH;
-            const int k = k0 + kk, iy = iy0 + r, ix = ix0 + c;
-            float v = 0.f;
-            if (c < PWD && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
-                v = xb[k * xchan + iy * p.in_w + ix];
-                if (p.si) v *= p.si[(size_t)b * p.K + k];
+            xreg[j] = load_x(xb, sib, e / MAINW, e % MAINW, iy0, ix0);
+        }
+        if (TAILW > 0) {
+#pragma unroll
+            for (int j = 0; j < C::NPXT; ++j) {
+                const int e = t_ + 256 * j;
+                treg[j] = load_x(xb, sib, e / (TAILW > 0 ? TAILW : 1), MAINW + e % (TAILW > 0 ? TAILW : 1), iy0, ix0);
             }
-            xreg[j] = v;
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
@@ -371,7 +383,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
             const int r = row % TR, nn = row / TR;
             const int n = n0 + nn, oy = oy0 + r, ox = ox0 + c;
             float v = 0.f;
-            if (c < TPW && n < p.N && oy < p.out_h && ox < p.out_w) {
+            if (n < p.N && oy < p.out_h && ox < p.out_w) {
                 v = yb[n * ychan + oy * p.out_w + ox];
                 if (p.so) v *= p.so[(size_t)b * p.N + n];
             }
@@ -381,16 +393,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
     auto commit = [&]() {
         const int t_ = opaque(tid);
 #pragma unroll
-        for (int j = 0; j < C::NPX; ++j) {
+        for (int j = 0; j < C::NPXM; ++j) {
             const int e = t_ + 256 * j;
-            const int kk = e / (PH * PWL);
-            xs[kk * C::CSX + e % (PH * PWL)] = xreg[j];
+            const int c = e % MAINW, row = e / MAINW;
+            if (c < PWD) xs[(row / PH) * C::CSX + (row % PH) * PP + c] = xreg[j];
+        }
+        if (TAILW > 0) {
+#pragma unroll
+            for (int j = 0; j < C::NPXT; ++j) {
+                const int e = t_ + 256 * j;
+                const int c = MAINW + e % (TAILW > 0 ? TAILW : 1), row = e / (TAILW > 0 ? TAILW : 1);
+                if (row < C::RX) xs[(row / PH) * C::CSX + (row % PH) * PP + c] = treg[j];
+            }
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
             const int e = t_ + 256 * j;
-            const int nn = e / (TR * 32);
-            ds[nn * C::CSY + e % (TR * 32)] = yreg[j];
+            ds[(e / (TR * 32)) * C::CSY + e % (TR * 32)] = yreg[j];
         }
     };
 
@@ -409,10 +428,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
                 for (int c = 0; c < TPW; c += 2) {
                     const int col = c + hi;
                     const float bv = db[r * 32 + col];
-                    const float* xr = xa + r * DOWN * PWL + col * DOWN;
+                    const float* xr = xa + r * DOWN * PP + col * DOWN;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const float av = xr[(t / KS) * PWL + (t % KS)];
+                        const float av = xr[(t / KS) * PP + (t % KS)];
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
                     }
                 }
@@ -425,8 +444,30 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
         }
     }
 
-    // ---- partial result: ws[split*WP + wp][tap][k][n]; lanes 0..31 = consecutive n ----
-    float* out = p.ws + (size_t)(split * WP + wp) * NT * p.K * p.N;
+    if (WP > 1) {
+        // the WP pixel-waves of a (wk, wn) group hold partial sums of the SAME (k, n) block: add them through LDS
+        float* red = smem + (wk * WN + wn) * (WP - 1) * 16 * 64;
+        for (int t = 0; t < NT; ++t) {
+            __syncthreads();
+            if (wp > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wp - 1) * 16 + r) * 64 + lane] = acc[t][r];
+            }
+            __syncthreads();
+            if (wp == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[t][r];
+                    for (int o = 0; o < WP - 1; ++o) v += red[(o * 16 + r) * 64 + lane];
+                    acc[t][r] = v;
+                }
+            }
+        }
+        if (wp != 0) return;
+    }
+
+    // ---- partial result: ws[split][tap][k][n] (or dw itself when there is a single split); lanes 0..31 = consecutive n ----
+    float* out = p.ws + (size_t)split * NT * p.K * p.N;
     const int n = n0 + wn * 32 + l31;
     if (n < p.N) {
 #pragma unroll
@@ -440,11 +481,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
     }
 }
 
+// dw[i] = sum_s ws[s][i] in fixed order; count is a multiple of 4 when VEC (16-byte loads, 8 in flight per lane)
+template <bool VEC>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t count, int parts) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
-        float acc = 0.f;
-        for (int s = 0; s < parts; ++s) acc += ws[(size_t)s * count + i];
-        dw[i] = acc;
+    if (VEC) {
+        const size_t n4 = count / 4;
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int s = 0;
+            for (; s + 8 <= parts; s += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(ws + (size_t)(s + u) * count)[i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; s < parts; ++s) {
+                const float4 v = reinterpret_cast<const float4*>(ws + (size_t)s * count)[i];
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            reinterpret_cast<float4*>(dw)[i] = acc;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+            float acc = 0.f;
+            for (int s = 0; s < parts; ++s) acc += ws[(size_t)s * count + i];
+            dw[i] = acc;
+        }
     }
 }
 
@@ -496,34 +559,40 @@ int dispatch_conv(const ConvArgs& a, hipStream_t s) {
     return launch_conv<2, 2, 1, 2, 2, 32, UP, DOWN, KS>(a, s);
 }
 
-struct WgradPlan { int cfg, kt, nt, wp, tr, splits, tiles_per_split, tiles_x, tiles_y, parts; };
+struct WgradPlan { int cfg, kt, nt, tr, splits, tiles_per_split, tiles_x, tiles_y, parts; };
 
 WgradPlan plan_wgrad(const gc_conv_desc* d) {
     WgradPlan pl;
-    // cfg 0: 64k x 64n per workgroup; cfg 1: 32k x 32n with the four waves splitting the pixel rows
-    pl.cfg = (d->in_ch <= 32 && d->out_ch <= 32 && d->down == 1) ? 1 : 0;
-    pl.kt = pl.cfg ? 32 : 64; pl.nt = pl.cfg ? 32 : 64; pl.wp = pl.cfg ? 4 : 1;
-    pl.tr = pl.cfg ? 4 : ((d->down == 2 || d->kh == 3) ? 1 : 2);   // 64x64x9-tap tiles: one row keeps 144 accumulators + prefetch in 256 VGPRs
-    pl.tiles_x = gc::ceil_div(d->out_w, wgrad_tile_w(d->down, d->kh));
+    // cfg 0: 64k x 64n per workgroup; 1: 32k x 64n, 2: 64k x 32n (two pixel-waves); 3: 32k x 32n (four pixel-waves)
+    const bool ksmall = d->in_ch <= 32, nsmall = d->out_ch <= 32;
+    pl.cfg = (ksmall && nsmall) ? 3 : (ksmall ? 1 : (nsmall ? 2 : 0));
+    pl.kt = (pl.cfg == 1 || pl.cfg == 3) ? 32 : 64;
+    pl.nt = (pl.cfg == 2 || pl.cfg == 3) ? 32 : 64;
+    const bool narrow = d->down == 2 || d->kh == 3;      // register budget: 144 accumulators + prefetch in 256 VGPRs
+    pl.tr = pl.cfg == 0 ? (narrow ? 1 : 2) : (pl.cfg == 3 ? (d->down == 2 ? 4 : 4) : 2);
+    pl.tiles_x = gc::ceil_div(d->out_w, 32);
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
     const int ctiles = gc::ceil_div(d->in_ch, pl.kt) * gc::ceil_div(d->out_ch, pl.nt);
-    int want = gc::ceil_div(1024, ctiles);          // ~4 workgroups per CU over the whole grid
+    int want = gc::ceil_div(512, ctiles);           // ~2 workgroups per CU (2 waves/SIMD at ~200 VGPRs) over the whole grid
     if (want > total) want = total;
     if (want < 1) want = 1;
     pl.tiles_per_split = gc::ceil_div(total, want);
     pl.splits = gc::ceil_div(total, pl.tiles_per_split);
-    pl.parts = pl.splits * pl.wp;
+    pl.parts = pl.splits;                            // pixel-waves are summed in LDS inside the kernel
     return pl;
 }
 
 template <int DOWN, int KS>
 int dispatch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
     dim3 grid(gc::ceil_div(a.K, pl.kt), gc::ceil_div(a.N, pl.nt), pl.splits);
-    if (DOWN == 1 && pl.cfg == 1)
-        hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 4, 4, 1, KS>), grid, dim3(256), 0, s, a);
-    else
-        hipLaunchKernelGGL((wgrad_mfma_kernel<2, 2, 1, ((DOWN == 2 || KS == 3) ? 1 : 2), DOWN, KS>), grid, dim3(256), 0, s, a);
+    constexpr bool narrow = DOWN == 2 || KS == 3;
+    switch (pl.cfg) {
+        case 0: hipLaunchKernelGGL((wgrad_mfma_kernel<2, 2, 1, (narrow ? 1 : 2), DOWN, KS>), grid, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL((wgrad_mfma_kernel<1, 2, 2, 2, DOWN, KS>), grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL((wgrad_mfma_kernel<2, 1, 2, 2, DOWN, KS>), grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL((wgrad_mfma_kernel<1, 1, 4, 4, DOWN, KS>), grid, dim3(256), 0, s, a); break;
+    }
     return gc::check_launch("gc_conv2d_wgrad_f32(mfma)");
 }
 
@@ -567,12 +636,15 @@ extern "C" int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const 
     const WgradPlan pl = plan_wgrad(d);
     const size_t need = gc_conv2d_wgrad_workspace(d);
     if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_f32: workspace %zu < %zu bytes", workspace_bytes, need);
-    WgradArgs a{x, dy, in_scale, out_scale, static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w,
+    WgradArgs a{x, dy, in_scale, out_scale, pl.parts == 1 ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w,
                 d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
     if (d->kh == 3) rc = d->down == 2 ? dispatch_wgrad<2, 3>(a, pl, s) : dispatch_wgrad<1, 3>(a, pl, s);
     else            rc = d->down == 2 ? dispatch_wgrad<2, 1>(a, pl, s) : dispatch_wgrad<1, 1>(a, pl, s);
     if (rc) return rc;
-    const int blocks = (int)std::min<size_t>((count + 255) / 256, 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(workspace), dw, count, pl.parts);
+    if (pl.parts == 1) return GC_OK;
+    const bool vec = count % 4 == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    const int blocks = (int)std::min<size_t>(((vec ? count / 4 : count) + 255) / 256, 2048);
+    if (vec) hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(workspace), dw, count, pl.parts);
+    else     hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(workspace), dw, count, pl.parts);
     return gc::check_launch("gc_conv2d_wgrad_f32(reduce)");
 }
