@@ -1,0 +1,322 @@
+// K3/K4 fast path: the generalised convolution of include/gancontrol_hip.h on the bf16 matrix cores
+// with SPLIT-bf16 ("bf16x3") arithmetic:
+//
+//   a = a_hi + a_lo,  a_hi = bf16(a), a_lo = bf16(a - a_hi)        (16 mantissa bits kept)
+//   a * b ~= a_hi*b_hi + a_hi*b_lo + a_lo*b_hi                    (fp32 accumulate in the MFMA)
+//
+// Three v_mfma_f32_32x32x16_bf16 (32 cycles, K = 16) replace eight v_mfma_f32_32x32x2_f32
+// (64 cycles, K = 2): 5.3x the fp32-MFMA rate.  Measured error vs fp64 on a 512-channel 3x3 layer:
+// 5e-6 relative (fp32: 3e-7, plain bf16: 3e-3) -- two orders inside the 1e-3 parity bound.
+// fp32 in HBM on both sides: the split happens while staging into LDS (activations, after the
+// per-sample in_scale multiply) and in a pre-pass over the weights (pack_weights_kernel).
+//
+// Structure mirrors conv_mfma_kernel (conv.hip): per chunk of 16 input channels the workgroup stages
+// the halo'd input patch once, channel-LAST in LDS -- one 16-byte unit = 8 consecutive channels of one
+// pixel = exactly one lane's MFMA B fragment, so every tap reads it with a single conflict-free
+// ds_read_b128 at a shifted unit index -- plus the [tap][2][OCT] weight units (A fragments).
+// Register-prefetch pipeline over chunks, compile-time geometry, phase decomposition for up = 2.
+#include "conv_common.h"
+
+namespace {
+
+using namespace gcconv;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int KCB = 16;   // input channels per chunk = K of one bf16 MFMA
+constexpr int KG = 2;     // 8-channel groups per chunk
+
+struct Bf16Args {
+    ConvArgs c;
+    const uint4* wh; const uint4* wl;   // packed weights [tap][ceil(K/8)][N] units of 8 bf16 (hi / lo parts)
+    int kgroups;                        // ceil(K / 8)
+};
+
+// wp[t][kg][n] = 8 x bf16 of w[t][kg*8 + q][n], q = 0..7 (zero beyond K); hi and lo parts
+__global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restrict__ w, uint4* __restrict__ wh, uint4* __restrict__ wl,
+                                                           int taps, int K, int N, int kgroups) {
+    const size_t total = (size_t)taps * kgroups * N;
+    for (size_t u = (size_t)blockIdx.x * 256 + threadIdx.x; u < total; u += (size_t)gridDim.x * 256) {
+        const int n = (int)(u % N);
+        const size_t rest = u / N;
+        const int kg = (int)(rest % kgroups), t = (int)(rest / kgroups);
+        bf16x8 h, l;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = kg * 8 + q;
+            const float v = k < K ? w[((size_t)t * K + k) * N + n] : 0.f;
+            const __bf16 hh = (__bf16)v;
+            h[q] = hh;
+            l[q] = (__bf16)(v - (float)hh);
+        }
+        wh[u] = *reinterpret_cast<uint4*>(&h);
+        wl[u] = *reinterpret_cast<uint4*>(&l);
+    }
+}
+
+template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
+struct BCfg {
+    static constexpr int OCT = WG_OC * WOC * 32;
+    static constexpr int TPH = WG_PX * WPX;                 // tile rows (each 32-pixel MFMA column block is one row segment)
+    static constexpr int NT1 = UP == 1 ? KS : (KS + UP - 1) / UP;
+    static constexpr int PH = (TPH - 1) * DOWN + NT1, PWD = 31 * DOWN + NT1;
+    static constexpr int PLANE = PH * PWD;                  // units per channel group
+    static constexpr int WUNITS = NT1 * NT1 * KG * OCT;     // weight units per chunk (per hi / lo)
+    static constexpr int PUNITS = KG * PLANE;
+    static constexpr int SMEM_UNITS = 2 * (WUNITS + PUNITS);
+    static constexpr int NWU = (WUNITS + 255) / 256;        // weight units prefetched per thread (x2: hi, lo)
+    static constexpr int NPU = (PLANE + 127) / 128;         // patch units per thread (half the block per channel group)
+};
+
+template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
+__global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
+    using C = BCfg<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>;
+    static_assert(WG_OC * WG_PX == 4, "4 waves per workgroup");
+    constexpr int OCT = C::OCT, TPH = C::TPH, PH = C::PH, PWD = C::PWD, PLANE = C::PLANE;
+    const ConvArgs& p = a.c;
+    __shared__ uint4 smem[C::SMEM_UNITS];
+    uint4* wl_h = smem;                         // [tap][kg][OCT]
+    uint4* wl_l = wl_h + C::WUNITS;
+    uint4* p_h = wl_l + C::WUNITS;              // [kg][PH][PWD]
+    uint4* p_l = p_h + C::PUNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wave_px = wave % WG_PX, wave_oc = wave / WG_PX;
+
+    int bid = blockIdx.x;
+    const int tile_x = bid % p.tiles_x; bid /= p.tiles_x;
+    const int tile_y = bid % p.tiles_y; bid /= p.tiles_y;
+    const int phase = bid % (UP * UP);
+    const int b = bid / (UP * UP);
+    const int phy = phase / UP, phx = phase % UP;
+    const int n0 = blockIdx.y * OCT;
+    const int qh = (p.out_h - phy + UP - 1) / UP, qw = (p.out_w - phx + UP - 1) / UP;
+    const int qy0 = tile_y * TPH, qx0 = tile_x * 32;
+    if (qy0 >= qh || qx0 >= qw) return;
+
+    const AxisTaps ay = axis_taps<UP, KS>(phy, p.pad_y), ax = axis_taps<UP, KS>(phx, p.pad_x);
+    const int ntaps = ay.n * ax.n;
+    const int iy0 = qy0 * DOWN + ay.d0, ix0 = qx0 * DOWN + ax.d0;
+
+    f32x16 acc[WOC][WPX];
+#pragma unroll
+    for (int i = 0; i < WOC; ++i)
+#pragma unroll
+        for (int j = 0; j < WPX; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int boff[WPX];
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) boff[j] = hi * PLANE + (wave_px * WPX + j) * DOWN * PWD + l31 * DOWN;
+    const int aoff = hi * OCT + wave_oc * WOC * 32 + l31;
+
+    const float* xb = p.x + (size_t)b * p.K * p.in_h * p.in_w;
+    const float* sib = p.si ? p.si + (size_t)b * p.K : nullptr;
+    const int chan = p.in_h * p.in_w;
+
+    uint4 wreg_h[C::NWU], wreg_l[C::NWU];
+    float preg[C::NPU][8];
+    float sreg[8];
+
+    auto prefetch = [&](int k0) {
+        const int t_ = opaque(tid);
+        // weights: unit u -> (tap, kg, oc); plain 16-byte copies of the pre-split slab
+#pragma unroll
+        for (int j = 0; j < C::NWU; ++j) {
+            const int u = t_ + 256 * j;
+            const int oc = u % OCT, rest = u / OCT;
+            const int kgl = rest % KG, t = rest / KG;
+            const int jy = UP == 1 ? t / KS : (ax.n == 2 ? t >> 1 : t), jx = UP == 1 ? t % KS : (ax.n == 2 ? t & 1 : 0);
+            const int tap = (ay.t0 + jy * UP) * KS + ax.t0 + jx * UP;
+            const int kg = k0 / 8 + kgl, n = n0 + oc;
+            uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
+            if (u < C::WUNITS && t < ntaps && kg < a.kgroups && n < p.N) {
+                const int g = (tap * a.kgroups + kg) * p.N + n;
+                vh = a.wh[g];
+                vl = a.wl[g];
+            }
+            wreg_h[j] = vh;
+            wreg_l[j] = vl;
+        }
+        // patch: threads 0..127 take channel group 0, 128..255 group 1; a unit = 8 channels of one pixel
+        const int kgl = t_ >> 7, pbase = t_ & 127;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + kgl * 8 + q;
+            sreg[q] = (sib && k < p.K) ? sib[k] : 1.f;
+        }
+#pragma unroll
+        for (int j = 0; j < C::NPU; ++j) {
+            const int pos = pbase + 128 * j;
+            const int r = pos / PWD, c = pos % PWD;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool ok = pos < PLANE && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+            const int off = iy * p.in_w + ix;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = k0 + kgl * 8 + q;
+                preg[j][q] = (ok && k < p.K) ? xb[k * chan + off] : 0.f;
+            }
+        }
+    };
+    auto commit = [&]() {
+        const int t_ = opaque(tid);
+#pragma unroll
+        for (int j = 0; j < C::NWU; ++j) {
+            const int u = t_ + 256 * j;
+            if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; wl_l[u] = wreg_l[j]; }
+        }
+        const int kgl = t_ >> 7, pbase = t_ & 127;
+#pragma unroll
+        for (int j = 0; j < C::NPU; ++j) {
+            const int pos = pbase + 128 * j;
+            bf16x8 h, l;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const float v = preg[j][q] * sreg[q];
+                const __bf16 hh = (__bf16)v;
+                h[q] = hh;
+                l[q] = (__bf16)(v - (float)hh);
+            }
+            if (pos < PLANE) {
+                p_h[kgl * PLANE + pos] = *reinterpret_cast<uint4*>(&h);
+                p_l[kgl * PLANE + pos] = *reinterpret_cast<uint4*>(&l);
+            }
+        }
+    };
+
+    if (ntaps > 0) {
+        prefetch(0);
+        commit();
+        __syncthreads();
+        for (int k0 = 0; k0 < p.K; k0 += KCB) {
+            const bool more = k0 + KCB < p.K;
+            if (more) prefetch(k0 + KCB);
+            const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
+            for (int jy = 0; jy < nty; ++jy) {
+                for (int jx = 0; jx < ntx; ++jx) {
+                    const int wbase = (jy * ntx + jx) * KG * OCT + aoff;
+                    const int pbase = jy * PWD + jx;
+                    bf16x8 ah[WOC], al[WOC], bh[WPX], bl[WPX];
+#pragma unroll
+                    for (int i = 0; i < WOC; ++i) {
+                        const uint4 uh = wl_h[wbase + i * 32], ul = wl_l[wbase + i * 32];
+                        ah[i] = *reinterpret_cast<const bf16x8*>(&uh);
+                        al[i] = *reinterpret_cast<const bf16x8*>(&ul);
+                    }
+#pragma unroll
+                    for (int j = 0; j < WPX; ++j) {
+                        const uint4 uh = p_h[pbase + boff[j]], ul = p_l[pbase + boff[j]];
+                        bh[j] = *reinterpret_cast<const bf16x8*>(&uh);
+                        bl[j] = *reinterpret_cast<const bf16x8*>(&ul);
+                    }
+#pragma unroll
+                    for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                        for (int j = 0; j < WPX; ++j) {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                        }
+                }
+            }
+            __syncthreads();
+            if (more) {
+                commit();
+                __syncthreads();
+            }
+        }
+    }
+
+    const float* sob = p.so ? p.so + (size_t)b * p.N : nullptr;
+    float* yb = p.y + (size_t)b * p.N * p.out_h * p.out_w;
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) {
+        const int qy = qy0 + wave_px * WPX + j, qx = qx0 + l31;
+        if (qy >= qh || qx >= qw) continue;
+        const int oy = qy * UP + phy, ox = qx * UP + phx;
+#pragma unroll
+        for (int i = 0; i < WOC; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = n0 + (wave_oc * WOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (oc < p.N) {
+                    float v = acc[i][j][r];
+                    if (sob) v *= sob[oc];
+                    yb[((size_t)oc * p.out_h + oy) * p.out_w + ox] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
+int launch(Bf16Args a, hipStream_t s) {
+    using C = BCfg<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>;
+    const int qh = gc::ceil_div(a.c.out_h, UP), qw = gc::ceil_div(a.c.out_w, UP);
+    a.c.tiles_y = gc::ceil_div(qh, C::TPH);
+    a.c.tiles_x = gc::ceil_div(qw, 32);
+    const long long gx = (long long)a.c.tiles_x * a.c.tiles_y * UP * UP * a.c.B;
+    if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
+    dim3 grid((unsigned)gx, gc::ceil_div(a.c.N, C::OCT));
+    hipLaunchKernelGGL((conv_bf16x3_kernel<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>), grid, dim3(256), 0, s, a);
+    return gc::check_launch("gc_conv2d_bf16x3_f32");
+}
+
+template <int UP, int DOWN, int KS>
+int dispatch(const Bf16Args& a, hipStream_t s) {
+    if constexpr (DOWN == 2) {
+        // patch extents double: 4-row tiles only
+        if (a.c.N <= 32) return launch<1, 4, 1, 1, UP, DOWN, KS>(a, s);
+        return launch<1, 4, 2, 1, UP, DOWN, KS>(a, s);
+    } else {
+        if (a.c.N <= 32) return launch<1, 4, 1, 4, UP, DOWN, KS>(a, s);     // 32oc x (16 rows x 32 px)
+        return launch<1, 4, 2, 2, UP, DOWN, KS>(a, s);                      // 64oc x (8 rows x 32 px)
+    }
+}
+
+// shapes the split-bf16 kernel is built for; everything else runs on the exact fp32 kernel
+bool eligible(const gc_conv_desc* d) {
+    const int qw = gc::ceil_div(d->out_w, d->up);
+    return d->in_ch >= 16 && qw > 16;
+}
+
+}  // namespace
+
+extern "C" size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d) {
+    if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
+    const size_t units = (size_t)d->kh * d->kw * ((d->in_ch + 7) / 8) * d->out_ch;
+    return 2 * units * sizeof(uint4);
+}
+
+extern "C" int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
+                                    const float* in_scale, const float* out_scale, float* y,
+                                    void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    int rc = validate(d, "gc_conv2d_bf16x3_f32", false);
+    if (rc) return rc;
+    if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_bf16x3_f32: null pointer");
+    if (d->batch == 0) return GC_OK;
+    if (!eligible(d)) return gc_conv2d_f32(d, x, w, in_scale, out_scale, y, stream);
+    const size_t need = gc_conv2d_bf16x3_workspace(d);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_bf16x3_f32: workspace %zu < %zu bytes (or not 16-byte aligned)", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    const int kgroups = (d->in_ch + 7) / 8, taps = d->kh * d->kw;
+    const size_t units = (size_t)taps * kgroups * d->out_ch;
+    uint4* wh = static_cast<uint4*>(workspace);
+    uint4* wl = wh + units;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<size_t>((units + 255) / 256, 4096)), dim3(256), 0, s,
+                       w, wh, wl, taps, d->in_ch, d->out_ch, kgroups);
+    rc = gc::check_launch("gc_conv2d_bf16x3_f32(pack)");
+    if (rc) return rc;
+    Bf16Args a{{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
+                d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups};
+    if (d->kh == 3) {
+        if (d->up == 2) return dispatch<2, 1, 3>(a, s);
+        return d->down == 2 ? dispatch<1, 2, 3>(a, s) : dispatch<1, 1, 3>(a, s);
+    }
+    if (d->up == 2) return dispatch<2, 1, 1>(a, s);
+    return d->down == 2 ? dispatch<1, 2, 1>(a, s) : dispatch<1, 1, 1>(a, s);
+}

@@ -1,0 +1,60 @@
+// Helpers shared by the fp32 (conv.hip) and split-bf16 (conv_bf16x3.hip) convolution kernels.
+#pragma once
+#include "common.h"
+
+namespace gcconv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct ConvArgs {
+    const float* x; const float* w; const float* si; const float* so; float* y;
+    int B, K, N, in_h, in_w, out_h, out_w, pad_y, pad_x;
+    int tiles_x, tiles_y;     // pixel tiles per phase sub-grid (sized for phase 0, the largest)
+};
+
+// Taps of one output phase along one axis: tap index t0 + j*up, source offset d0 + j, j < n.
+struct AxisTaps { int t0, n, d0; };
+template <int UP, int KS>
+__device__ __forceinline__ AxisTaps axis_taps(int phase, int pad) {
+    AxisTaps a;
+    if (UP == 1) { a.t0 = 0; a.n = KS; a.d0 = -pad; return a; }
+    a.t0 = gc::pos_mod(pad - phase, UP);
+    a.n = a.t0 < KS ? (KS - a.t0 + UP - 1) / UP : 0;
+    a.d0 = gc::floor_div(phase + a.t0 - pad, UP);
+    return a;
+}
+
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+constexpr int patch_pitch(int width, int tpw) {
+    // distinct LDS banks for the (32/tpw) rows one MFMA column block touches: pitch == tpw (mod 32)
+    if (tpw == 32) return width | 1;
+    int pp = width;
+    while (pp % 32 != tpw) ++pp;
+    return pp;
+}
+
+// Fresh, optimiser-opaque copy of a lane value: staging index arithmetic written in terms of it is
+// recomputed where it is used (a few dozen VALU ops per chunk) instead of being hoisted out of the
+// K loop into dozens of live registers, which would cost a wave of occupancy.
+__device__ __forceinline__ int opaque(int v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
+
+inline int validate(const gc_conv_desc* d, const char* who, bool wgrad) {
+    if (!d) return gc::fail(GC_ERR_BAD_ARG, "%s: null descriptor", who);
+    if (d->batch < 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->in_h <= 0 || d->in_w <= 0 || d->out_h <= 0 || d->out_w <= 0)
+        return gc::fail(GC_ERR_BAD_ARG, "%s: non-positive extent", who);
+    if (d->kh != d->kw || (d->kh != 1 && d->kh != 3)) return gc::fail(GC_ERR_UNSUPPORTED, "%s: taps %dx%d (1x1 and 3x3 only)", who, d->kh, d->kw);
+    const bool ok = (d->up == 1 && (d->down == 1 || d->down == 2)) || (d->up == 2 && d->down == 1);
+    if (!ok) return gc::fail(GC_ERR_UNSUPPORTED, "%s: up=%d down=%d", who, d->up, d->down);
+    if (wgrad && d->up != 1) return gc::fail(GC_ERR_UNSUPPORTED, "%s: up must be 1 (swap the operands for a transposed conv)", who);
+    const long long lim = 2147483647LL;
+    if ((long long)d->in_ch * d->in_h * d->in_w > lim || (long long)d->out_ch * d->out_h * d->out_w > lim ||
+        (long long)d->kh * d->kw * d->in_ch * d->out_ch > lim)
+        return gc::fail(GC_ERR_UNSUPPORTED, "%s: a per-sample plane set exceeds 2^31 elements", who);
+    return GC_OK;
+}
+
+
+}  // namespace gcconv

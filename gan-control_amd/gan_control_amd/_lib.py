@@ -34,6 +34,8 @@ SIGNATURES = {
     'gc_channel_sum_workspace': (_sz, [_i32, _i32, _i64]),
     'gc_channel_sum_f32': (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _sz, _vp]),
     'gc_conv2d_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gc_conv2d_bf16x3_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
+    'gc_conv2d_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_wgrad_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }

@@ -5,6 +5,7 @@ implementation shipped is ``HipBackend`` (ctypes -> libgancontrol_hip.so).  Test
 emulation of the same interface to validate the autograd wiring on machines without a GPU;
 the product never does.
 """
+import os
 from collections import namedtuple
 
 import torch
@@ -18,6 +19,8 @@ ConvGeom = namedtuple('ConvGeom', 'kh kw up down pad_y pad_x out_h out_w')
 class HipBackend:
     name = 'hip'
     timer = None          # optional utils.profiling.KernelTimer (bench.py); None in normal operation
+    # 'f32': exact fp32 MFMA (the parity mode); 'bf16x3': split-bf16 MFMA, ~5e-6 relative error per layer
+    conv_mode = os.environ.get('GANCONTROL_CONV_PRECISION', 'f32')
 
     @staticmethod
     def _guard(dev):
@@ -117,11 +120,21 @@ class HipBackend:
             return y
         desc = self._desc(x, n_out, geom)
         lib = _lib.load()
+        ws = None
+        if self.conv_mode == 'bf16x3':
+            nbytes = lib.gc_conv2d_bf16x3_workspace(desc)
+            ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
+        elif self.conv_mode != 'f32':
+            raise RuntimeError('GANCONTROL_CONV_PRECISION must be f32 or bf16x3, got %r' % self.conv_mode)
         g = self._guard(dev)
         t0 = self.timer.start() if self.timer else None
         if g: g.__enter__()
         try:
-            rc = lib.gc_conv2d_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(y), _lib.stream_of(x))
+            if ws is None:
+                rc = lib.gc_conv2d_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(y), _lib.stream_of(x))
+            else:
+                rc = lib.gc_conv2d_bf16x3_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(y),
+                                              _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
         finally:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_conv2d_f32')

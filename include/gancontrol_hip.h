@@ -118,6 +118,17 @@ typedef struct gc_conv_desc {
 int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,
                   const float* in_scale, const float* out_scale, float* y, gc_stream_t stream);
 
+/* The same contraction on the bf16 matrix cores with split-bf16 ("bf16x3") arithmetic: every fp32
+ * operand is split into bf16 hi + lo parts and a*b is formed as hi*hi + hi*lo + lo*hi with fp32
+ * accumulation (~5e-6 relative error per layer, 5.3x the fp32 MFMA rate).  Inputs and outputs stay
+ * fp32; `workspace` (gc_conv2d_bf16x3_workspace() bytes, 16-byte aligned) receives the split weights.
+ * Shapes the fast kernel does not cover (in_ch < 16, planes <= 16 px wide) run on gc_conv2d_f32.
+ */
+size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d);
+int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
+                         const float* in_scale, const float* out_scale, float* y,
+                         void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
 /* Weight gradient of the same contraction (up must be 1):
  *
  *   dw[ty,tx,k,n] = sum_{b,oy,ox} in_scale[b,k] * x[b,k, oy*down + ty - pad_y, ox*down + tx - pad_x]

@@ -184,3 +184,48 @@ def test_error_reporting():
 def test_step_golden():
     import step_checks
     step_checks.check_step(DEV)
+
+
+@pytest.fixture
+def bf16x3_mode():
+    hip, _ = _be()
+    prev, hip.conv_mode = hip.conv_mode, 'bf16x3'
+    yield
+    hip.conv_mode = prev
+
+
+BF16_CASES = CONV_CASES + [
+    (2, 64, 64, 40, 70, 3, 1, 1, 1), (1, 130, 140, 33, 65, 3, 1, 1, 1), (1, 32, 32, 70, 40, 3, 1, 1, 1), (2, 48, 24, 36, 36, 1, 1, 1, 0),
+    (1, 64, 130, 65, 129, 3, 1, 2, 0), (2, 40, 20, 71, 67, 3, 1, 2, 0), (2, 16, 24, 63, 63, 1, 1, 2, 0),
+    (1, 64, 40, 32, 48, 3, 2, 1, 2), (2, 24, 70, 20, 33, 3, 2, 1, 2), (2, 16, 5, 40, 40, 1, 2, 1, 0), (1, 513, 40, 40, 40, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize('case', BF16_CASES)
+def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
+    """Split-bf16 MFMA path: ~5e-6 relative error per layer by construction; assert 5e-5 (parity bound is 1e-3)."""
+    from gan_control_amd.models.op._backend import ConvGeom
+    hip, emu = _be()
+    b, K, N, h, w, k, up, down, pad = case
+    gen = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    x = torch.randn(b, K, h, w, generator=gen)
+    wt = torch.randn(k, k, K, N, generator=gen)
+    si = torch.randn(b, K, generator=gen)
+    so = torch.rand(b, N, generator=gen) + 0.5
+    oh, ow = _out_size(h, k, up, down, pad, up > 1), _out_size(w, k, up, down, pad, up > 1)
+    geom = ConvGeom(k, k, up, down, pad, pad, oh, ow)
+    for use_scales in (False, True):
+        a = (si, so) if use_scales else (None, None)
+        ref = emu.conv2d(x.double(), wt.double(), *[None if t is None else t.double() for t in a], geom)
+        out = hip.conv2d(x.to(DEV), wt.to(DEV), *[None if t is None else t.to(DEV) for t in a], geom)
+        assert rel_err(out, ref) < 5e-5, use_scales
+
+
+@pytest.mark.parametrize('size', [64, 256])
+def test_network_golden_bf16x3(size, bf16x3_mode):
+    oc.check_network(size, DEV)
+
+
+def test_step_golden_bf16x3(bf16x3_mode):
+    import step_checks
+    step_checks.check_step(DEV)

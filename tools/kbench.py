@@ -31,8 +31,10 @@ def main():
     ap.add_argument('--batch', type=int, default=4)
     ap.add_argument('--reps', type=int, default=10)
     ap.add_argument('--only', default='')
+    ap.add_argument('--mode', default='f32')
     args = ap.parse_args()
     be = _backend.get()
+    be.conv_mode = args.mode
     B, dev = args.batch, 'cuda'
     rows = []
     convs = []
