@@ -44,6 +44,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--batch-per-gpu', type=int, default=4)
+    ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3'], help='conv arithmetic (default: GANCONTROL_CONV_PRECISION or f32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--cpu-baseline-size', type=int, default=None, help='resolution of the CPU sample (default: --size)')
@@ -104,6 +105,9 @@ def main():
     from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
     from gan_control_amd.utils.profiling import KernelTimer
 
+    if args.precision:
+        _backend.get().conv_mode = args.precision
+    precision = _backend.get().conv_mode
     cfg = default_config(args.size, args.batch_per_gpu * world)
     trainer = GeneratorTrainer(cfg, device=f'cuda:{local_rank}', seed=0)
     real = trainer.synthetic_batch()              # resident in HBM before the timed region
@@ -142,9 +146,9 @@ def main():
         out = {
             'metric': 'images/sec G+D step FFHQ-%d' % args.size, 'value': images / elapsed, 'unit': 'images/sec',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': 1e3 * elapsed / args.steps,
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': precision, 'data': 'synthetic',
             'config': {'workload': 'FFHQ %dx%d full G+D train step (D step, G step, lazy R1 every 16 and path-length every 4, '
-                                   'Adam, EMA), %d images/GPU, fp32 storage and fp32 MFMA' % (args.size, args.size, args.batch_per_gpu),
+                                   'Adam, EMA), %d images/GPU, fp32 storage, conv arithmetic %s' % (args.size, args.size, args.batch_per_gpu, precision),
                        'global_batch': args.batch_per_gpu * world, 'parallelism': 'dp%d' % world},
             'losses': {k: round(v, 5) for k, v in stats.items()},
         }

@@ -96,6 +96,48 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
     return r;
 }
 
+// Backward through the activation fused with the two reductions its caller needs:
+//   dx = dy * mask(y_ref);  psum[plane][chunk] = sum_chunk dx;  pdot[plane][chunk] = sum_chunk dx * noise[b, :]
+// (bias gradient = sum of psum over batch and chunks; noise-strength gradient = sum of pdot).  One read of dy and
+// y_ref, one write of dx -- the separate channel-sum / product passes over dx disappear.
+template <bool NOISE>
+__global__ __launch_bounds__(256) void bias_act_bwd_reduce_kernel(
+    const float* __restrict__ dy, const float* __restrict__ yref, const float* __restrict__ noise, float* __restrict__ dx,
+    float* __restrict__ psum, float* __restrict__ pdot, int channels, int64_t inner, int chunks, int64_t chunk_len, float pos, float neg) {
+    __shared__ float lds[4];
+    const int plane = blockIdx.y, j = blockIdx.x;
+    const int b = plane / channels;
+    const size_t base = (size_t)plane * inner;
+    const float* np = NOISE ? noise + (size_t)b * inner : nullptr;
+    const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
+    float s = 0.f, d = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+        const float g = dy[base + i] * (yref[base + i] > 0.f ? pos : neg);
+        dx[base + i] = g;
+        s += g;
+        if (NOISE) d = fmaf(g, np[i], d);
+    }
+    const float rs = block_sum(s, lds);
+    if (threadIdx.x == 0) psum[(size_t)plane * chunks + j] = rs;
+    if (NOISE) {
+        const float rd = block_sum(d, lds);
+        if (threadIdx.x == 0) pdot[(size_t)plane * chunks + j] = rd;
+    }
+}
+
+// partial[plane][chunk] = sum over the chunk of a * b  (per-sample modulation / demodulation gradients)
+__global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial,
+                                                        int64_t inner, int chunks, int64_t chunk_len) {
+    __shared__ float lds[4];
+    const int plane = blockIdx.y, j = blockIdx.x;
+    const size_t base = (size_t)plane * inner;
+    const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
+    float acc = 0.f;
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc = fmaf(a[base + i], b[base + i], acc);
+    const float r = block_sum(acc, lds);
+    if (threadIdx.x == 0) partial[(size_t)plane * chunks + j] = r;
+}
+
 // stage 1: partial[c][b * chunks + j] = sum over chunk j of plane (b, c); fixed summation order
 __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ x, float* __restrict__ partial,
                                                           int batch, int channels, int64_t inner, int chunks, int64_t chunk_len) {
@@ -200,4 +242,39 @@ extern "C" int gc_channel_sum_f32(const float* x, float* out, int batch, int cha
     if (rc) return rc;
     hipLaunchKernelGGL(channel_sum_stage2, dim3(channels), dim3(256), 0, s, partial, out, batch * chunks);
     return gc::check_launch("gc_channel_sum_f32(stage2)");
+}
+
+extern "C" int gc_bias_act_bwd_chunks(int64_t inner) {
+    if (inner <= 0) return 0;
+    int chunks; int64_t len;
+    channel_sum_plan(inner, &chunks, &len);
+    return chunks;
+}
+
+extern "C" int gc_bias_act_bwd_reduce_f32(const float* dy, const float* y_ref, const float* noise, float* dx,
+                                          float* psum, float* pdot, int batch, int channels, int64_t inner,
+                                          float slope, float gain, gc_stream_t stream) {
+    if (!dy || !y_ref || !dx || !psum) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_f32: null pointer");
+    if ((noise == nullptr) != (pdot == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_f32: noise and pdot go together");
+    if (batch <= 0 || channels <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_f32: bad extents");
+    if ((int64_t)batch * channels > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_f32: more than 65535 planes");
+    hipStream_t s = (hipStream_t)stream;
+    int chunks; int64_t len;
+    channel_sum_plan(inner, &chunks, &len);
+    dim3 grid(chunks, batch * channels);
+    if (noise)
+        hipLaunchKernelGGL(bias_act_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, dy, y_ref, noise, dx, psum, pdot, channels, inner, chunks, len, gain, gain * slope);
+    else
+        hipLaunchKernelGGL(bias_act_bwd_reduce_kernel<false>, grid, dim3(256), 0, s, dy, y_ref, noise, dx, psum, pdot, channels, inner, chunks, len, gain, gain * slope);
+    return gc::check_launch("gc_bias_act_bwd_reduce_f32");
+}
+
+extern "C" int gc_plane_dot_f32(const float* a, const float* b, float* partial, int planes, int64_t inner, gc_stream_t stream) {
+    if (!a || !b || !partial) return gc::fail(GC_ERR_BAD_ARG, "gc_plane_dot_f32: null pointer");
+    if (planes <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_plane_dot_f32: bad extents");
+    if (planes > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_plane_dot_f32: more than 65535 planes");
+    int chunks; int64_t len;
+    channel_sum_plan(inner, &chunks, &len);
+    hipLaunchKernelGGL(plane_dot_kernel, dim3(chunks, planes), dim3(256), 0, (hipStream_t)stream, a, b, partial, inner, chunks, len);
+    return gc::check_launch("gc_plane_dot_f32");
 }

@@ -310,14 +310,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
     const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;   // host guarantees C * H * W < 2^31
 
     float xreg[C::NPXM], treg[C::NPXT > 0 ? C::NPXT : 1], yreg[C::NPY];
-    auto load_x = [&](const float* xb, const float* sb, int row, int c, int iy0, int ix0) -> float {
+    // per-sample channel factors of the tile in flight: this lane's A rows are channel k0 + wk*32 + l31 and its
+    // B columns channel n0 + wn*32 + l31, so modulation is one multiply per fragment (loaded with the prefetch)
+    float sx_cur = 1.f, sy_cur = 1.f, sx_next = 1.f, sy_next = 1.f;
+    auto load_x = [&](const float* xb, int row, int c, int iy0, int ix0) -> float {
         const int r = row % PH, kk = row / PH;
         const int k = k0 + kk, iy = iy0 + r, ix = ix0 + c;
         float v = 0.f;
-        if (c < PWD && row < C::RX && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
-            v = xb[k * xchan + iy * p.in_w + ix];
-            if (sb) v *= sb[k];
-        }
+        if (c < PWD && row < C::RX && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xb[k * xchan + iy * p.in_w + ix];
         return v;
     };
     auto prefetch = [&](int tile) {
@@ -328,17 +328,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
         const int iy0 = oy0 * DOWN - p.pad_y, ix0 = ox0 * DOWN - p.pad_x;
         const float* xb = p.x + (size_t)b * p.K * xchan;
         const float* yb = p.dy + (size_t)b * p.N * ychan;
-        const float* sib = p.si ? p.si + (size_t)b * p.K : nullptr;
+        {
+            const int kl = k0 + wk * 32 + l31, nl = n0 + wn * 32 + l31;
+            sx_next = (p.si && kl < p.K) ? p.si[(size_t)b * p.K + kl] : 1.f;
+            sy_next = (p.so && nl < p.N) ? p.so[(size_t)b * p.N + nl] : 1.f;
+        }
 #pragma unroll
         for (int j = 0; j < C::NPXM; ++j) {
             const int e = t_ + 256 * j;
-            xreg[j] = load_x(xb, sib, e / MAINW, e % MAINW, iy0, ix0);
+            xreg[j] = load_x(xb, e / MAINW, e % MAINW, iy0, ix0);
         }
         if (TAILW > 0) {
 #pragma unroll
             for (int j = 0; j < C::NPXT; ++j) {
                 const int e = t_ + 256 * j;
-                treg[j] = load_x(xb, sib, e / (TAILW > 0 ? TAILW : 1), MAINW + e % (TAILW > 0 ? TAILW : 1), iy0, ix0);
+                treg[j] = load_x(xb, e / (TAILW > 0 ? TAILW : 1), MAINW + e % (TAILW > 0 ? TAILW : 1), iy0, ix0);
             }
         }
 #pragma unroll
@@ -348,10 +352,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
             const int r = row % TR, nn = row / TR;
             const int n = n0 + nn, oy = oy0 + r, ox = ox0 + c;
             float v = 0.f;
-            if (n < p.N && oy < p.out_h && ox < p.out_w) {
-                v = yb[n * ychan + oy * p.out_w + ox];
-                if (p.so) v *= p.so[(size_t)b * p.N + n];
-            }
+            if (n < p.N && oy < p.out_h && ox < p.out_w) v = yb[n * ychan + oy * p.out_w + ox];
             yreg[j] = v;
         }
     };
@@ -381,6 +382,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
     if (t_begin < t_end) {
         prefetch(t_begin);
         commit();
+        sx_cur = sx_next; sy_cur = sy_next;
         __syncthreads();
         const float* xa = xs + (wk * 32 + l31) * C::CSX;
         const float* db = ds + (wn * 32 + l31) * C::CSY;
@@ -392,11 +394,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
 #pragma unroll 2
                 for (int c = 0; c < TPW; c += 2) {
                     const int col = c + hi;
-                    const float bv = db[r * 32 + col];
+                    const float bv = db[r * 32 + col] * sy_cur;
                     const float* xr = xa + r * DOWN * PP + col * DOWN;
 #pragma unroll
                     for (int t = 0; t < NT; ++t) {
-                        const float av = xr[(t / KS) * PP + (t % KS)];
+                        const float av = xr[(t / KS) * PP + (t % KS)] * sx_cur;
                         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[t], 0, 0, 0);
                     }
                 }
@@ -404,6 +406,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
             __syncthreads();
             if (more) {
                 commit();
+                sx_cur = sx_next; sy_cur = sy_next;
                 __syncthreads();
             }
         }

@@ -86,6 +86,43 @@ class HipBackend:
         _lib.check(rc, 'gc_bias_act_bwd_f32')
         return dx
 
+    def bias_act_bwd_reduce(self, dy, y_ref, noise, slope, gain):
+        """-> (dx, psum [B, C, chunks], pdot [B, C, chunks] or None); see gc_bias_act_bwd_reduce_f32."""
+        dev = _lib.require_cuda_f32(dy, y_ref, noise)
+        batch, ch = dy.shape[0], dy.shape[1]
+        inner = dy.numel() // (batch * ch)
+        lib = _lib.load()
+        chunks = lib.gc_bias_act_bwd_chunks(inner)
+        dx = torch.empty_like(dy)
+        psum = torch.empty((batch, ch, chunks), dtype=dy.dtype, device=dev)
+        pdot = torch.empty((batch, ch, chunks), dtype=dy.dtype, device=dev) if noise is not None else None
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_bias_act_bwd_reduce_f32(_lib.ptr(dy), _lib.ptr(y_ref), _lib.ptr(noise), _lib.ptr(dx), _lib.ptr(psum), _lib.ptr(pdot),
+                                                batch, ch, inner, slope, gain, _lib.stream_of(dy))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_bias_act_bwd_reduce_f32')
+        return dx, psum, pdot
+
+    def plane_dot(self, a, b):
+        """[B, C, *] x [B, C, *] -> [B, C]: sum over the trailing dims of a * b."""
+        dev = _lib.require_cuda_f32(a, b)
+        batch, ch = a.shape[0], a.shape[1]
+        inner = a.numel() // (batch * ch)
+        lib = _lib.load()
+        chunks = lib.gc_bias_act_bwd_chunks(inner)
+        partial = torch.empty((batch, ch, chunks), dtype=a.dtype, device=dev)
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_plane_dot_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(partial), batch * ch, inner, _lib.stream_of(a))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_plane_dot_f32')
+        return partial.sum(2) if chunks > 1 else partial.reshape(batch, ch)
+
     def channel_sum(self, x):
         """[B, C, *] -> [C]: sum over every dim but 1."""
         dev = _lib.require_cuda_f32(x)

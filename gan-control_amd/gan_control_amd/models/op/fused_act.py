@@ -44,19 +44,64 @@ class _BiasAct(Function):
         y, noise, noise_w = ctx.saved_tensors
         slope, gain = ctx.cfg
         gx = gb = gn = gnw = None
-        if any(ctx.needs_input_grad[:4]):
+        if not any(ctx.needs_input_grad[:4]):
+            return None, None, None, None, None, None
+        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        want_n = ctx.has_noise and ctx.needs_input_grad[2]
+        want_nw = ctx.has_noise and ctx.needs_input_grad[3]
+        if (want_b or want_nw) and not want_n:
+            # one pass: activation gradient + per-plane partial sums for the bias / noise-strength gradients
+            gx, psum, pdot = _BiasActGradReduce.apply(gy, y, noise if want_nw else None, slope, gain)
+            if want_b:
+                gb = psum.sum((0, 2))
+            if want_nw:
+                gnw = pdot.sum().reshape(noise_w.shape)
+        else:
             gx = _BiasActGrad.apply(gy, y, slope, gain)
-            if ctx.has_bias and ctx.needs_input_grad[1]:
+            if want_b:
                 gb = _channel_sum(gx)
-            if ctx.has_noise and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+            if want_n or want_nw:
                 per_px = gx.sum(1, keepdim=True)                   # [B, 1, *]
-                if ctx.needs_input_grad[2]:
+                if want_n:
                     gn = per_px * noise_w
-                if ctx.needs_input_grad[3]:
+                if want_nw:
                     gnw = (per_px * noise).sum().reshape(noise_w.shape)
-            if not ctx.needs_input_grad[0]:
-                gx = None
+        if not ctx.needs_input_grad[0]:
+            gx = None
         return gx, gb, gn, gnw, None, None
+
+
+REDUCE_CHUNK = 16384      # elements of one plane summed per workgroup (channel_sum_plan in csrc/bias_act.hip)
+
+
+class _BiasActGradReduce(Function):
+    """(gx, psum, pdot) = gc_bias_act_bwd_reduce_f32; every output is linear in gy."""
+
+    @staticmethod
+    def forward(ctx, gy, y, noise, slope, gain):
+        ctx.save_for_backward(y, noise if noise is not None else y.new_empty(0))
+        ctx.cfg = (slope, gain)
+        ctx.has_noise = noise is not None
+        gx, psum, pdot = _backend.get().bias_act_bwd_reduce(gy.contiguous(), y, None if noise is None else noise.contiguous(), slope, gain)
+        if pdot is None:
+            pdot = psum.new_empty(0)
+            ctx.mark_non_differentiable(pdot)
+        return gx, psum, pdot
+
+    @staticmethod
+    def backward(ctx, ggx, gpsum, gpdot):
+        y, noise = ctx.saved_tensors
+        slope, gain = ctx.cfg
+        if not ctx.needs_input_grad[0]:
+            return None, None, None, None, None
+        b, c = y.shape[0], y.shape[1]
+        inner = y.numel() // (b * c)
+        total = torch.zeros_like(y) if ggx is None else ggx
+        if gpsum is not None:
+            total = total + gpsum.repeat_interleave(REDUCE_CHUNK, dim=2)[:, :, :inner].reshape(y.shape)
+        if ctx.has_noise and gpdot is not None and gpdot.numel() > 0:
+            total = total + gpdot.repeat_interleave(REDUCE_CHUNK, dim=2)[:, :, :inner].reshape(y.shape) * noise.reshape(b, 1, *y.shape[2:])
+        return _BiasActGrad.apply(total, y, slope, gain), None, None, None, None
 
 
 class _BiasActGrad(Function):

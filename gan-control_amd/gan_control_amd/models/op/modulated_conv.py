@@ -6,14 +6,26 @@ and runs a grouped conv with groups = B.  Algebraically the same result is
     y = d[b,oc] * conv(x * s[b,ic], W * scale),   d = rsqrt(scale^2 * sum_ic s^2 * sum_k W^2 + 1e-8)
 
 i.e. ONE shared-weight convolution with a per-(b,ic) scale on the way in and a per-(b,oc) scale
-on the way out (relative error vs the reference ~3e-7).
+on the way out (relative error vs the reference ~3e-7).  Both scales
+are applied INSIDE the convolution kernels (while staging / in the epilogue), forward and backward:
+no elementwise pass over the activations is spent on modulation.
+
+Autograd closure (all orders): with  F(x, w, si, so) = so * gconv(si * x, w)
+
+    dF/dx   = F(gy, adj(w), so, si)  with the adjoint geometry       -> _ModConv again
+    dF/dw   = WG(x, gy, si, so)                                      -> _ModWGrad
+    dF/dsi  = sum_hw x * (dF/dx) / si ;  dF/dso = sum_hw gy * y / so -> _PlaneDot (+ a [B,C] division)
+
+and both derivatives of _ModWGrad are _ModConv's, so R1 / path-length double-backward close.
 """
 import math
 
 import torch
+from torch.autograd import Function
 
-from . import conv2d_gradfix, _backend
+from . import _backend
 from ._backend import ConvGeom
+from .conv2d_gradfix import _adjoint_geom, _adjoint_weight
 from .upfirdn2d import upfirdn2d
 
 
@@ -21,6 +33,98 @@ def demod_coefficients(weight, s, scale, eps=1e-8):
     """d[b,oc] = rsqrt(sum_{ic,k} (scale * W[oc,ic,k] * s[b,ic])^2 + eps); weight is [1,OC,IC,k,k], s is [B,IC]."""
     wsq = weight[0].pow(2).sum([2, 3])                     # [OC, IC]
     return torch.rsqrt((s.pow(2) @ wsq.t()) * (scale * scale) + eps)
+
+
+def _safe(scale):
+    """Divisor for the scale gradients; an exactly-zero factor (measure zero) would otherwise give 0/0."""
+    return torch.where(scale == 0, torch.ones_like(scale), scale)
+
+
+class _PlaneDot(Function):
+    """[B,C,H,W] x [B,C,H,W] -> [B,C] on gc_plane_dot_f32."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.save_for_backward(a, b)
+        return _backend.get().plane_dot(a.contiguous(), b.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g4 = g[:, :, None, None]
+        return (g4 * b if ctx.needs_input_grad[0] else None), (g4 * a if ctx.needs_input_grad[1] else None)
+
+
+class _ModConv(Function):
+    """y = so * gconv(si * x, w_t); si / so may be None."""
+
+    @staticmethod
+    def forward(ctx, x, w_t, si, so, geom):
+        y = _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None if si is None else si.contiguous(),
+                                  None if so is None else so.contiguous(), geom)
+        ctx.geom, ctx.in_hw = geom, (x.shape[2], x.shape[3])
+        ctx.has_si, ctx.has_so = si is not None, so is not None
+        empty = x.new_empty(0)
+        ctx.save_for_backward(x, w_t, si if si is not None else empty, so if so is not None else empty, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w_t, si, so, y = ctx.saved_tensors
+        si = si if ctx.has_si else None
+        so = so if ctx.has_so else None
+        g = ctx.geom
+        gx = gw = gsi = gso = None
+        need_si = ctx.has_si and ctx.needs_input_grad[2]
+        if ctx.needs_input_grad[0] or need_si:
+            gx = _ModConv.apply(gy, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw))
+        if ctx.needs_input_grad[1]:
+            gw = _mod_weight_grad(x, gy, si, so, g)
+        if need_si:
+            gsi = _PlaneDot.apply(x, gx) / _safe(si)
+        if ctx.has_so and ctx.needs_input_grad[3]:
+            gso = _PlaneDot.apply(gy, y) / _safe(so)
+        return (gx if ctx.needs_input_grad[0] else None), gw, gsi, gso, None
+
+
+def _mod_weight_grad(x, gy, si, so, g):
+    if g.up == 1:
+        return _ModWGrad.apply(x, gy, si, so, g)
+    # transposed conv: correlate gy (as the "input", decimated by `up`) with x (as the "output gradient")
+    swapped = ConvGeom(g.kh, g.kw, 1, g.up, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x, x.shape[2], x.shape[3])
+    return _ModWGrad.apply(gy, x, so, si, swapped).flip(0, 1).transpose(2, 3)
+
+
+class _ModWGrad(Function):
+    """gw[t,k,n] = sum_{b,o} si[b,k] x[b,k,o*down+t-pad] so[b,n] gy[b,n,o]."""
+
+    @staticmethod
+    def forward(ctx, x, gy, si, so, geom):
+        ctx.geom, ctx.in_hw = geom, (x.shape[2], x.shape[3])
+        ctx.has_si, ctx.has_so = si is not None, so is not None
+        empty = x.new_empty(0)
+        ctx.save_for_backward(x, gy, si if si is not None else empty, so if so is not None else empty)
+        return _backend.get().conv2d_wgrad(x.contiguous(), gy.contiguous(), None if si is None else si.contiguous(),
+                                           None if so is None else so.contiguous(), geom)
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy, si, so = ctx.saved_tensors
+        si = si if ctx.has_si else None
+        so = so if ctx.has_so else None
+        g = ctx.geom
+        gx = ggy = gsi = gso = None
+        need_si = ctx.has_si and ctx.needs_input_grad[2]
+        need_so = ctx.has_so and ctx.needs_input_grad[3]
+        if ctx.needs_input_grad[0] or need_si:
+            gx = _ModConv.apply(gy, _adjoint_weight(ggw), so, si, _adjoint_geom(g, *ctx.in_hw))
+        if ctx.needs_input_grad[1] or need_so:
+            ggy = _ModConv.apply(x, ggw.contiguous(), si, so, g)
+        if need_si:
+            gsi = _PlaneDot.apply(x, gx) / _safe(si)
+        if need_so:
+            gso = _PlaneDot.apply(gy, ggy) / _safe(so)
+        return (gx if ctx.needs_input_grad[0] else None), (ggy if ctx.needs_input_grad[1] else None), gsi, gso, None
 
 
 def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=None, blur_pad=None, padding=None):
@@ -33,26 +137,12 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
     scale = 1.0 / math.sqrt(ic * k * k)
     d = demod_coefficients(weight, s, scale) if demodulate else None
     w = weight[0] * scale                                                  # [OC, IC, k, k]
-    be = _backend.get()
-    fused = not (torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad or s.requires_grad))
     if upsample:
         w_t = w.flip(2, 3).permute(2, 3, 1, 0).contiguous()                # correlation form, [k,k,IC,OC]
-        if fused:
-            oh, ow = (x.shape[2] - 1) * 2 + k, (x.shape[3] - 1) * 2 + k
-            y = be.conv2d(x.contiguous(), w_t, s.contiguous(), None if d is None else d.contiguous(),
-                          ConvGeom(k, k, 2, 1, k - 1, k - 1, oh, ow))
-        else:
-            y = conv2d_gradfix.conv_transpose2d_t(x * s[:, :, None, None], w_t, stride=2, padding=0)
-            if d is not None:
-                y = y * d[:, :, None, None]
+        oh, ow = (x.shape[2] - 1) * 2 + k, (x.shape[3] - 1) * 2 + k
+        y = _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 2, 1, k - 1, k - 1, oh, ow))
         return upfirdn2d(y, blur_kernel, pad=blur_pad)
     pad = k // 2 if padding is None else padding
     w_t = w.permute(2, 3, 1, 0).contiguous()
-    if fused:
-        oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1
-        return be.conv2d(x.contiguous(), w_t, s.contiguous(), None if d is None else d.contiguous(),
-                         ConvGeom(k, k, 1, 1, pad, pad, oh, ow))
-    y = conv2d_gradfix.conv2d_t(x * s[:, :, None, None], w_t, stride=1, padding=pad)
-    if d is not None:
-        y = y * d[:, :, None, None]
-    return y
+    oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1
+    return _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow))

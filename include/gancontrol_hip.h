@@ -83,6 +83,20 @@ int gc_bias_act_f32(const float* x, const float* bias, const float* noise, const
 int gc_bias_act_bwd_f32(const float* dy, const float* y_ref, float* dx, int64_t count,
                         float slope, float gain, gc_stream_t stream);
 
+/* The same gradient fused with the reductions its caller needs (one pass instead of three):
+ *   dx = dy * mask(y_ref);   psum[(b*C + c)*chunks + j] = sum over chunk j of dx[b,c,:]
+ *   pdot[(b*C + c)*chunks + j] = sum over chunk j of dx[b,c,:] * noise[b,:]      (only when noise != null)
+ * with chunks = gc_bias_act_bwd_chunks(inner).  Bias gradient = psum summed over b and j; noise-strength
+ * gradient = pdot summed over everything.  Deterministic (fixed-order block reductions, no atomics). */
+int gc_bias_act_bwd_chunks(int64_t inner);
+int gc_bias_act_bwd_reduce_f32(const float* dy, const float* y_ref, const float* noise, float* dx,
+                               float* psum, float* pdot, int batch, int channels, int64_t inner,
+                               float slope, float gain, gc_stream_t stream);
+
+/* partial[p*chunks + j] = sum over chunk j of a[p,:] * b[p,:], chunks = gc_bias_act_bwd_chunks(inner); planes = B*C.
+ * Gradients of the per-sample modulation / demodulation factors of K3 (sum_hw x * dx and sum_hw dy * y). */
+int gc_plane_dot_f32(const float* a, const float* b, float* partial, int planes, int64_t inner, gc_stream_t stream);
+
 /* Per-channel sum over batch and inner dims: out[c] = sum_{b,i} x[b,c,i]  (bias gradient).
  * Deterministic two-stage reduction; workspace must hold gc_channel_sum_workspace() bytes. */
 size_t gc_channel_sum_workspace(int batch, int channels, int64_t inner);

@@ -80,6 +80,23 @@ class EmulatedBackend:
     def bias_act_bwd(self, dy, y_ref, slope, gain):
         return dy * torch.where(y_ref > 0, torch.full_like(dy, gain), torch.full_like(dy, gain * slope))
 
+    def bias_act_bwd_reduce(self, dy, y_ref, noise, slope, gain):
+        dx = self.bias_act_bwd(dy, y_ref, slope, gain)
+        b, c = dy.shape[0], dy.shape[1]
+        inner = dy.numel() // (b * c)
+        chunk = 16384
+        chunks = -(-inner // chunk)
+        flat = F.pad(dx.reshape(b, c, inner), [0, chunks * chunk - inner]).reshape(b, c, chunks, chunk)
+        psum = flat.sum(3)
+        pdot = None
+        if noise is not None:
+            nz = F.pad(noise.reshape(b, 1, inner), [0, chunks * chunk - inner]).reshape(b, 1, chunks, chunk)
+            pdot = (flat * nz).sum(3)
+        return dx, psum, pdot
+
+    def plane_dot(self, a, b):
+        return (a * b).reshape(a.shape[0], a.shape[1], -1).sum(2)
+
     def channel_sum(self, x):
         return x.sum([d for d in range(x.ndim) if d != 1])
 
