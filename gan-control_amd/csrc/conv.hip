@@ -595,9 +595,13 @@ extern "C" int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const 
     else            rc = d->down == 2 ? dispatch_wgrad<2, 1>(a, pl, s) : dispatch_wgrad<1, 1>(a, pl, s);
     if (rc) return rc;
     if (pl.parts == 1) return GC_OK;
-    const bool vec = count % 4 == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    return launch_wgrad_reduce(static_cast<const float*>(workspace), dw, count, pl.parts, s);
+}
+
+int gcconv::launch_wgrad_reduce(const float* ws, float* dw, size_t count, int parts, hipStream_t s) {
+    const bool vec = count % 4 == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
     const int blocks = (int)std::min<size_t>(((vec ? count / 4 : count) + 255) / 256, 2048);
-    if (vec) hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(workspace), dw, count, pl.parts);
-    else     hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, static_cast<const float*>(workspace), dw, count, pl.parts);
-    return gc::check_launch("gc_conv2d_wgrad_f32(reduce)");
+    if (vec) hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, ws, dw, count, parts);
+    else     hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, ws, dw, count, parts);
+    return gc::check_launch("gc_conv2d_wgrad(reduce)");
 }

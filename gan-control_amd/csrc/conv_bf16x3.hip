@@ -252,6 +252,225 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Weight gradient in split-bf16:  dW[tap][k][n] = sum_px X[k][px + tap] * dY[n][px]   (down = 1)
+// The MFMA reduction index is the PIXEL, so a lane's fragment is 8 consecutive pixels of one channel.  Both
+// tiles sit in LDS pixel-contiguous as 16-byte units of 8 pixels (hi and lo parts).  A horizontal tap shift of
+// tx pixels is a funnel shift over two neighbouring units (4 v_perm for tx = 1, register moves for tx = 2) --
+// every ds_read_b128 stays 16-byte aligned.  Each wave owns a 32k x 32n block for all taps (144 accumulators).
+struct WgArgs {
+    const float* x; const float* dy; const float* si; const float* so; float* ws;
+    int B, K, N, in_h, in_w, out_h, out_w, pad_y, pad_x;
+    int tiles_x, tiles_y, tiles_per_split;
+};
+
+__device__ __forceinline__ uint4 shift_px(const uint4 a, const uint4 b, int tx) {
+    if (tx == 0) return a;
+    if (tx == 2) return make_uint4(a.y, a.z, a.w, b.x);
+    return make_uint4(__builtin_amdgcn_alignbit(a.y, a.x, 16), __builtin_amdgcn_alignbit(a.z, a.y, 16),
+                      __builtin_amdgcn_alignbit(a.w, a.z, 16), __builtin_amdgcn_alignbit(b.x, a.w, 16));
+}
+
+// 8 consecutive floats of one image row starting at column x0 (zero outside [0, width)): two 16-byte loads when
+// the run is interior -- rows start at odd offsets (pad - 1, 1025-wide planes), so the loads are only 4-byte
+// aligned, which global_load_dwordx4 accepts -- and guarded scalar loads at the borders.
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+__device__ __forceinline__ void load8(const float* src, bool ok, int x0, int width, float (&v)[8]) {
+    if (ok && x0 >= 0 && x0 + 7 < width) {
+        const f4u a = *reinterpret_cast<const f4u*>(src), b = *reinterpret_cast<const f4u*>(src + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (ok && x0 + q >= 0 && x0 + q < width) ? src[q] : 0.f;
+    }
+}
+
+__device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4* h, uint4* l) {
+    bf16x8 hh, ll;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float f = v[q] * scale;
+        const __bf16 t = (__bf16)f;
+        hh[q] = t;
+        ll[q] = (__bf16)(f - (float)t);
+    }
+    *h = *reinterpret_cast<uint4*>(&hh);
+    *l = *reinterpret_cast<uint4*>(&ll);
+}
+
+template <int TR, int KS>
+struct WgCfg {
+    static constexpr int KT = 64, NTL = 64;
+    static constexpr int PH = TR + KS - 1;
+    static constexpr int XU = KS == 3 ? 5 : 4, YU = 4;            // 8-pixel units per patch row / dY row
+    static constexpr int CSX = (PH * XU) | 1, CSY = (TR * YU) | 1;   // odd unit strides between channels: conflict-free b128 reads
+    static constexpr int NXU = KT * PH * XU, NYU = NTL * TR * YU;
+    static constexpr int NPX = (NXU + 255) / 256, NPY = (NYU + 255) / 256;
+    static constexpr int SMEM_UNITS = 2 * (KT * CSX + NTL * CSY);
+    static constexpr int NT = KS * KS;
+};
+
+template <int TR, int KS>
+__global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
+    using C = WgCfg<TR, KS>;
+    constexpr int KT = C::KT, NTL = C::NTL, PH = C::PH, XU = C::XU, YU = C::YU, NT = C::NT;
+    __shared__ uint4 smem[C::SMEM_UNITS];
+    uint4* xh = smem;
+    uint4* xl = xh + KT * C::CSX;
+    uint4* yh = xl + KT * C::CSX;
+    uint4* yl = yh + NTL * C::CSY;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int k0 = blockIdx.x * KT, n0 = blockIdx.y * NTL, split = blockIdx.z;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int tiles_per_sample = p.tiles_x * p.tiles_y;
+    const int total_tiles = tiles_per_sample * p.B;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
+    const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
+
+    float xreg[C::NPX][8], yreg[C::NPY][8], xsc[C::NPX], ysc[C::NPY];
+    auto prefetch = [&](int tile) {
+        const int t_ = opaque(tid);
+        const int b = tile / tiles_per_sample;
+        const int rem = tile - b * tiles_per_sample;
+        const int oy0 = (rem / p.tiles_x) * TR, ox0 = (rem % p.tiles_x) * 32;
+        const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+        const float* xb = p.x + (size_t)b * p.K * xchan;
+        const float* yb = p.dy + (size_t)b * p.N * ychan;
+#pragma unroll
+        for (int j = 0; j < C::NPX; ++j) {
+            const int u = t_ + 256 * j;
+            const int xu = u % XU, row = u / XU;
+            const int r = row % PH, kk = row / PH;
+            const int k = k0 + kk, iy = iy0 + r, ixb = ix0 + 8 * xu;
+            const bool ok = u < C::NXU && k < p.K && iy >= 0 && iy < p.in_h;
+            const float* src = xb + k * xchan + iy * p.in_w + ixb;
+            load8(src, ok, ixb, p.in_w, xreg[j]);
+            xsc[j] = (ok && p.si) ? p.si[(size_t)b * p.K + k] : 1.f;
+        }
+#pragma unroll
+        for (int j = 0; j < C::NPY; ++j) {
+            const int u = t_ + 256 * j;
+            const int yu = u % YU, row = u / YU;
+            const int r = row % TR, nn = row / TR;
+            const int n = n0 + nn, oy = oy0 + r, oxb = ox0 + 8 * yu;
+            const bool ok = u < C::NYU && n < p.N && oy < p.out_h;
+            const float* src = yb + n * ychan + oy * p.out_w + oxb;
+            load8(src, ok, oxb, p.out_w, yreg[j]);
+            ysc[j] = (ok && p.so) ? p.so[(size_t)b * p.N + n] : 1.f;
+        }
+    };
+    auto commit = [&]() {
+        const int t_ = opaque(tid);
+#pragma unroll
+        for (int j = 0; j < C::NPX; ++j) {
+            const int u = t_ + 256 * j;
+            const int row = u / XU;
+            uint4 h, l;
+            split8(xreg[j], xsc[j], &h, &l);
+            if (u < C::NXU) {
+                const int o = (row / PH) * C::CSX + (row % PH) * XU + u % XU;
+                xh[o] = h; xl[o] = l;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < C::NPY; ++j) {
+            const int u = t_ + 256 * j;
+            const int row = u / YU;
+            uint4 h, l;
+            split8(yreg[j], ysc[j], &h, &l);
+            if (u < C::NYU) {
+                const int o = (row / TR) * C::CSY + (row % TR) * YU + u % YU;
+                yh[o] = h; yl[o] = l;
+            }
+        }
+    };
+
+    if (t_begin < t_end) {
+        prefetch(t_begin);
+        commit();
+        __syncthreads();
+        const int xa = (wk * 32 + l31) * C::CSX + hi, yb_ = (wn * 32 + l31) * C::CSY + hi;
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            const bool more = tile + 1 < t_end;
+            if (more) prefetch(tile + 1);
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const uint4 ubh = yh[yb_ + r * YU + 2 * st], ubl = yl[yb_ + r * YU + 2 * st];
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&ubh), bl = *reinterpret_cast<const bf16x8*>(&ubl);
+#pragma unroll
+                    for (int ty = 0; ty < KS; ++ty) {
+                        const int o = xa + (r + ty) * XU + 2 * st;
+                        const uint4 a0h = xh[o], a0l = xl[o];
+                        uint4 a1h = a0h, a1l = a0l;
+                        if (KS == 3) { a1h = xh[o + 1]; a1l = xl[o + 1]; }
+#pragma unroll
+                        for (int tx = 0; tx < KS; ++tx) {
+                            const uint4 uh = shift_px(a0h, a1h, tx), ul = shift_px(a0l, a1l, tx);
+                            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh), al = *reinterpret_cast<const bf16x8*>(&ul);
+                            f32x16 c = acc[ty * KS + tx];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                            acc[ty * KS + tx] = c;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (more) {
+                commit();
+                __syncthreads();
+            }
+        }
+    }
+
+    float* out = p.ws + (size_t)split * NT * p.K * p.N;
+    const int n = n0 + wn * 32 + l31;
+    if (n < p.N) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (k < p.K) out[((size_t)t * p.K + k) * p.N + n] = acc[t][r];
+            }
+        }
+    }
+}
+
+struct WgPlan { int splits, tiles_per_split, tiles_x, tiles_y; };
+constexpr int WG_TR = 2;
+
+WgPlan plan_wg(const gc_conv_desc* d) {
+    WgPlan pl;
+    pl.tiles_x = gc::ceil_div(d->out_w, 32);
+    pl.tiles_y = gc::ceil_div(d->out_h, WG_TR);
+    const int total = pl.tiles_x * pl.tiles_y * d->batch;
+    const int ctiles = gc::ceil_div(d->in_ch, 64) * gc::ceil_div(d->out_ch, 64);
+    int want = gc::ceil_div(512, ctiles);      // one workgroup per CU is resident (512 registers per lane): two rounds
+    if (want > total) want = total;
+    if (want < 1) want = 1;
+    pl.tiles_per_split = gc::ceil_div(total, want);
+    pl.splits = gc::ceil_div(total, pl.tiles_per_split);
+    return pl;
+}
+
+bool wg_eligible(const gc_conv_desc* d) {
+    return d->up == 1 && d->down == 1 && d->in_ch >= 64 && d->out_ch >= 64 && d->out_w > 16;
+}
+
 template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
 int launch(Bf16Args a, hipStream_t s) {
     using C = BCfg<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>;
@@ -319,4 +538,36 @@ extern "C" int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const
     }
     if (d->up == 2) return dispatch<2, 1, 1>(a, s);
     return d->down == 2 ? dispatch<1, 2, 1>(a, s) : dispatch<1, 1, 1>(a, s);
+}
+
+extern "C" size_t gc_conv2d_wgrad_bf16x3_workspace(const gc_conv_desc* d) {
+    if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->out_h <= 0 || d->out_w <= 0) return 0;
+    size_t need = gc_conv2d_wgrad_workspace(d);
+    if (wg_eligible(d)) {
+        const WgPlan pl = plan_wg(d);
+        need = std::max(need, (size_t)pl.splits * d->kh * d->kw * d->in_ch * d->out_ch * sizeof(float));
+    }
+    return need;
+}
+
+extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* dy,
+                                          const float* in_scale, const float* out_scale, float* dw,
+                                          void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    int rc = validate(d, "gc_conv2d_wgrad_bf16x3_f32", true);
+    if (rc) return rc;
+    if (!x || !dy || !dw) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_wgrad_bf16x3_f32: null pointer");
+    if (d->batch == 0 || !wg_eligible(d)) return gc_conv2d_wgrad_f32(d, x, dy, in_scale, out_scale, dw, workspace, workspace_bytes, stream);
+    const WgPlan pl = plan_wg(d);
+    const size_t count = (size_t)d->kh * d->kw * d->in_ch * d->out_ch;
+    const size_t need = (size_t)pl.splits * count * sizeof(float);
+    if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_bf16x3_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    WgArgs a{x, dy, in_scale, out_scale, pl.splits == 1 ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch,
+             d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
+    dim3 grid(gc::ceil_div(d->in_ch, 64), gc::ceil_div(d->out_ch, 64), pl.splits);
+    if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<WG_TR, 3>), grid, dim3(256), 0, s, a);
+    else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<WG_TR, 1>), grid, dim3(256), 0, s, a);
+    rc = gc::check_launch("gc_conv2d_wgrad_bf16x3_f32");
+    if (rc || pl.splits == 1) return rc;
+    return launch_wgrad_reduce(static_cast<const float*>(workspace), dw, count, pl.splits, s);
 }

@@ -57,4 +57,7 @@ inline int validate(const gc_conv_desc* d, const char* who, bool wgrad) {
 }
 
 
+// defined in conv.hip: dw[i] = sum_s ws[s][i] in fixed order (deterministic split reduction)
+int launch_wgrad_reduce(const float* ws, float* dw, size_t count, int parts, hipStream_t s);
+
 }  // namespace gcconv

@@ -41,6 +41,8 @@ SIGNATURES = {
     'gc_conv2d_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_wgrad_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'gc_conv2d_wgrad_bf16x3_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
+    'gc_conv2d_wgrad_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
 }
 
 _lib = None

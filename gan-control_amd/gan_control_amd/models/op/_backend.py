@@ -187,14 +187,16 @@ class HipBackend:
         dw = torch.empty((geom.kh, geom.kw, x.shape[1], n_out), dtype=x.dtype, device=dev)
         desc = self._desc(x, n_out, geom)
         lib = _lib.load()
-        nbytes = lib.gc_conv2d_wgrad_workspace(desc)
-        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+        fast = self.conv_mode == 'bf16x3'
+        nbytes = (lib.gc_conv2d_wgrad_bf16x3_workspace if fast else lib.gc_conv2d_wgrad_workspace)(desc)
+        ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
         g = self._guard(dev)
         t0 = self.timer.start() if self.timer else None
         if g: g.__enter__()
         try:
-            rc = lib.gc_conv2d_wgrad_f32(desc, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(dw),
-                                         _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
+            fn = lib.gc_conv2d_wgrad_bf16x3_f32 if fast else lib.gc_conv2d_wgrad_f32
+            rc = fn(desc, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(dw),
+                    _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
         finally:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_conv2d_wgrad_f32')

@@ -157,6 +157,13 @@ int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const float* dy,
                         const float* in_scale, const float* out_scale, float* dw,
                         void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
+/* Split-bf16 variant of the weight gradient (same contract; shapes it does not cover -- down = 2, fewer than
+ * 32 channels, planes <= 16 px wide -- run on gc_conv2d_wgrad_f32, so size the workspace with this function). */
+size_t gc_conv2d_wgrad_bf16x3_workspace(const gc_conv_desc* d);
+int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* dy,
+                               const float* in_scale, const float* out_scale, float* dw,
+                               void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,6 +219,13 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
         ref = emu.conv2d(x.double(), wt.double(), *[None if t is None else t.double() for t in a], geom)
         out = hip.conv2d(x.to(DEV), wt.to(DEV), *[None if t is None else t.to(DEV) for t in a], geom)
         assert rel_err(out, ref) < 5e-5, use_scales
+    if up == 1:
+        dy = torch.randn(b, N, oh, ow, generator=gen)
+        for use_scales in (False, True):
+            a = (si, so) if use_scales else (None, None)
+            ref = emu.conv2d_wgrad(x.double(), dy.double(), *[None if t is None else t.double() for t in a], geom)
+            out = hip.conv2d_wgrad(x.to(DEV), dy.to(DEV), *[None if t is None else t.to(DEV) for t in a], geom)
+            assert rel_err(out, ref) < 5e-5, ('wgrad', use_scales)
 
 
 @pytest.mark.parametrize('size', [64, 256])
