@@ -72,7 +72,7 @@ template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
 __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     using C = BCfg<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>;
     static_assert(WG_OC * WG_PX == 4, "4 waves per workgroup");
-    constexpr int OCT = C::OCT, TPH = C::TPH, PH = C::PH, PWD = C::PWD, PLANE = C::PLANE;
+    constexpr int OCT = C::OCT, TPH = C::TPH, PWD = C::PWD, PLANE = C::PLANE;
     const ConvArgs& p = a.c;
     __shared__ uint4 smem[C::SMEM_UNITS];
     uint4* wl_h = smem;                         // [tap][kg][OCT]
@@ -120,6 +120,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     float preg[C::NPU][8];
     float sreg[8];
 
+    // Buffer-descriptor loads: scalar channel offset + 32-bit lane offset, hardware zero-fill outside the image, and
+    // nothing touches the results until commit(), so every load stays in flight across the MFMA block.
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)p.K * chan * 4u);
+    const unsigned wbytes = (unsigned)(KS * KS) * a.kgroups * p.N * 16u;
+    const __amdgpu_buffer_rsrc_t rwh = make_rsrc(a.wh, wbytes), rwl = make_rsrc(a.wl, wbytes);
     auto prefetch = [&](int k0) {
         const int t_ = opaque(tid);
         // weights: unit u -> (tap, kg, oc); plain 16-byte copies of the pre-split slab
@@ -131,21 +136,17 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
             const int jy = UP == 1 ? t / KS : (ax.n == 2 ? t >> 1 : t), jx = UP == 1 ? t % KS : (ax.n == 2 ? t & 1 : 0);
             const int tap = (ay.t0 + jy * UP) * KS + ax.t0 + jx * UP;
             const int kg = k0 / 8 + kgl, n = n0 + oc;
-            uint4 vh = make_uint4(0, 0, 0, 0), vl = vh;
-            if (u < C::WUNITS && t < ntaps && kg < a.kgroups && n < p.N) {
-                const int g = (tap * a.kgroups + kg) * p.N + n;
-                vh = a.wh[g];
-                vl = a.wl[g];
-            }
-            wreg_h[j] = vh;
-            wreg_l[j] = vl;
+            const bool ok = u < C::WUNITS && t < ntaps && kg < a.kgroups && n < p.N;
+            const unsigned gb = ok ? (unsigned)((tap * a.kgroups + kg) * p.N + n) * 16u : OOB;
+            wreg_h[j] = buf_load_u128(rwh, gb, 0);
+            wreg_l[j] = buf_load_u128(rwl, gb, 0);
         }
-        // patch: threads 0..127 take channel group 0, 128..255 group 1; a unit = 8 channels of one pixel
-        const int kgl = t_ >> 7, pbase = t_ & 127;
+        // patch: waves 0,1 take channel group 0, waves 2,3 group 1; a unit = 8 channels of one pixel
+        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), pbase = t_ & 127;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = k0 + kgl * 8 + q;
-            sreg[q] = (sib && k < p.K) ? sib[k] : 1.f;
+            sreg[q] = sib ? sib[min(k, p.K - 1)] : 1.f;
         }
 #pragma unroll
         for (int j = 0; j < C::NPU; ++j) {
@@ -153,29 +154,30 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
             const int r = pos / PWD, c = pos % PWD;
             const int iy = iy0 + r, ix = ix0 + c;
             const bool ok = pos < PLANE && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-            const int off = iy * p.in_w + ix;
+            const unsigned boff = ok ? (unsigned)(iy * p.in_w + ix) * 4u : OOB;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const int k = k0 + kgl * 8 + q;
-                preg[j][q] = (ok && k < p.K) ? xb[k * chan + off] : 0.f;
+                const int k = min(k0 + kgl * 8 + q, p.K - 1);          // wave-uniform -> scalar offset
+                preg[j][q] = buf_load_f32(rx, boff, (unsigned)k * chan * 4u);
             }
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int k0) {
         const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
             const int u = t_ + 256 * j;
             if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; wl_l[u] = wreg_l[j]; }
         }
-        const int kgl = t_ >> 7, pbase = t_ & 127;
+        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), pbase = t_ & 127;
 #pragma unroll
         for (int j = 0; j < C::NPU; ++j) {
             const int pos = pbase + 128 * j;
             bf16x8 h, l;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float v = preg[j][q] * sreg[q];
+                const bool kok = k0 + kgl * 8 + q < p.K;               // only false in a ragged last chunk
+                const float v = kok ? preg[j][q] * sreg[q] : 0.f;
                 const __bf16 hh = (__bf16)v;
                 h[q] = hh;
                 l[q] = (__bf16)(v - (float)hh);
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
 
     if (ntaps > 0) {
         prefetch(0);
-        commit();
+        commit(0);
         __syncthreads();
         for (int k0 = 0; k0 < p.K; k0 += KCB) {
             const bool more = k0 + KCB < p.K;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
             }
             __syncthreads();
             if (more) {
-                commit();
+                commit(k0 + KCB);
                 __syncthreads();
             }
         }
@@ -269,20 +271,6 @@ __device__ __forceinline__ uint4 shift_px(const uint4 a, const uint4 b, int tx) 
     if (tx == 2) return make_uint4(a.y, a.z, a.w, b.x);
     return make_uint4(__builtin_amdgcn_alignbit(a.y, a.x, 16), __builtin_amdgcn_alignbit(a.z, a.y, 16),
                       __builtin_amdgcn_alignbit(a.w, a.z, 16), __builtin_amdgcn_alignbit(b.x, a.w, 16));
-}
-
-// 8 consecutive floats of one image row starting at column x0 (zero outside [0, width)): two 16-byte loads when
-// the run is interior -- rows start at odd offsets (pad - 1, 1025-wide planes), so the loads are only 4-byte
-// aligned, which global_load_dwordx4 accepts -- and guarded scalar loads at the borders.
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-__device__ __forceinline__ void load8(const float* src, bool ok, int x0, int width, float (&v)[8]) {
-    if (ok && x0 >= 0 && x0 + 7 < width) {
-        const f4u a = *reinterpret_cast<const f4u*>(src), b = *reinterpret_cast<const f4u*>(src + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-    } else {
-#pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (ok && x0 + q >= 0 && x0 + q < width) ? src[q] : 0.f;
-    }
 }
 
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4* h, uint4* l) {
@@ -337,15 +325,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
     const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
     const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
 
-    float xreg[C::NPX][8], yreg[C::NPY][8], xsc[C::NPX], ysc[C::NPY];
+    float4 xreg[C::NPX][2], yreg[C::NPY][2];
+    float xsc[C::NPX], ysc[C::NPY];
+    int xcol[C::NPX], ycol[C::NPY];          // first column of each unit (for the border masks applied at commit)
+    unsigned xneg = 0;                       // units loaded from offset 0 instead of -pad (see prefetch)
+    const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
     auto prefetch = [&](int tile) {
         const int t_ = opaque(tid);
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
         const int oy0 = (rem / p.tiles_x) * TR, ox0 = (rem % p.tiles_x) * 32;
         const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
-        const float* xb = p.x + (size_t)b * p.K * xchan;
-        const float* yb = p.dy + (size_t)b * p.N * ychan;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
 #pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
             const int u = t_ + 256 * j;
@@ -353,9 +345,18 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
             const int r = row % PH, kk = row / PH;
             const int k = k0 + kk, iy = iy0 + r, ixb = ix0 + 8 * xu;
             const bool ok = u < C::NXU && k < p.K && iy >= 0 && iy < p.in_h;
-            const float* src = xb + k * xchan + iy * p.in_w + ixb;
-            load8(src, ok, ixb, p.in_w, xreg[j]);
-            xsc[j] = (ok && p.si) ? p.si[(size_t)b * p.K + k] : 1.f;
+            // rows start at odd offsets (pad - 1, 1025-wide planes): the 16-byte loads are only 4-byte aligned,
+            // which buffer_load_dwordx4 accepts; each dword is range-checked separately
+            // The very first unit of a sample (k = 0, iy = 0, left halo) would start at a NEGATIVE offset, which the
+            // range check rejects as a whole: load it from offset 0 and shift it into place at commit time.
+            const int lin = k * xchan + iy * p.in_w + ixb;
+            const bool neg = ok && lin < 0;
+            const unsigned off = ok ? (unsigned)(neg ? 0 : lin) * 4u : OOB;
+            xreg[j][0] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 0));
+            xreg[j][1] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 16));
+            xsc[j] = p.si ? p.si[(size_t)b * p.K + min(k, p.K - 1)] : 1.f;
+            xcol[j] = ok ? ixb : -100000;
+            xneg = neg ? (xneg | (1u << j)) : (xneg & ~(1u << j));
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
@@ -364,10 +365,23 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
             const int r = row % TR, nn = row / TR;
             const int n = n0 + nn, oy = oy0 + r, oxb = ox0 + 8 * yu;
             const bool ok = u < C::NYU && n < p.N && oy < p.out_h;
-            const float* src = yb + n * ychan + oy * p.out_w + oxb;
-            load8(src, ok, oxb, p.out_w, yreg[j]);
-            ysc[j] = (ok && p.so) ? p.so[(size_t)b * p.N + n] : 1.f;
+            const unsigned off = ok ? (unsigned)(n * ychan + oy * p.out_w + oxb) * 4u : OOB;
+            yreg[j][0] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 0));
+            yreg[j][1] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 16));
+            ysc[j] = p.so ? p.so[(size_t)b * p.N + min(n, p.N - 1)] : 1.f;
+            ycol[j] = ok ? oxb : -100000;
         }
+    };
+    auto unit8 = [&](const float4 (&r)[2], int col0, int width, float scale, bool shifted, uint4* h, uint4* l) {
+        float v[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
+        if (shifted) {      // data starts at column 0 but the unit starts at column -1 (pad_x = 1, checked on the host)
+#pragma unroll
+            for (int q = 7; q > 0; --q) v[q] = v[q - 1];
+            v[0] = 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = (col0 + q >= 0 && col0 + q < width) ? v[q] : 0.f;   // row borders
+        split8(v, scale, h, l);
     };
     auto commit = [&]() {
         const int t_ = opaque(tid);
@@ -376,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
             const int u = t_ + 256 * j;
             const int row = u / XU;
             uint4 h, l;
-            split8(xreg[j], xsc[j], &h, &l);
+            unit8(xreg[j], xcol[j], p.in_w, xsc[j], (xneg >> j) & 1u, &h, &l);
             if (u < C::NXU) {
                 const int o = (row / PH) * C::CSX + (row % PH) * XU + u % XU;
                 xh[o] = h; xl[o] = l;
@@ -387,7 +401,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
             const int u = t_ + 256 * j;
             const int row = u / YU;
             uint4 h, l;
-            split8(yreg[j], ysc[j], &h, &l);
+            unit8(yreg[j], ycol[j], p.out_w, ysc[j], false, &h, &l);
             if (u < C::NYU) {
                 const int o = (row / TR) * C::CSY + (row % TR) * YU + u % YU;
                 yh[o] = h; yl[o] = l;
@@ -468,7 +482,7 @@ WgPlan plan_wg(const gc_conv_desc* d) {
 }
 
 bool wg_eligible(const gc_conv_desc* d) {
-    return d->up == 1 && d->down == 1 && d->in_ch >= 64 && d->out_ch >= 64 && d->out_w > 16;
+    return d->up == 1 && d->down == 1 && d->in_ch >= 64 && d->out_ch >= 64 && d->out_w > 16 && d->pad_x >= 0 && d->pad_x <= 1;
 }
 
 template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>

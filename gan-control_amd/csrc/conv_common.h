@@ -53,9 +53,33 @@ inline int validate(const gc_conv_desc* d, const char* who, bool wgrad) {
     if ((long long)d->in_ch * d->in_h * d->in_w > lim || (long long)d->out_ch * d->out_h * d->out_w > lim ||
         (long long)d->kh * d->kw * d->in_ch * d->out_ch > lim)
         return gc::fail(GC_ERR_UNSUPPORTED, "%s: a per-sample plane set exceeds 2^31 elements", who);
+    // buffer-descriptor addressing: one sample's planes (and the weight slab) must stay below 2 GiB
+    const long long blim = (1LL << 31) - 1;
+    if ((long long)d->in_ch * d->in_h * d->in_w * 4 > blim || (long long)d->out_ch * d->out_h * d->out_w * 4 > blim ||
+        (long long)d->kh * d->kw * (d->in_ch + 7) / 8 * d->out_ch * 16 > blim)
+        return gc::fail(GC_ERR_UNSUPPORTED, "%s: a per-sample tensor exceeds 2 GiB", who);
     return GC_OK;
 }
 
+
+// Buffer-descriptor loads (cdna guide T8): address = descriptor base + scalar byte offset + 32-bit lane byte
+// offset -> no 64-bit VALU address arithmetic, and the hardware returns 0 for lane offsets >= the buffer size, so
+// out-of-image elements need no exec-mask branch: they are given the offset OOB (beyond any buffer used here).
+constexpr unsigned OOB = 0x80000000u;
+// The descriptor inputs go through readfirstlane so the compiler can PROVE them wave-uniform; otherwise it wraps
+// every buffer instruction in a waterfall loop (cdna guide T20).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    const unsigned nb = __builtin_amdgcn_readfirstlane(bytes);
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0, (int)nb, 0x00020000);
+}
+__device__ __forceinline__ float buf_load_f32(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 0));
+}
+__device__ __forceinline__ uint4 buf_load_u128(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 0));
+}
 
 // defined in conv.hip: dw[i] = sum_s ws[s][i] in fixed order (deterministic split reduction)
 int launch_wgrad_reduce(const float* ws, float* dw, size_t count, int parts, hipStream_t s);
