@@ -114,6 +114,10 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     float4 wreg[C::NWI];
     float preg[C::NPE], sreg[C::NPE];   // raw patch values and their in_scale factors (multiplied at commit time)
 
+    // Buffer-descriptor loads (conv_common.h): 32-bit lane byte offsets, hardware zero-fill for everything outside
+    // the image / the weight slab, results untouched until commit() so the loads span the whole MFMA block.
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)p.K * chan * 4u);
+    const __amdgpu_buffer_rsrc_t rw = make_rsrc(p.w, (unsigned)(KS * KS) * p.K * p.N * 4u);
     auto prefetch = [&](int k0) {
         const int t_ = opaque(tid);
         const int wcol = (t_ % C::F4) * 4, wrow0 = t_ / C::F4;
@@ -125,19 +129,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
             const int jy = UP == 1 ? t / KS : (ax.n == 2 ? t >> 1 : t), jx = UP == 1 ? t % KS : (ax.n == 2 ? t & 1 : 0);
             const int ty = ay.t0 + jy * UP, tx = ax.t0 + jx * UP;
             const int k = k0 + kk, n = n0 + wcol;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (t < ntaps && k < p.K) {
-                const float* src = p.w + ((ty * KS + tx) * p.K + k) * p.N + n;
-                if (wvec) {
-                    if (n < p.N) v = *reinterpret_cast<const float4*>(src);
-                } else {
-                    if (n < p.N) v.x = src[0];
-                    if (n + 1 < p.N) v.y = src[1];
-                    if (n + 2 < p.N) v.z = src[2];
-                    if (n + 3 < p.N) v.w = src[3];
-                }
+            const bool ok = t < ntaps && k < p.K;
+            const unsigned base = (unsigned)(((ty * KS + tx) * p.K + k) * p.N + n) * 4u;
+            if (wvec) {
+                wreg[j] = __builtin_bit_cast(float4, buf_load_u128(rw, (ok && n < p.N) ? base : OOB, 0));
+            } else {
+                wreg[j].x = buf_load_f32(rw, (ok && n < p.N) ? base : OOB, 0);
+                wreg[j].y = buf_load_f32(rw, (ok && n + 1 < p.N) ? base + 4u : OOB, 0);
+                wreg[j].z = buf_load_f32(rw, (ok && n + 2 < p.N) ? base + 8u : OOB, 0);
+                wreg[j].w = buf_load_f32(rw, (ok && n + 3 < p.N) ? base + 12u : OOB, 0);
             }
-            wreg[j] = v;
         }
         // input patch: element e = tid + 256 j -> (kk, r, c), zero outside the image
 #pragma unroll
@@ -146,13 +147,9 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
             const int kk = e / (PH * PWD), pos = e % (PH * PWD);
             const int r = pos / PWD, c = pos % PWD;
             const int k = k0 + kk, iy = iy0 + r, ix = ix0 + c;
-            float v = 0.f, sc = 1.f;
-            if (e < KC * PH * PWD && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) {
-                v = xb[k * chan + iy * p.in_w + ix];
-                if (sib) sc = sib[k];
-            }
-            preg[j] = v;
-            sreg[j] = sc;
+            const bool ok = e < KC * PH * PWD && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+            preg[j] = buf_load_f32(rx, ok ? (unsigned)(k * chan + iy * p.in_w + ix) * 4u : OOB, 0);
+            sreg[j] = sib ? sib[min(k, p.K - 1)] : 1.f;
         }
     };
     auto commit = [&]() {
@@ -313,12 +310,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
     // per-sample channel factors of the tile in flight: this lane's A rows are channel k0 + wk*32 + l31 and its
     // B columns channel n0 + wn*32 + l31, so modulation is one multiply per fragment (loaded with the prefetch)
     float sx_cur = 1.f, sy_cur = 1.f, sx_next = 1.f, sy_next = 1.f;
-    auto load_x = [&](const float* xb, int row, int c, int iy0, int ix0) -> float {
+    const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
+    auto load_x = [&](__amdgpu_buffer_rsrc_t rx, int row, int c, int iy0, int ix0) -> float {
         const int r = row % PH, kk = row / PH;
         const int k = k0 + kk, iy = iy0 + r, ix = ix0 + c;
-        float v = 0.f;
-        if (c < PWD && row < C::RX && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w) v = xb[k * xchan + iy * p.in_w + ix];
-        return v;
+        const bool ok = c < PWD && row < C::RX && k < p.K && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        return buf_load_f32(rx, ok ? (unsigned)(k * xchan + iy * p.in_w + ix) * 4u : OOB, 0);
     };
     auto prefetch = [&](int tile) {
         const int t_ = opaque(tid);
@@ -326,8 +323,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
         const int rem = tile - b * tiles_per_sample;
         const int oy0 = (rem / p.tiles_x) * TR, ox0 = (rem % p.tiles_x) * TPW;
         const int iy0 = oy0 * DOWN - p.pad_y, ix0 = ox0 * DOWN - p.pad_x;
-        const float* xb = p.x + (size_t)b * p.K * xchan;
-        const float* yb = p.dy + (size_t)b * p.N * ychan;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
         {
             const int kl = k0 + wk * 32 + l31, nl = n0 + wn * 32 + l31;
             sx_next = (p.si && kl < p.K) ? p.si[(size_t)b * p.K + kl] : 1.f;
@@ -336,13 +333,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
 #pragma unroll
         for (int j = 0; j < C::NPXM; ++j) {
             const int e = t_ + 256 * j;
-            xreg[j] = load_x(xb, e / MAINW, e % MAINW, iy0, ix0);
+            xreg[j] = load_x(rx, e / MAINW, e % MAINW, iy0, ix0);
         }
         if (TAILW > 0) {
 #pragma unroll
             for (int j = 0; j < C::NPXT; ++j) {
                 const int e = t_ + 256 * j;
-                treg[j] = load_x(xb, e / (TAILW > 0 ? TAILW : 1), MAINW + e % (TAILW > 0 ? TAILW : 1), iy0, ix0);
+                treg[j] = load_x(rx, e / (TAILW > 0 ? TAILW : 1), MAINW + e % (TAILW > 0 ? TAILW : 1), iy0, ix0);
             }
         }
 #pragma unroll
@@ -351,9 +348,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
             const int c = e % 32, row = e / 32;
             const int r = row % TR, nn = row / TR;
             const int n = n0 + nn, oy = oy0 + r, ox = ox0 + c;
-            float v = 0.f;
-            if (n < p.N && oy < p.out_h && ox < p.out_w) v = yb[n * ychan + oy * p.out_w + ox];
-            yreg[j] = v;
+            const bool ok = n < p.N && oy < p.out_h && ox < p.out_w;
+            yreg[j] = buf_load_f32(ry, ok ? (unsigned)(n * ychan + oy * p.out_w + ox) * 4u : OOB, 0);
         }
     };
     auto commit = [&]() {
