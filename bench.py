@@ -47,6 +47,7 @@ def parse():
     ap.add_argument('--precision', default=None, choices=['f32', 'bf16x3'], help='conv arithmetic (default: GANCONTROL_CONV_PRECISION or f32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--timer', default='roofline', choices=['roofline', 'all'], help='which launches get HIP-event brackets in the timed region')
     ap.add_argument('--cpu-baseline-size', type=int, default=None, help='resolution of the CPU sample (default: --size)')
     return ap.parse_args()
 
@@ -95,8 +96,10 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('GANCONTROL_FORCE_DDP') == '1')
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29511')
         dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
 
     from gan_control_amd import _lib
@@ -114,7 +117,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -124,7 +127,7 @@ def main():
         it += 1
     timer = None
     if rank == 0 and not args.no_kernel_timer:
-        timer = KernelTimer()
+        timer = KernelTimer(only=None if args.timer == 'all' else ('conv', 'fir44'))
         _backend.get().timer = timer
     barrier()
     t0 = time.perf_counter()
@@ -136,7 +139,7 @@ def main():
     _backend.get().timer = None
 
     t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
     stats = trainer.reduced_stats()
@@ -177,7 +180,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_size or args.size)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

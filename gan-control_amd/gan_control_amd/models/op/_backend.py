@@ -36,7 +36,7 @@ class HipBackend:
             return y
         lib = _lib.load()
         g = self._guard(dev)
-        t0 = self.timer.start() if self.timer else None
+        t0 = self.timer.start('fir44') if self.timer else None
         if g: g.__enter__()
         try:
             rc = lib.gc_upfirdn2d_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n * c, h, w, out_h, out_w,
@@ -59,7 +59,7 @@ class HipBackend:
         inner = x.numel() // (batch * ch)
         lib = _lib.load()
         g = self._guard(dev)
-        t0 = self.timer.start() if self.timer else None
+        t0 = self.timer.start('bias_act') if self.timer else None
         if g: g.__enter__()
         try:
             rc = lib.gc_bias_act_f32(_lib.ptr(x), _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), _lib.ptr(y),
@@ -164,7 +164,7 @@ class HipBackend:
         elif self.conv_mode != 'f32':
             raise RuntimeError('GANCONTROL_CONV_PRECISION must be f32 or bf16x3, got %r' % self.conv_mode)
         g = self._guard(dev)
-        t0 = self.timer.start() if self.timer else None
+        t0 = self.timer.start('conv') if self.timer else None
         if g: g.__enter__()
         try:
             if ws is None:
@@ -191,7 +191,7 @@ class HipBackend:
         nbytes = (lib.gc_conv2d_wgrad_bf16x3_workspace if fast else lib.gc_conv2d_wgrad_workspace)(desc)
         ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
         g = self._guard(dev)
-        t0 = self.timer.start() if self.timer else None
+        t0 = self.timer.start('wgrad') if self.timer else None
         if g: g.__enter__()
         try:
             fn = lib.gc_conv2d_wgrad_bf16x3_f32 if fast else lib.gc_conv2d_wgrad_f32

@@ -12,12 +12,18 @@ all-reduce moves 2*(N-1)/N of the payload per GPU; 32 MiB buckets are large enou
 bandwidth- rather than latency-bound yet leave 4 buckets per network in flight to hide behind
 the remaining backward.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
 
 def is_dist():
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    """True when gradients must be exchanged.  GANCONTROL_FORCE_DDP=1 also turns the collective path on for a
+    single-rank group, so the RCCL code path can be exercised on a one-GPU machine (tests)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get('GANCONTROL_FORCE_DDP') == '1'
 
 
 def world_size():

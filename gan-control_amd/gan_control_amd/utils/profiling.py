@@ -43,12 +43,13 @@ def conv_flops(batch, k_in, n_out, in_h, in_w, geom):
 
 
 class KernelTimer:
-    def __init__(self):
+    def __init__(self, only=None):
         self.records = []          # (name, start_event, end_event, work)
         self.enabled = True
+        self.only = only           # None: every launch; else a tuple of kinds ('conv', 'wgrad', 'fir44', 'bias_act')
 
-    def start(self):
-        if not self.enabled:
+    def start(self, kind=None):
+        if not self.enabled or (self.only is not None and kind not in self.only):
             return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()

@@ -236,3 +236,23 @@ def test_network_golden_bf16x3(size, bf16x3_mode):
 def test_step_golden_bf16x3(bf16x3_mode):
     import step_checks
     step_checks.check_step(DEV)
+
+
+def test_bench_ddp_path_single_rank():
+    """bench.py through torch.distributed.run with one rank and the collective path forced on: RCCL init, bucketed
+    gradient all-reduce from autograd hooks, barrier/MAX timing -- everything the multi-GPU launch does."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import REPO
+    env = dict(os.environ, GANCONTROL_FORCE_DDP='1', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', os.path.join(REPO, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+           '--size', '64', '--batch-per-gpu', '4', '--no-cpu-baseline']
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith('{')][-1]
+    rec = json.loads(line)
+    assert rec['n_gpus'] == 1 and rec['value'] > 0 and rec['unit'] == 'images/sec'
+    assert all(v == v for v in rec['losses'].values()), 'NaN loss'
