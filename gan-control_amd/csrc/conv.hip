@@ -37,9 +37,7 @@ namespace {
 
 using namespace gcconv;
 
-constexpr int KC = 8;  // input channels staged per LDS chunk (forward kernel)
-
-template <int WG_OC, int WG_PX, int KSPLIT, int WOC, int WPX, int TPW, int UP, int DOWN, int KS>
+template <int WG_OC, int WG_PX, int KSPLIT, int KCT, int WOC, int WPX, int TPW, int UP, int DOWN, int KS>
 struct ConvCfg {
     static constexpr int OCT = WG_OC * WOC * 32;           // output channels per workgroup
     static constexpr int RPB = 32 / TPW;                   // tile rows covered by one 32-pixel MFMA column block
@@ -49,19 +47,20 @@ struct ConvCfg {
     static constexpr int PWD = (TPW - 1) * DOWN + NT1;     // patch columns
     static constexpr int PP = patch_pitch(PWD, TPW);       // patch row pitch
     static constexpr int PLANE = PH * PP;
-    static constexpr int WL = NT1 * NT1 * KC * OCT;        // weight slab floats
-    static constexpr int PATCH = KC * PLANE;
+    static constexpr int WL = NT1 * NT1 * KCT * OCT;        // weight slab floats
+    static constexpr int PATCH = KCT * PLANE;
     static constexpr int RED = KSPLIT > 1 ? 4 * WOC * WPX * 16 * 64 : 0;
     static constexpr int SMEM = cmax(WL + PATCH, RED);
-    static constexpr int NPE = (KC * PH * PWD + 255) / 256;   // patch elements prefetched per thread
+    static constexpr int NPE = (KCT * PH * PWD + 255) / 256;   // patch elements prefetched per thread
     static constexpr int F4 = OCT / 4;                        // float4 per weight row
     static constexpr int RPI = 256 / F4;                      // weight rows per staging iteration
-    static constexpr int NWI = (NT1 * NT1 * KC + RPI - 1) / RPI;
+    static constexpr int NWI = (NT1 * NT1 * KCT + RPI - 1) / RPI;
 };
 
-template <int WG_OC, int WG_PX, int KSPLIT, int WOC, int WPX, int TPW, int UP, int DOWN, int KS>
+template <int WG_OC, int WG_PX, int KSPLIT, int KCT, int WOC, int WPX, int TPW, int UP, int DOWN, int KS>
 __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
-    using C = ConvCfg<WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW, UP, DOWN, KS>;
+    using C = ConvCfg<WG_OC, WG_PX, KSPLIT, KCT, WOC, WPX, TPW, UP, DOWN, KS>;
+    constexpr int KC = KCT;   // input channels staged per LDS chunk
     static_assert(WG_OC * WG_PX * KSPLIT == 4, "4 waves per workgroup");
     static_assert(UP == 1 || DOWN == 1, "up and down are exclusive");
     constexpr int OCT = C::OCT, RPB = C::RPB, TPH = C::TPH, PH = C::PH, PWD = C::PWD, PP = C::PP, PLANE = C::PLANE;
@@ -476,16 +475,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 }
 
 // --------------------------------------------------------------------------------------------
-template <int WG_OC, int WG_PX, int KSPLIT, int WOC, int WPX, int TPW, int UP, int DOWN, int KS>
+template <int WG_OC, int WG_PX, int KSPLIT, int KCT, int WOC, int WPX, int TPW, int UP, int DOWN, int KS>
 int launch_conv(ConvArgs a, hipStream_t s) {
-    using C = ConvCfg<WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW, UP, DOWN, KS>;
+    using C = ConvCfg<WG_OC, WG_PX, KSPLIT, KCT, WOC, WPX, TPW, UP, DOWN, KS>;
     const int qh = gc::ceil_div(a.out_h, UP), qw = gc::ceil_div(a.out_w, UP);
     a.tiles_y = gc::ceil_div(qh, C::TPH);
     a.tiles_x = gc::ceil_div(qw, TPW);
     const long long gx = (long long)a.tiles_x * a.tiles_y * UP * UP * a.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_f32: grid too large");
     dim3 grid((unsigned)gx, gc::ceil_div(a.N, C::OCT));
-    hipLaunchKernelGGL((conv_mfma_kernel<WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW, UP, DOWN, KS>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_mfma_kernel<WG_OC, WG_PX, KSPLIT, KCT, WOC, WPX, TPW, UP, DOWN, KS>), grid, dim3(256), 0, s, a);
     return gc::check_launch("gc_conv2d_f32");
 }
 
@@ -493,19 +492,19 @@ int launch_conv(ConvArgs a, hipStream_t s) {
 template <int UP, int DOWN, int KS>
 int dispatch_conv(const ConvArgs& a, hipStream_t s) {
     const int qw = gc::ceil_div(a.out_w, UP), qh = gc::ceil_div(a.out_h, UP);
-    if (qw <= 4) return launch_conv<1, 1, 4, 1, 1, 4, UP, DOWN, KS>(a, s);
-    if (qw <= 8) return launch_conv<1, 1, 4, 1, 1, 8, UP, DOWN, KS>(a, s);
-    if (qw <= 16) return launch_conv<1, 1, 4, 1, 1, 16, UP, DOWN, KS>(a, s);
+    if (qw <= 4) return launch_conv<1, 1, 4, 32, 1, 1, 4, UP, DOWN, KS>(a, s);
+    if (qw <= 8) return launch_conv<1, 1, 4, 32, 1, 1, 8, UP, DOWN, KS>(a, s);
+    if (qw <= 16) return launch_conv<1, 1, 4, 32, 1, 1, 16, UP, DOWN, KS>(a, s);
     if constexpr (DOWN == 2) {
-        if (a.N <= 64) return launch_conv<2, 2, 1, 1, 1, 32, UP, DOWN, KS>(a, s);
+        if (a.N <= 64) return launch_conv<2, 2, 1, 8, 1, 1, 32, UP, DOWN, KS>(a, s);
     } else {
-        if (a.N <= 32) return launch_conv<1, 4, 1, 1, 4, 32, UP, DOWN, KS>(a, s);
-        if (a.N <= 64) return launch_conv<1, 4, 1, 2, 2, 32, UP, DOWN, KS>(a, s);
+        if (a.N <= 32) return launch_conv<1, 4, 1, 8, 1, 4, 32, UP, DOWN, KS>(a, s);
+        if (a.N <= 64) return launch_conv<1, 4, 1, 8, 2, 2, 32, UP, DOWN, KS>(a, s);
     }
     // 128oc x (4 rows x 32 px) tiles unless that leaves most CUs idle
     const long long big = (long long)gc::ceil_div(qw, 32) * gc::ceil_div(qh, 4) * UP * UP * a.B * gc::ceil_div(a.N, 128);
-    if (big < 512) return launch_conv<2, 2, 1, 1, 1, 32, UP, DOWN, KS>(a, s);
-    return launch_conv<2, 2, 1, 2, 2, 32, UP, DOWN, KS>(a, s);
+    if (big < 512) return launch_conv<2, 2, 1, 8, 1, 1, 32, UP, DOWN, KS>(a, s);
+    return launch_conv<2, 2, 1, 8, 2, 2, 32, UP, DOWN, KS>(a, s);
 }
 
 struct WgradPlan { int cfg, kt, nt, tr, splits, tiles_per_split, tiles_x, tiles_y, parts; };

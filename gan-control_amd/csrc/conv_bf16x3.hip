@@ -286,21 +286,24 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4* 
     *l = *reinterpret_cast<uint4*>(&ll);
 }
 
-template <int TR, int KS>
+template <int WK, int WN, int WP, int TR, int KS>
 struct WgCfg {
-    static constexpr int KT = 64, NTL = 64;
+    static constexpr int KT = WK * 32, NTL = WN * 32;
     static constexpr int PH = TR + KS - 1;
     static constexpr int XU = KS == 3 ? 5 : 4, YU = 4;            // 8-pixel units per patch row / dY row
     static constexpr int CSX = (PH * XU) | 1, CSY = (TR * YU) | 1;   // odd unit strides between channels: conflict-free b128 reads
     static constexpr int NXU = KT * PH * XU, NYU = NTL * TR * YU;
     static constexpr int NPX = (NXU + 255) / 256, NPY = (NYU + 255) / 256;
-    static constexpr int SMEM_UNITS = 2 * (KT * CSX + NTL * CSY);
+    static constexpr int RED_UNITS = (WP - 1) * WK * WN * 16 * 64 / 4;      // cross-wave reduction scratch (floats / 4)
+    static constexpr int SMEM_UNITS = cmax(2 * (KT * CSX + NTL * CSY), RED_UNITS);
     static constexpr int NT = KS * KS;
 };
 
-template <int TR, int KS>
+template <int WK, int WN, int WP, int TR, int KS>
 __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
-    using C = WgCfg<TR, KS>;
+    using C = WgCfg<WK, WN, WP, TR, KS>;
+    static_assert(WK * WN * WP == 4, "4 waves per workgroup");
+    static_assert((2 * TR) % WP == 0, "pixel steps split evenly over the pixel waves");
     constexpr int KT = C::KT, NTL = C::NTL, PH = C::PH, XU = C::XU, YU = C::YU, NT = C::NT;
     __shared__ uint4 smem[C::SMEM_UNITS];
     uint4* xh = smem;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wk = wave >> 1, wn = wave & 1;
+    const int wp = wave % WP, wn = (wave / WP) % WN, wk = wave / (WP * WN);
     const int k0 = blockIdx.x * KT, n0 = blockIdx.y * NTL, split = blockIdx.z;
 
     f32x16 acc[NT];
@@ -418,9 +421,10 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
             const bool more = tile + 1 < t_end;
             if (more) prefetch(tile + 1);
 #pragma unroll
-            for (int r = 0; r < TR; ++r) {
-#pragma unroll
-                for (int st = 0; st < 2; ++st) {
+            for (int step = 0; step < 2 * TR / WP; ++step) {
+                {
+                    const int sidx = step * WP + wp;            // this wave's pixel step: row r, half-row st
+                    const int r = sidx >> 1, st = sidx & 1;
                     const uint4 ubh = yh[yb_ + r * YU + 2 * st], ubl = yl[yb_ + r * YU + 2 * st];
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&ubh), bl = *reinterpret_cast<const bf16x8*>(&ubl);
 #pragma unroll
@@ -432,6 +436,210 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
 #pragma unroll
                         for (int tx = 0; tx < KS; ++tx) {
                             const uint4 uh = shift_px(a0h, a1h, tx), ul = shift_px(a0l, a1l, tx);
+                            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh), al = *reinterpret_cast<const bf16x8*>(&ul);
+                            f32x16 c = acc[ty * KS + tx];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+                            acc[ty * KS + tx] = c;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            if (more) {
+                commit();
+                __syncthreads();
+            }
+        }
+    }
+
+    if (WP > 1) {
+        // the WP pixel-waves of a (wk, wn) group hold partial sums of the same (k, n) block: add them through LDS
+        float* red = reinterpret_cast<float*>(smem) + (wk * WN + wn) * (WP - 1) * 16 * 64;
+        for (int t = 0; t < NT; ++t) {
+            __syncthreads();
+            if (wp > 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[((wp - 1) * 16 + r) * 64 + lane] = acc[t][r];
+            }
+            __syncthreads();
+            if (wp == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[t][r];
+                    for (int o = 0; o < WP - 1; ++o) v += red[(o * 16 + r) * 64 + lane];
+                    acc[t][r] = v;
+                }
+            }
+        }
+        if (wp != 0) return;
+    }
+
+    float* out = p.ws + (size_t)split * NT * p.K * p.N;
+    const int n = n0 + wn * 32 + l31;
+    if (n < p.N) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = k0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (k < p.K) out[((size_t)t * p.K + k) * p.N + n] = acc[t][r];
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Stride-2 variant (down = 2, pad = 0): dW[tap][k][n] = sum_px X[k][2 px + tap] * dY[n][px] -- the weight gradient
+// of D's 3x3 / 1x1 stride-2 convolutions and (operands swapped) of G's transposed convolutions.  Each input row is
+// staged DE-INTERLEAVED: units of 8 even columns and units of 8 odd columns, so tap tx = 0 reads an even unit,
+// tx = 1 an odd unit and tx = 2 the even units funnel-shifted by one pixel -- every ds_read_b128 stays aligned.
+template <int TR, int KS>
+struct WgS2Cfg {
+    static constexpr int KT = 64, NTL = 64;
+    static constexpr int PH = (TR - 1) * 2 + KS;
+    static constexpr int XE = KS == 3 ? 5 : 4, XO = KS == 3 ? 4 : 0, RU = XE + XO, YU = 4;
+    static constexpr int NI = XE;                                    // 16-column staging items per row
+    static constexpr int CSX = (PH * RU) | 1, CSY = (TR * YU) | 1;
+    static constexpr int NXI = KT * PH * NI, NYU = NTL * TR * YU;
+    static constexpr int NPX = (NXI + 255) / 256, NPY = (NYU + 255) / 256;
+    static constexpr int SMEM_UNITS = 2 * (KT * CSX + NTL * CSY);
+    static constexpr int NT = KS * KS;
+};
+
+template <int TR, int KS>
+__global__ __launch_bounds__(256, 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
+    using C = WgS2Cfg<TR, KS>;
+    constexpr int KT = C::KT, NTL = C::NTL, PH = C::PH, XE = C::XE, RU = C::RU, YU = C::YU, NI = C::NI, NT = C::NT;
+    __shared__ uint4 smem[C::SMEM_UNITS];
+    uint4* xh = smem;
+    uint4* xl = xh + KT * C::CSX;
+    uint4* yh = xl + KT * C::CSX;
+    uint4* yl = yh + NTL * C::CSY;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wk = wave >> 1, wn = wave & 1;
+    const int k0 = blockIdx.x * KT, n0 = blockIdx.y * NTL, split = blockIdx.z;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    const int tiles_per_sample = p.tiles_x * p.tiles_y;
+    const int total_tiles = tiles_per_sample * p.B;
+    const int t_begin = split * p.tiles_per_split;
+    const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
+    const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
+    const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
+
+    float4 xreg[C::NPX][4], yreg[C::NPY][2];
+    float xsc[C::NPX], ysc[C::NPY];
+    int xcol[C::NPX], ycol[C::NPY];
+    auto prefetch = [&](int tile) {
+        const int t_ = opaque(tid);
+        const int b = tile / tiles_per_sample;
+        const int rem = tile - b * tiles_per_sample;
+        const int oy0 = (rem / p.tiles_x) * TR, ox0 = (rem % p.tiles_x) * 32;
+        const int iy0 = oy0 * 2, ix0 = ox0 * 2;                      // pad = 0 (checked on the host)
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
+        const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
+#pragma unroll
+        for (int j = 0; j < C::NPX; ++j) {
+            const int u = t_ + 256 * j;
+            const int it = u % NI, row = u / NI;
+            const int r = row % PH, kk = row / PH;
+            const int k = k0 + kk, iy = iy0 + r, ixb = ix0 + 16 * it;
+            const bool ok = u < C::NXI && k < p.K && iy < p.in_h;
+            const unsigned off = ok ? (unsigned)(k * xchan + iy * p.in_w + ixb) * 4u : OOB;
+#pragma unroll
+            for (int v = 0; v < 4; ++v) xreg[j][v] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 16 * v));
+            xsc[j] = p.si ? p.si[(size_t)b * p.K + min(k, p.K - 1)] : 1.f;
+            xcol[j] = ok ? ixb : -100000;
+        }
+#pragma unroll
+        for (int j = 0; j < C::NPY; ++j) {
+            const int u = t_ + 256 * j;
+            const int yu = u % YU, row = u / YU;
+            const int r = row % TR, nn = row / TR;
+            const int n = n0 + nn, oy = oy0 + r, oxb = ox0 + 8 * yu;
+            const bool ok = u < C::NYU && n < p.N && oy < p.out_h;
+            const unsigned off = ok ? (unsigned)(n * ychan + oy * p.out_w + oxb) * 4u : OOB;
+            yreg[j][0] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 0));
+            yreg[j][1] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 16));
+            ysc[j] = p.so ? p.so[(size_t)b * p.N + min(n, p.N - 1)] : 1.f;
+            ycol[j] = ok ? oxb : -100000;
+        }
+    };
+    auto commit = [&]() {
+        const int t_ = opaque(tid);
+#pragma unroll
+        for (int j = 0; j < C::NPX; ++j) {
+            const int u = t_ + 256 * j;
+            const int it = u % NI, row = u / NI;
+            const float4* q4 = xreg[j];
+            const float v[16] = {q4[0].x, q4[0].y, q4[0].z, q4[0].w, q4[1].x, q4[1].y, q4[1].z, q4[1].w,
+                                 q4[2].x, q4[2].y, q4[2].z, q4[2].w, q4[3].x, q4[3].y, q4[3].z, q4[3].w};
+            float ev[8], od[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                ev[q] = (xcol[j] + 2 * q >= 0 && xcol[j] + 2 * q < p.in_w) ? v[2 * q] : 0.f;
+                od[q] = (xcol[j] + 2 * q + 1 >= 0 && xcol[j] + 2 * q + 1 < p.in_w) ? v[2 * q + 1] : 0.f;
+            }
+            uint4 eh, el, oh, ol;
+            split8(ev, xsc[j], &eh, &el);
+            if (u < C::NXI) {
+                const int o = (row / PH) * C::CSX + (row % PH) * RU;
+                xh[o + it] = eh; xl[o + it] = el;
+                if (KS == 3 && it < C::XO) {
+                    split8(od, xsc[j], &oh, &ol);
+                    xh[o + XE + it] = oh; xl[o + XE + it] = ol;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < C::NPY; ++j) {
+            const int u = t_ + 256 * j;
+            const int row = u / YU;
+            float v[8] = {yreg[j][0].x, yreg[j][0].y, yreg[j][0].z, yreg[j][0].w, yreg[j][1].x, yreg[j][1].y, yreg[j][1].z, yreg[j][1].w};
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (ycol[j] + q >= 0 && ycol[j] + q < p.out_w) ? v[q] : 0.f;
+            uint4 h, l;
+            split8(v, ysc[j], &h, &l);
+            if (u < C::NYU) {
+                const int o = (row / TR) * C::CSY + (row % TR) * YU + u % YU;
+                yh[o] = h; yl[o] = l;
+            }
+        }
+    };
+
+    if (t_begin < t_end) {
+        prefetch(t_begin);
+        commit();
+        __syncthreads();
+        const int xa = (wk * 32 + l31) * C::CSX + hi, yb_ = (wn * 32 + l31) * C::CSY + hi;
+        for (int tile = t_begin; tile < t_end; ++tile) {
+            const bool more = tile + 1 < t_end;
+            if (more) prefetch(tile + 1);
+#pragma unroll
+            for (int r = 0; r < TR; ++r) {
+#pragma unroll
+                for (int st = 0; st < 2; ++st) {
+                    const uint4 ubh = yh[yb_ + r * YU + 2 * st], ubl = yl[yb_ + r * YU + 2 * st];
+                    const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&ubh), bl = *reinterpret_cast<const bf16x8*>(&ubl);
+#pragma unroll
+                    for (int ty = 0; ty < KS; ++ty) {
+                        const int o = xa + (2 * r + ty) * RU + 2 * st;
+                        const uint4 e0h = xh[o], e0l = xl[o];
+                        uint4 e1h = e0h, e1l = e0l, o0h = e0h, o0l = e0l;
+                        if (KS == 3) { e1h = xh[o + 1]; e1l = xl[o + 1]; o0h = xh[o + XE]; o0l = xl[o + XE]; }
+#pragma unroll
+                        for (int tx = 0; tx < KS; ++tx) {
+                            const uint4 uh = tx == 0 ? e0h : (tx == 1 ? o0h : shift_px(e0h, e1h, 1));
+                            const uint4 ul = tx == 0 ? e0l : (tx == 1 ? o0l : shift_px(e0l, e1l, 1));
                             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh), al = *reinterpret_cast<const bf16x8*>(&ul);
                             f32x16 c = acc[ty * KS + tx];
                             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
@@ -464,15 +672,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
     }
 }
 
-struct WgPlan { int splits, tiles_per_split, tiles_x, tiles_y; };
-constexpr int WG_TR = 2;
+struct WgPlan { int small, ct, tr, splits, tiles_per_split, tiles_x, tiles_y; };
 
+// 64k x 64n tiles (2 rows per pixel tile) when both channel counts reach 64, else 32k x 32n tiles with the four
+// waves splitting the pixel steps of a 4-row tile
 WgPlan plan_wg(const gc_conv_desc* d) {
     WgPlan pl;
+    pl.small = d->down == 1 && !(d->in_ch >= 64 && d->out_ch >= 64);
+    pl.ct = pl.small ? 32 : 64;
+    pl.tr = pl.small ? 4 : 2;
     pl.tiles_x = gc::ceil_div(d->out_w, 32);
-    pl.tiles_y = gc::ceil_div(d->out_h, WG_TR);
+    pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
-    const int ctiles = gc::ceil_div(d->in_ch, 64) * gc::ceil_div(d->out_ch, 64);
+    const int ctiles = gc::ceil_div(d->in_ch, pl.ct) * gc::ceil_div(d->out_ch, pl.ct);
     int want = gc::ceil_div(512, ctiles);      // one workgroup per CU is resident (512 registers per lane): two rounds
     if (want > total) want = total;
     if (want < 1) want = 1;
@@ -482,7 +694,9 @@ WgPlan plan_wg(const gc_conv_desc* d) {
 }
 
 bool wg_eligible(const gc_conv_desc* d) {
-    return d->up == 1 && d->down == 1 && d->in_ch >= 64 && d->out_ch >= 64 && d->out_w > 16 && d->pad_x >= 0 && d->pad_x <= 1;
+    if (d->up != 1 || d->out_w <= 16) return false;
+    if (d->down == 1) return d->in_ch >= 32 && d->out_ch >= 32 && d->pad_x >= 0 && d->pad_x <= 1;
+    return d->in_ch >= 64 && d->out_ch >= 64 && d->pad_x == 0 && d->pad_y == 0;      // stride-2 kernel: 64 x 64 tiles, no padding
 }
 
 template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
@@ -578,9 +792,17 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
     hipStream_t s = (hipStream_t)stream;
     WgArgs a{x, dy, in_scale, out_scale, pl.splits == 1 ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch,
              d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
-    dim3 grid(gc::ceil_div(d->in_ch, 64), gc::ceil_div(d->out_ch, 64), pl.splits);
-    if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<WG_TR, 3>), grid, dim3(256), 0, s, a);
-    else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<WG_TR, 1>), grid, dim3(256), 0, s, a);
+    dim3 grid(gc::ceil_div(d->in_ch, pl.ct), gc::ceil_div(d->out_ch, pl.ct), pl.splits);
+    if (d->down == 2) {
+        if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 3>), grid, dim3(256), 0, s, a);
+        else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 1>), grid, dim3(256), 0, s, a);
+    } else if (pl.small) {
+        if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 4, 3>), grid, dim3(256), 0, s, a);
+        else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 4, 1>), grid, dim3(256), 0, s, a);
+    } else {
+        if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 3>), grid, dim3(256), 0, s, a);
+        else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 1>), grid, dim3(256), 0, s, a);
+    }
     rc = gc::check_launch("gc_conv2d_wgrad_bf16x3_f32");
     if (rc || pl.splits == 1) return rc;
     return launch_wgrad_reduce(static_cast<const float*>(workspace), dw, count, pl.splits, s);

@@ -16,7 +16,8 @@ import torch
 def conv_variant(geom, n_out, batch=1):
     """Name of the conv_mfma_kernel tile configuration gc_conv2d_f32 selects (csrc/conv.hip, dispatch_conv).
 
-    Template arguments: <WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW>; the (up, down, taps) triple follows.
+    Template arguments: <WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW>; the (up, down, taps) triple follows.  In bf16x3 mode
+    the same shapes run on conv_bf16x3_kernel (planes wider than 16 px and >= 16 input channels).
     """
     qw, qh = -(-geom.out_w // geom.up), -(-geom.out_h // geom.up)
     geo = '|up%d,down%d,k%d' % (geom.up, geom.down, geom.kh)

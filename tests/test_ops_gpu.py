@@ -198,6 +198,7 @@ BF16_CASES = CONV_CASES + [
     (2, 64, 64, 40, 70, 3, 1, 1, 1), (1, 130, 140, 33, 65, 3, 1, 1, 1), (1, 32, 32, 70, 40, 3, 1, 1, 1), (2, 48, 24, 36, 36, 1, 1, 1, 0),
     (1, 64, 130, 65, 129, 3, 1, 2, 0), (2, 40, 20, 71, 67, 3, 1, 2, 0), (2, 16, 24, 63, 63, 1, 1, 2, 0),
     (1, 64, 40, 32, 48, 3, 2, 1, 2), (2, 24, 70, 20, 33, 3, 2, 1, 2), (2, 16, 5, 40, 40, 1, 2, 1, 0), (1, 513, 40, 40, 40, 3, 1, 1, 1),
+    (1, 64, 64, 63, 63, 1, 1, 2, 0), (2, 64, 96, 41, 77, 3, 1, 2, 0), (1, 128, 64, 129, 65, 3, 1, 2, 0), (1, 32, 32, 64, 96, 3, 1, 1, 1),
 ]
 
 
@@ -256,3 +257,25 @@ def test_bench_ddp_path_single_rank():
     rec = json.loads(line)
     assert rec['n_gpus'] == 1 and rec['value'] > 0 and rec['unit'] == 'images/sec'
     assert all(v == v for v in rec['losses'].values()), 'NaN loss'
+
+
+def test_transposed_conv_grads_bf16x3(bf16x3_mode):
+    """conv_transpose2d at >= 64 channels: forward on the up=2 kernel, input gradient on the down=2 kernel, weight
+    gradient on the stride-2 split-bf16 wgrad with swapped operands."""
+    import torch.nn.functional as F
+    from torch import autograd
+    from gan_control_amd.models.op import conv2d_gradfix
+    gen = torch.Generator().manual_seed(23)
+    for (b, ic, oc, h, w) in [(2, 64, 64, 33, 40), (1, 128, 64, 20, 37)]:
+        x = torch.randn(b, ic, h, w, generator=gen)
+        wt = torch.randn(ic, oc, 3, 3, generator=gen)
+        xr, wr = x.double().requires_grad_(True), wt.double().requires_grad_(True)
+        xp, wp = x.to(DEV).requires_grad_(True), wt.to(DEV).requires_grad_(True)
+        ref = F.conv_transpose2d(xr, wr, stride=2)
+        out = conv2d_gradfix.conv_transpose2d(xp, wp, stride=2)
+        assert rel_err(out, ref) < 5e-5
+        go = torch.randn_like(ref)
+        gr = autograd.grad(ref, [xr, wr], go)
+        gp = autograd.grad(out, [xp, wp], go.float().to(DEV))
+        for a, c in zip(gp, gr):
+            assert rel_err(a, c) < 5e-5
