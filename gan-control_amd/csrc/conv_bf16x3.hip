@@ -720,7 +720,11 @@ int dispatch(const Bf16Args& a, hipStream_t s) {
         return launch<1, 4, 2, 1, UP, DOWN, KS>(a, s);
     } else {
         if (a.c.N <= 32) return launch<1, 4, 1, 4, UP, DOWN, KS>(a, s);     // 32oc x (16 rows x 32 px)
-        return launch<1, 4, 2, 2, UP, DOWN, KS>(a, s);                      // 64oc x (8 rows x 32 px)
+        // 64oc x (8 rows x 32 px) unless that leaves most CUs idle (32x32 / 64x64 planes at batch 4): 4-row tiles
+        const int qw = gc::ceil_div(a.c.out_w, UP), qh = gc::ceil_div(a.c.out_h, UP);
+        const long long big = (long long)gc::ceil_div(qw, 32) * gc::ceil_div(qh, 8) * UP * UP * a.c.B * gc::ceil_div(a.c.N, 64);
+        if (big < 512) return launch<1, 4, 2, 1, UP, DOWN, KS>(a, s);
+        return launch<1, 4, 2, 2, UP, DOWN, KS>(a, s);
     }
 }
 

@@ -177,7 +177,7 @@ class HipBackend:
         _lib.check(rc, 'gc_conv2d_f32')
         if t0 is not None:
             from ...utils.profiling import conv_variant, conv_flops
-            self.timer.stop(conv_variant(geom, n_out, x.shape[0]), t0, conv_flops(x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom))
+            self.timer.stop(conv_variant(geom, n_out, x.shape[0], x.shape[1], self.conv_mode), t0, conv_flops(x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom))
         return y
 
     def conv2d_wgrad(self, x, dy, in_scale, out_scale, geom):

@@ -13,7 +13,7 @@ import collections
 import torch
 
 
-def conv_variant(geom, n_out, batch=1):
+def conv_variant(geom, n_out, batch=1, k_in=64, mode='f32'):
     """Name of the conv_mfma_kernel tile configuration gc_conv2d_f32 selects (csrc/conv.hip, dispatch_conv).
 
     Template arguments: <WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW>; the (up, down, taps) triple follows.  In bf16x3 mode
@@ -21,9 +21,17 @@ def conv_variant(geom, n_out, batch=1):
     """
     qw, qh = -(-geom.out_w // geom.up), -(-geom.out_h // geom.up)
     geo = '|up%d,down%d,k%d' % (geom.up, geom.down, geom.kh)
+    if mode == 'bf16x3' and k_in >= 16 and qw > 16:
+        # conv_bf16x3_kernel<WG_OC, WG_PX, WOC, WPX> (csrc/conv_bf16x3.hip, dispatch)
+        if geom.down == 2:
+            return ('conv_bf16x3_kernel<1,4,1,1>' if n_out <= 32 else 'conv_bf16x3_kernel<1,4,2,1>') + geo
+        if n_out <= 32:
+            return 'conv_bf16x3_kernel<1,4,1,4>' + geo
+        big = -(-qw // 32) * -(-qh // 8) * geom.up * geom.up * batch * -(-n_out // 64)
+        return ('conv_bf16x3_kernel<1,4,2,1>' if big < 512 else 'conv_bf16x3_kernel<1,4,2,2>') + geo
     if qw <= 16:
         tpw = 4 if qw <= 4 else (8 if qw <= 8 else 16)
-        return 'conv_mfma_kernel<1,1,4,1,1,%d>' % tpw + geo
+        return 'conv_mfma_kernel<1,1,4,32,1,1,%d>' % tpw + geo
     if geom.down == 2:
         if n_out <= 64:
             return 'conv_mfma_kernel<2,2,1,1,1,32>' + geo
