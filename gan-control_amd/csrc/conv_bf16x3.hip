@@ -495,6 +495,19 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
 // of D's 3x3 / 1x1 stride-2 convolutions and (operands swapped) of G's transposed convolutions.  Each input row is
 // staged DE-INTERLEAVED: units of 8 even columns and units of 8 odd columns, so tap tx = 0 reads an even unit,
 // tx = 1 an odd unit and tx = 2 the even units funnel-shifted by one pixel -- every ds_read_b128 stays aligned.
+__device__ __forceinline__ void split8v(const float (&v)[8], const float (&sc)[8], uint4* h, uint4* l) {
+    bf16x8 hh, ll;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const float f = v[q] * sc[q];
+        const __bf16 t = (__bf16)f;
+        hh[q] = t;
+        ll[q] = (__bf16)(f - (float)t);
+    }
+    *h = *reinterpret_cast<uint4*>(&hh);
+    *l = *reinterpret_cast<uint4*>(&ll);
+}
+
 template <int TR, int KS>
 struct WgS2Cfg {
     static constexpr int KT = 64, NTL = 64;
@@ -699,6 +712,212 @@ bool wg_eligible(const gc_conv_desc* d) {
     return d->in_ch >= 64 && d->out_ch >= 64 && d->pad_x == 0 && d->pad_y == 0;      // stride-2 kernel: 64 x 64 tiles, no padding
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Transposed 3x3 stride-2 convolution (up = 2, pad' = 2: ModulatedConv2d's up-sampling branch gan_model.py:295-306
+// and the input gradient of every 3x3 stride-2 conv) with the four output phases FUSED in one workgroup.
+// Output pixel (2q + py, 2q' + px) of phase (py, px) reads input pixels q + {-1, 0}: all phases share the same
+// 2x2 input neighbourhood, so a tile of q positions is staged once and each lane keeps one accumulator per phase.
+// Taps per axis: phase 0 -> (t = 0, d = -1), (t = 2, d = 0); phase 1 -> (t = 1, d = 0): 9 (phase, tap) pairs = the
+// MFMA count of a plain 3x3 tile, every workgroup does the same work, and B fragments are shared across phases.
+template <int WG_OC, int WG_PX, int WPX, int TPW>
+struct TCfg {
+    static constexpr int OCT = WG_OC * 32, RPB = 32 / TPW;
+    static constexpr int TQH = WG_PX * WPX * RPB;
+    static constexpr int PH = TQH + 1, PWD = TPW + 1, PLANE = PH * PWD;
+    static constexpr int WUNITS = 9 * KG * OCT, PUNITS = KG * PLANE;
+    static constexpr int SMEM_UNITS = 2 * (WUNITS + PUNITS);
+    static constexpr int NWU = (WUNITS + 255) / 256, NPU = (PLANE + 127) / 128;
+};
+
+template <int WG_OC, int WG_PX, int WPX, int TPW>
+__global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) {
+    using C = TCfg<WG_OC, WG_PX, WPX, TPW>;
+    static_assert(WG_OC * WG_PX == 4, "4 waves per workgroup");
+    constexpr int OCT = C::OCT, RPB = C::RPB, TQH = C::TQH, PWD = C::PWD, PLANE = C::PLANE;
+    const ConvArgs& p = a.c;
+    __shared__ uint4 smem[C::SMEM_UNITS];
+    uint4* wl_h = smem;                         // [tap][kg][OCT]
+    uint4* wl_l = wl_h + C::WUNITS;
+    uint4* p_h = wl_l + C::WUNITS;              // [kg][PH][PWD]
+    uint4* p_l = p_h + C::PUNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int wave_px = wave % WG_PX, wave_oc = wave / WG_PX;
+
+    int bid = blockIdx.x;
+    const int tile_x = bid % p.tiles_x; bid /= p.tiles_x;
+    const int tile_y = bid % p.tiles_y;
+    const int b = bid / p.tiles_y;
+    const int n0 = blockIdx.y * OCT;
+    const int qy0 = tile_y * TQH, qx0 = tile_x * TPW;
+
+    f32x16 acc[4][WPX];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph)
+#pragma unroll
+        for (int j = 0; j < WPX; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][j][r] = 0.f;
+
+    int boff[WPX];
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) boff[j] = hi * PLANE + ((wave_px * WPX + j) * RPB + l31 / TPW) * PWD + l31 % TPW;
+    const int aoff = hi * OCT + wave_oc * 32 + l31;
+
+    const float* xb = p.x + (size_t)b * p.K * p.in_h * p.in_w;
+    const float* sib = p.si ? p.si + (size_t)b * p.K : nullptr;
+    const int chan = p.in_h * p.in_w;
+    const int iy0 = qy0 - 1, ix0 = qx0 - 1;
+
+    uint4 wreg_h[C::NWU], wreg_l[C::NWU];
+    float preg[C::NPU][8];
+    float sreg[8];
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)p.K * chan * 4u);
+    const unsigned wbytes = 9u * a.kgroups * p.N * 16u;
+    const __amdgpu_buffer_rsrc_t rwh = make_rsrc(a.wh, wbytes), rwl = make_rsrc(a.wl, wbytes);
+    auto prefetch = [&](int k0) {
+        const int t_ = opaque(tid);
+#pragma unroll
+        for (int j = 0; j < C::NWU; ++j) {
+            const int u = t_ + 256 * j;
+            const int oc = u % OCT, rest = u / OCT;
+            const int kgl = rest % KG, tap = rest / KG;
+            const int kg = k0 / 8 + kgl, n = n0 + oc;
+            const bool ok = u < C::WUNITS && kg < a.kgroups && n < p.N;
+            const unsigned gb = ok ? (unsigned)((tap * a.kgroups + kg) * p.N + n) * 16u : OOB;
+            wreg_h[j] = buf_load_u128(rwh, gb, 0);
+            wreg_l[j] = buf_load_u128(rwl, gb, 0);
+        }
+        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), pbase = t_ & 127;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = k0 + kgl * 8 + q;
+            sreg[q] = sib ? sib[min(k, p.K - 1)] : 1.f;
+        }
+#pragma unroll
+        for (int j = 0; j < C::NPU; ++j) {
+            const int pos = pbase + 128 * j;
+            const int r = pos / PWD, c = pos % PWD;
+            const int iy = iy0 + r, ix = ix0 + c;
+            const bool ok = pos < PLANE && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+            const unsigned boff_ = ok ? (unsigned)(iy * p.in_w + ix) * 4u : OOB;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int k = min(k0 + kgl * 8 + q, p.K - 1);
+                preg[j][q] = buf_load_f32(rx, boff_, (unsigned)k * chan * 4u);
+            }
+        }
+    };
+    auto commit = [&](int k0) {
+        const int t_ = opaque(tid);
+#pragma unroll
+        for (int j = 0; j < C::NWU; ++j) {
+            const int u = t_ + 256 * j;
+            if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; wl_l[u] = wreg_l[j]; }
+        }
+        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), pbase = t_ & 127;
+#pragma unroll
+        for (int j = 0; j < C::NPU; ++j) {
+            const int pos = pbase + 128 * j;
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = (k0 + kgl * 8 + q < p.K) ? preg[j][q] : 0.f;
+            uint4 h, l;
+            split8v(v, sreg, &h, &l);
+            if (pos < PLANE) { p_h[kgl * PLANE + pos] = h; p_l[kgl * PLANE + pos] = l; }
+        }
+    };
+
+    prefetch(0);
+    commit(0);
+    __syncthreads();
+    for (int k0 = 0; k0 < p.K; k0 += KCB) {
+        const bool more = k0 + KCB < p.K;
+        if (more) prefetch(k0 + KCB);
+#pragma unroll
+        for (int dyi = 0; dyi < 2; ++dyi) {
+#pragma unroll
+            for (int dxi = 0; dxi < 2; ++dxi) {
+                bf16x8 bh[WPX], bl[WPX];
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) {
+                    const uint4 uh = p_h[boff[j] + dyi * PWD + dxi], ul = p_l[boff[j] + dyi * PWD + dxi];
+                    bh[j] = *reinterpret_cast<const bf16x8*>(&uh);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(&ul);
+                }
+                // (phase, tap) pairs reading the neighbour at offset d = dyi - 1: d = -1 -> (0, t=0); d = 0 -> (0, t=2), (1, t=1)
+#pragma unroll
+                for (int iy = 0; iy < 1 + dyi; ++iy) {
+                    const int py = (dyi == 1 && iy == 1) ? 1 : 0, ty = dyi == 0 ? 0 : (iy == 0 ? 2 : 1);
+#pragma unroll
+                    for (int ix = 0; ix < 1 + dxi; ++ix) {
+                        const int px = (dxi == 1 && ix == 1) ? 1 : 0, tx = dxi == 0 ? 0 : (ix == 0 ? 2 : 1);
+                        const int wbase = (ty * 3 + tx) * KG * OCT + aoff;
+                        const uint4 uh = wl_h[wbase], ul = wl_l[wbase];
+                        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh), al = *reinterpret_cast<const bf16x8*>(&ul);
+#pragma unroll
+                        for (int j = 0; j < WPX; ++j) {
+                            f32x16 c = acc[py * 2 + px][j];
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], c, 0, 0, 0);
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], c, 0, 0, 0);
+                            acc[py * 2 + px][j] = c;
+                        }
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (more) {
+            commit(k0 + KCB);
+            __syncthreads();
+        }
+    }
+
+    const float* sob = p.so ? p.so + (size_t)b * p.N : nullptr;
+    float* yb = p.y + (size_t)b * p.N * p.out_h * p.out_w;
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) {
+        const int qy = qy0 + (wave_px * WPX + j) * RPB + l31 / TPW, qx = qx0 + l31 % TPW;
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int oy = 2 * qy + (ph >> 1), ox = 2 * qx + (ph & 1);
+            if (oy >= p.out_h || ox >= p.out_w) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int oc = n0 + wave_oc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (oc < p.N) {
+                    float v = acc[ph][j][r];
+                    if (sob) v *= sob[oc];
+                    yb[((size_t)oc * p.out_h + oy) * p.out_w + ox] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int WG_OC, int WG_PX, int WPX, int TPW>
+int launch_t(Bf16Args a, hipStream_t s) {
+    using C = TCfg<WG_OC, WG_PX, WPX, TPW>;
+    const int qh = gc::ceil_div(a.c.out_h, 2), qw = gc::ceil_div(a.c.out_w, 2);
+    a.c.tiles_y = gc::ceil_div(qh, C::TQH);
+    a.c.tiles_x = gc::ceil_div(qw, TPW);
+    const long long gx = (long long)a.c.tiles_x * a.c.tiles_y * a.c.B;
+    if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
+    dim3 grid((unsigned)gx, gc::ceil_div(a.c.N, C::OCT));
+    hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW>), grid, dim3(256), 0, s, a);
+    return gc::check_launch("gc_conv2d_bf16x3_f32(fused transposed)");
+}
+
+// q-space is (H + 1) wide for a (2H + 1)-wide output: take the tile width that wastes fewer lanes
+int dispatch_t(const Bf16Args& a, hipStream_t s) {
+    const int qw = gc::ceil_div(a.c.out_w, 2);
+    const bool narrow = gc::ceil_div(qw, 16) * 16 < gc::ceil_div(qw, 32) * 32;
+    if (a.c.N <= 32) return narrow ? launch_t<1, 4, 2, 16>(a, s) : launch_t<1, 4, 2, 32>(a, s);
+    return narrow ? launch_t<2, 2, 2, 16>(a, s) : launch_t<2, 2, 2, 32>(a, s);
+}
+
 template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
 int launch(Bf16Args a, hipStream_t s) {
     using C = BCfg<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>;
@@ -765,6 +984,7 @@ extern "C" int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const
     Bf16Args a{{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
                 d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups};
     if (d->kh == 3) {
+        if (d->up == 2 && d->pad_y == 2 && d->pad_x == 2) return dispatch_t(a, s);
         if (d->up == 2) return dispatch<2, 1, 3>(a, s);
         return d->down == 2 ? dispatch<1, 2, 3>(a, s) : dispatch<1, 1, 3>(a, s);
     }

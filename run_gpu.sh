@@ -1,3 +1,2 @@
 cd $GRAFT_REPO_ROOT
-( time timeout 1500 python bench.py ) > gpurun_out/bench_default.log 2>&1
-tail -5 gpurun_out/bench_default.log | cut -c1-3000
+GC_T_OC32=1 timeout 600 python tools/kbench.py --only "convT" --mode bf16x3 2>&1 | grep -v amdgpu.ids
