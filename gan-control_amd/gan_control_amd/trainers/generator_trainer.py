@@ -53,8 +53,9 @@ def none_grad_names(generator, discriminator):
 
 
 class GeneratorTrainer:
-    def __init__(self, config, device='cuda', seed=0, fused_adam=None):
+    def __init__(self, config, device='cuda', seed=0, fused_adam=None, fuse_d_pair=True):
         self.config = config
+        self.fuse_d_pair = fuse_d_pair
         self.model_config = config['model_config']
         self.training_config = config['training_config']
         self.device = torch.device(device)
@@ -178,8 +179,7 @@ class GeneratorTrainer:
         for k, (real, z) in enumerate(zip(mini_real_inputs, mini_noise_inputs)):
             self.d_reducer.begin(sync=(k == n - 1))
             fake_img, _ = self.generator(z, noise=noise)
-            fake_pred, _ = self.discriminator(fake_img)
-            real_pred, _ = self.discriminator(real)
+            fake_pred, real_pred = self.discriminate_pair(fake_img, real)
             d_loss = self.d_logistic_loss(real_pred, fake_pred)
             # reference divides by the number of IMAGES in the (global) mini-batch (:658)
             d_loss = d_loss / (len(real) * self.world)
@@ -189,6 +189,21 @@ class GeneratorTrainer:
         self.d_reducer.finish()
         self.d_optim.step()
         self.last_real_pred = real_pred.detach()
+
+    def discriminate_pair(self, fake_img, real_img):
+        """D(fake), D(real) as the reference computes them (:655-656), in ONE pass over the interleaved batch
+        [f0, r0, f1, r1, ...] when that provably changes nothing: the minibatch-stddev groups of D are strided
+        (members i, i + B/4, ...; gan_model.py:1005-1011), so with the per-call batch a multiple of 4 the interleaved
+        batch of 2B puts exactly the fake samples of one original group, or the real ones, in each group.  Every
+        other layer treats samples independently.  Halves the launches and doubles the work per launch."""
+        b = fake_img.shape[0]
+        if self.fuse_d_pair and b == real_img.shape[0] and b % 4 == 0:
+            both = torch.stack([fake_img, real_img], dim=1).reshape(2 * b, *fake_img.shape[1:])
+            pred, _ = self.discriminator(both)
+            return pred[0::2], pred[1::2]
+        fake_pred, _ = self.discriminator(fake_img)
+        real_pred, _ = self.discriminator(real_img)
+        return fake_pred, real_pred
 
     def discriminator_regularize_step(self, mini_real_inputs):
         tc = self.training_config
