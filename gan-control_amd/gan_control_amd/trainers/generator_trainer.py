@@ -25,6 +25,7 @@ from ..models.gan_model import Generator, Discriminator
 from ..utils.fc_config import fc_config_from_sub_groups
 from . import ddp
 from .utils import accumulate, requires_grad, mixing_noise, make_mini_batch_from_noise, set_grad_none
+from .non_leaking import augment, AdaptiveAugmentState
 
 
 def default_config(size=512, batch=16):
@@ -78,6 +79,7 @@ class GeneratorTrainer:
         self.init_models_and_optim(fused_adam)
         self.dry_run()
         self.mean_path_length = 0
+        self.ada = AdaptiveAugmentState(tc['augment'], self.device)        # generator_trainer.py:333-339
         self.accum = 0.5 ** (tc['batch'] / tc['g_moving_average'])
         self.stats = {}
 
@@ -179,6 +181,9 @@ class GeneratorTrainer:
         for k, (real, z) in enumerate(zip(mini_real_inputs, mini_noise_inputs)):
             self.d_reducer.begin(sync=(k == n - 1))
             fake_img, _ = self.generator(z, noise=noise)
+            if self.training_config['augment']['enabled']:                       # generator_trainer.py:651-653
+                real, _ = augment(real, self.ada.p)
+                fake_img, _ = augment(fake_img, self.ada.p)
             fake_pred, real_pred = self.discriminate_pair(fake_img, real)
             d_loss = self.d_logistic_loss(real_pred, fake_pred)
             # reference divides by the number of IMAGES in the (global) mini-batch (:658)
@@ -189,6 +194,11 @@ class GeneratorTrainer:
         self.d_reducer.finish()
         self.d_optim.step()
         self.last_real_pred = real_pred.detach()
+        if self.training_config['augment']['enabled']:
+            # ADA statistic on the last mini-batch's real predictions (generator_trainer.py:669-688), summed over ranks
+            reduce_sum = (lambda t: ddp.all_reduce_mean_(t).mul_(ddp.world_size())) if ddp.is_dist() else None
+            self.stats['ada_aug_p'] = self.ada.update(self.last_real_pred, reduce_sum)
+            self.stats['r_t_stat'] = self.ada.r_t
 
     def discriminate_pair(self, fake_img, real_img):
         """D(fake), D(real) as the reference computes them (:655-656), in ONE pass over the interleaved batch
@@ -241,7 +251,11 @@ class GeneratorTrainer:
         for k, z in enumerate(mini_noise_inputs):
             self.g_reducer.begin(sync=(k == n - 1))
             fake_img, _ = self.generator(z, noise=noise)
-            fake_pred, _ = self.discriminator(fake_img)
+            if self.training_config['augment']['enabled']:                       # generator_trainer.py:421-424
+                fake_for_d, _ = augment(fake_img, self.ada.p)
+            else:
+                fake_for_d = fake_img
+            fake_pred, _ = self.discriminator(fake_for_d)
             g_loss = self.g_nonsaturating_loss(fake_pred) / n
             self.stats['g_adv_loss'] = self.stats['g_adv_loss'] + g_loss.detach()
             g_loss.backward()

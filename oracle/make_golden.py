@@ -460,6 +460,35 @@ def golden_step():
     print('step ok; none_g =', none_g, '; none_d =', none_d, '; zero-grad-under-R1 D params:', len(zero_d))
 
 
+def golden_augment():
+    """ADA transforms: sampled matrices under a fixed torch seed (pins the RNG call order) and the image-space
+    result + input gradient of the reference's augment() for those matrices (non_leaking.py:394-398)."""
+    from oracle import augment as oaug
+    out = {}
+    for tag, (b, h, w, p_aug, seed) in {'a': (3, 48, 40, 0.8, 5), 'b': (2, 64, 64, 1.0, 6)}.items():
+        # the reference loops forever when a GIVEN G needs more reflect padding than the image has
+        # (non_leaking.py:288-313): advance the seed until the padding fits
+        while True:
+            torch.manual_seed(seed)
+            G = REF_NL.sample_affine(p_aug, b, h, w)
+            C = REF_NL.sample_color(p_aug, b)
+            pads = REF_NL.get_padding(torch.inverse(G), h, w)
+            if max(pads[0], pads[1]) + 6 < w and max(pads[2], pads[3]) + 6 < h:
+                break
+            seed += 1
+        gen = torch.Generator().manual_seed(seed + 100)
+        img = torch.randn(b, 3, h, w, generator=gen)
+        x = img.clone().requires_grad_(True)
+        ref, _ = REF_NL.augment(x, p_aug, (G, C))
+        go = torch.randn(ref.shape, generator=gen)
+        gi, = autograd.grad(ref, x, go)
+        close(oaug.augment(img, G, C, REF_NL.SYM6), ref, 1e-5, f'augment/{tag}')
+        out.update({f'{tag}/cfg': np.array([b, h, w, seed]), f'{tag}/p': p_aug, f'{tag}/G': G, f'{tag}/C': C, f'{tag}/img': img,
+                    f'{tag}/out': ref, f'{tag}/go': go, f'{tag}/gi': gi})
+    np.savez_compressed(os.path.join(GOLD, 'augment.npz'), **to_np(out))
+    print('augment ok')
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -469,6 +498,7 @@ def main():
     golden_misc()
     golden_networks()
     golden_step()
+    golden_augment()
     total = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print('fixtures written to %s (%.1f KiB)' % (GOLD, total / 1024))
 
