@@ -98,6 +98,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
     torch.cuda.set_device(local_rank)
+    if world > 1:
+        torch.set_num_threads(4)          # N ranks share the host: do not let each spawn one intra-op thread per core
     use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('GANCONTROL_FORCE_DDP') == '1')
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
