@@ -27,128 +27,122 @@ SYM6 = (
 )
 
 
-# ---- homogeneous 2-D / 3-D matrices, batched on dim 0 ------------------------------------------------------
-def _eye(n, dim):
+# ---- batched homogeneous matrices ------------------------------------------------------------------------------
+def _identity(n, dim):
     return torch.eye(dim).unsqueeze(0).repeat(n, 1, 1)
 
 
-def translate_mat(t_x, t_y):
-    m = _eye(t_x.shape[0], 3)
-    m[:, 0, 2], m[:, 1, 2] = t_x, t_y
+def _with(n, dim, entries):
+    """Identity [n, dim, dim] with the given {(row, col): values[n]} entries overwritten."""
+    m = _identity(n, dim)
+    for (r, c), v in entries.items():
+        m[:, r, c] = v
     return m
 
 
-def rotate_mat(theta):
-    m = _eye(theta.shape[0], 3)
+def _shift2(tx, ty):
+    return _with(tx.shape[0], 3, {(0, 2): tx, (1, 2): ty})
+
+
+def _rot2(theta):
     c, s = torch.cos(theta), torch.sin(theta)
-    m[:, 0, 0], m[:, 0, 1], m[:, 1, 0], m[:, 1, 1] = c, -s, s, c
-    return m
+    return _with(theta.shape[0], 3, {(0, 0): c, (0, 1): -s, (1, 0): s, (1, 1): c})
 
 
-def scale_mat(s_x, s_y):
-    m = _eye(s_x.shape[0], 3)
-    m[:, 0, 0], m[:, 1, 1] = s_x, s_y
-    return m
+def _scale2(sx, sy):
+    return _with(sx.shape[0], 3, {(0, 0): sx, (1, 1): sy})
 
 
-def translate3d_mat(t_x, t_y, t_z):
-    m = _eye(t_x.shape[0], 4)
-    m[:, 0, 3], m[:, 1, 3], m[:, 2, 3] = t_x, t_y, t_z
-    return m
+def _shift3(t):
+    return _with(t.shape[0], 4, {(0, 3): t, (1, 3): t, (2, 3): t})
 
 
-def scale3d_mat(s_x, s_y, s_z):
-    m = _eye(s_x.shape[0], 4)
-    m[:, 0, 0], m[:, 1, 1], m[:, 2, 2] = s_x, s_y, s_z
-    return m
+def _scale3(k):
+    return _with(k.shape[0], 4, {(0, 0): k, (1, 1): k, (2, 2): k})
 
 
-def rotate3d_mat(axis, theta):
-    """Rodrigues rotation about ``axis`` by ``theta`` (batched)."""
-    ux, uy, uz = (float(a) for a in axis)
-    u = torch.tensor((ux, uy, uz), dtype=torch.float32)
+_GREY = (1 / math.sqrt(3),) * 3          # luma axis of the colour transforms
+
+
+def _rot3_about_grey(theta):
+    """Rodrigues rotation about the grey axis (hue rotation)."""
+    u = torch.tensor(_GREY, dtype=torch.float32)
+    ux, uy, uz = _GREY
     cross = torch.tensor([[0.0, -uz, uy], [uz, 0.0, -ux], [-uy, ux, 0.0]], dtype=torch.float32)
     c, s = torch.cos(theta).view(-1, 1, 1), torch.sin(theta).view(-1, 1, 1)
-    rot = c * torch.eye(3) + s * cross + (1 - c) * torch.outer(u, u)
-    m = _eye(theta.shape[0], 4)
-    m[:, :3, :3] = rot
+    m = _identity(theta.shape[0], 4)
+    m[:, :3, :3] = c * torch.eye(3) + s * cross + (1 - c) * torch.outer(u, u)
     return m
 
 
-def luma_flip_mat(axis, i):
-    v = torch.tensor(tuple(axis) + (0,), dtype=torch.float32)
-    return _eye(i.shape[0], 4) - 2 * torch.outer(v, v) * i.view(-1, 1, 1)
+def _grey_projector():
+    v = torch.tensor(_GREY + (0,), dtype=torch.float32)
+    return torch.outer(v, v)
 
 
-def saturation_mat(axis, i):
-    v = torch.tensor(tuple(axis) + (0,), dtype=torch.float32)
-    proj = torch.outer(v, v)
-    return proj + (_eye(i.shape[0], 4) - proj) * i.view(-1, 1, 1)
+def _luma_flip(i):
+    return _identity(i.shape[0], 4) - 2 * _grey_projector() * i.view(-1, 1, 1)
 
 
-# ---- samplers (one torch RNG call each, in the reference's order) ------------------------------------------------
-def lognormal_sample(size, mean=0, std=1):
-    return torch.empty(size).log_normal_(mean=mean, std=std)
+def _saturation(k):
+    proj = _grey_projector()
+    return proj + (_identity(k.shape[0], 4) - proj) * k.view(-1, 1, 1)
 
 
-def category_sample(size, categories):
-    return torch.tensor(categories)[torch.randint(high=len(categories), size=(size,))]
+# ---- samplers: exactly one torch RNG call each, so the draw order below reproduces the reference's stream -----
+def _lognormal(n, std):
+    return torch.empty(n).log_normal_(mean=0, std=std)
 
 
-def uniform_sample(size, low, high):
-    return torch.empty(size).uniform_(low, high)
+def _choice(n, values):
+    return torch.tensor(values)[torch.randint(high=len(values), size=(n,))]
 
 
-def normal_sample(size, mean=0, std=1):
-    return torch.empty(size).normal_(mean, std)
+def _uniform(n, lo, hi):
+    return torch.empty(n).uniform_(lo, hi)
 
 
-def bernoulli_sample(size, p):
-    return torch.empty(size).bernoulli_(p)
+def _normal(n, std):
+    return torch.empty(n).normal_(0, std)
 
 
-def random_mat_apply(p, transform, prev, eye):
-    """With probability p per sample, left-multiply ``prev`` by ``transform``."""
-    keep = bernoulli_sample(transform.shape[0], p).view(-1, 1, 1)
-    return (keep * transform + (1 - keep) * eye) @ prev
+def _maybe(p, transform, prev):
+    """Per sample, with probability p: prev <- transform @ prev (one bernoulli draw of size n)."""
+    n = transform.shape[0]
+    on = torch.empty(n).bernoulli_(p).view(n, 1, 1)
+    return (on * transform + (1 - on) * _identity(n, transform.shape[1])) @ prev
 
 
 def sample_affine(p, size, height, width):
-    """Geometric pipeline of the ADA paper (x-flip, 90-degree rotations, integer translation, isotropic scale,
-    rotation split around an anisotropic scale, fractional translation); reference :151-207."""
-    eye = _eye(size, 3)
-    G = eye
-    flip = category_sample(size, (0, 1))
-    G = random_mat_apply(p, scale_mat(1 - 2.0 * flip, torch.ones(size)), G, eye)
-    quarter = category_sample(size, (0, 3))
-    G = random_mat_apply(p, rotate_mat(-math.pi / 2 * quarter), G, eye)
-    shift = uniform_sample(size, -0.125, 0.125)
-    G = random_mat_apply(p, translate_mat(torch.round(shift * width) / width, torch.round(shift * height) / height), G, eye)
-    iso = lognormal_sample(size, std=0.2 * math.log(2))
-    G = random_mat_apply(p, scale_mat(iso, iso), G, eye)
+    """Geometric ADA pipeline: x-flip, 90-degree rotation, integer translation, isotropic scale, rotation split
+    around an anisotropic scale, fractional translation (reference sample_affine :151-207).  Every stage draws
+    its parameter first and its on/off mask second -- the reference's RNG order."""
+    ln2 = math.log(2)
     p_rot = 1 - math.sqrt(1 - p)
-    G = random_mat_apply(p_rot, rotate_mat(-uniform_sample(size, -math.pi, math.pi)), G, eye)
-    aniso = lognormal_sample(size, std=0.2 * math.log(2))
-    G = random_mat_apply(p, scale_mat(aniso, 1 / aniso), G, eye)
-    G = random_mat_apply(p_rot, rotate_mat(-uniform_sample(size, -math.pi, math.pi)), G, eye)
-    frac = normal_sample(size, std=0.125)
-    G = random_mat_apply(p, translate_mat(frac, frac), G, eye)
-    return G
+    G = _identity(size, 3)
+    G = _maybe(p, _scale2(1 - 2.0 * _choice(size, (0, 1)), torch.ones(size)), G)
+    G = _maybe(p, _rot2(-math.pi / 2 * _choice(size, (0, 3))), G)
+    t = _uniform(size, -0.125, 0.125)
+    G = _maybe(p, _shift2(torch.round(t * width) / width, torch.round(t * height) / height), G)
+    k = _lognormal(size, 0.2 * ln2)
+    G = _maybe(p, _scale2(k, k), G)
+    G = _maybe(p_rot, _rot2(-_uniform(size, -math.pi, math.pi)), G)
+    k = _lognormal(size, 0.2 * ln2)
+    G = _maybe(p, _scale2(k, 1 / k), G)
+    G = _maybe(p_rot, _rot2(-_uniform(size, -math.pi, math.pi)), G)
+    t = _normal(size, 0.125)
+    return _maybe(p, _shift2(t, t), G)
 
 
 def sample_color(p, size):
-    """Colour pipeline (brightness, contrast, luma flip, hue rotation, saturation); reference :210-241."""
-    eye = _eye(size, 4)
-    C = eye
-    axis = (1 / math.sqrt(3),) * 3
-    b = normal_sample(size, std=0.2)
-    C = random_mat_apply(p, translate3d_mat(b, b, b), C, eye)
-    c = lognormal_sample(size, std=0.5 * math.log(2))
-    C = random_mat_apply(p, scale3d_mat(c, c, c), C, eye)
-    C = random_mat_apply(p, luma_flip_mat(axis, category_sample(size, (0, 1))), C, eye)
-    C = random_mat_apply(p, rotate3d_mat(axis, uniform_sample(size, -math.pi, math.pi)), C, eye)
-    C = random_mat_apply(p, saturation_mat(axis, lognormal_sample(size, std=1 * math.log(2))), C, eye)
-    return C
+    """Colour ADA pipeline: brightness, contrast, luma flip, hue rotation, saturation (reference :210-241)."""
+    ln2 = math.log(2)
+    C = _identity(size, 4)
+    C = _maybe(p, _shift3(_normal(size, 0.2)), C)
+    C = _maybe(p, _scale3(_lognormal(size, 0.5 * ln2)), C)
+    C = _maybe(p, _luma_flip(_choice(size, (0, 1))), C)
+    C = _maybe(p, _rot3_about_grey(_uniform(size, -math.pi, math.pi)), C)
+    return _maybe(p, _saturation(_lognormal(size, 1 * ln2)), C)
 
 
 # ---- image-space application ---------------------------------------------------------------------------------

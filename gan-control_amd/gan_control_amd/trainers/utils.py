@@ -1,42 +1,59 @@
-"""Small trainer helpers with the reference's names and semantics (src/gan_control/trainers/utils.py)."""
+"""Trainer helpers: EMA, grad switches, latent sampling, mini-batch chunking.
+
+Same names and semantics as the reference's src/gan_control/trainers/utils.py (cited per function), written
+for device-resident execution: the EMA is two foreach kernels over all parameters instead of a Python loop of
+per-tensor ops, and latent sampling takes an explicit device generator so every rank draws its own stream.
+"""
 import random
 
 import torch
 
 
 def accumulate(model1, model2, decay=0.999):
-    """EMA over named parameters only -- buffers are not averaged (utils.py:8-12)."""
-    p1 = [p.data for _, p in sorted(model1.named_parameters())]
-    p2 = [p.data for _, p in sorted(model2.named_parameters())]
-    torch._foreach_mul_(p1, decay)
-    torch._foreach_add_(p1, p2, alpha=1 - decay)
+    """model1 <- decay * model1 + (1 - decay) * model2 over NAMED PARAMETERS only; buffers (the per-layer noise
+    maps, blur kernels) are not averaged (reference utils.py:8-12)."""
+    target = dict(model1.named_parameters())
+    source = dict(model2.named_parameters())
+    names = sorted(target)
+    dst = [target[n].data for n in names]
+    src = [source[n].data for n in names]
+    torch._foreach_mul_(dst, decay)
+    torch._foreach_add_(dst, src, alpha=1 - decay)
 
 
 def requires_grad(model, flag=True):
-    for p in model.parameters():
-        p.requires_grad = flag
+    """Freeze / unfreeze every parameter of a network (reference utils.py:14-16)."""
+    for param in model.parameters():
+        param.requires_grad_(flag)
 
 
 def make_noise(batch, latent_dim, n_noise, device, generator=None):
+    """One [batch, latent_dim] normal sample, or a tuple of n_noise of them (reference utils.py:26-30)."""
     if n_noise == 1:
         return torch.randn(batch, latent_dim, device=device, generator=generator)
-    return torch.randn(n_noise, batch, latent_dim, device=device, generator=generator).unbind(0)
+    stacked = torch.randn(n_noise, batch, latent_dim, device=device, generator=generator)
+    return stacked.unbind(0)
 
 
 def mixing_noise(batch, latent_dim, prob, device, generator=None):
-    """Style-mixing latents with probability ``prob`` (utils.py:19-23)."""
-    if prob > 0 and random.random() < prob:
+    """Latents for one step: with probability ``prob`` two codes (style mixing), else a single one wrapped in a
+    list (reference utils.py:19-23).  The coin uses Python's ``random`` like the reference."""
+    two_styles = prob > 0 and random.random() < prob
+    if two_styles:
         return make_noise(batch, latent_dim, 2, device, generator)
     return [make_noise(batch, latent_dim, 1, device, generator)]
 
 
 def make_mini_batch_from_noise(noise, batch, mini_batch):
-    """[n_noise][batch, D] -> [n_chunks][n_noise][mini_batch, D] (utils.py:33-42)."""
-    chunks = [n.chunk(batch // mini_batch) for n in noise]
-    return [[c[i] for c in chunks] for i in range(len(chunks[0]))]
+    """Split every latent tensor into batch // mini_batch chunks and regroup per chunk:
+    [n_noise][batch, D] -> [n_chunks][n_noise][mini_batch, D] (reference utils.py:33-42)."""
+    n_chunks = batch // mini_batch
+    per_noise = [t.chunk(n_chunks) for t in noise]
+    return [[pieces[c] for pieces in per_noise] for c in range(len(per_noise[0]))]
 
 
 def set_grad_none(model, targets):
-    for n, p in model.named_parameters():
-        if n in targets:
-            p.grad = None
+    """Drop the gradients of the named parameters so Adam skips them (reference utils.py:45-48)."""
+    for name, param in model.named_parameters():
+        if name in targets:
+            param.grad = None
