@@ -1,2 +1,3 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+timeout 600 python tools/train_sanity.py --size 64 --batch 8 --iters 150 2>&1 | grep -v amdgpu.ids | tail -9
+timeout 600 python tools/train_sanity.py --size 64 --batch 8 --iters 60 --ada --precision f32 2>&1 | grep -v amdgpu.ids | tail -4
