@@ -152,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
         }
     };
     auto commit = [&]() {
+        wait_staged_loads();
         const int t_ = opaque(tid);
         const int wcol = (t_ % C::F4) * 4, wrow0 = t_ / C::F4;
 #pragma unroll
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
         commit();
         __syncthreads();
         for (int k0 = 0; k0 < p.K; k0 += KC) {
+            wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = k0 + KC < p.K;
             if (more) prefetch(k0 + KC);
             // ---- MFMA over taps x channel pairs ----
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
                 }
             }
             __syncthreads();
-            if (more) {
+            if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
+            {
                 commit();
                 __syncthreads();
             }
@@ -352,6 +355,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
         }
     };
     auto commit = [&]() {
+        wait_staged_loads();
         const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NPXM; ++j) {
@@ -382,6 +386,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
         const float* xa = xs + (wk * 32 + l31) * C::CSX;
         const float* db = ds + (wn * 32 + l31) * C::CSY;
         for (int tile = t_begin; tile < t_end; ++tile) {
+            wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
             if (more) prefetch(tile + 1);
             // ---- MFMA: reduction over the pixels of this tile; this wave takes rows r = wp, wp+WP, ... ----
@@ -399,7 +404,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
                 }
             }
             __syncthreads();
-            if (more) {
+            if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
+            {
                 commit();
                 sx_cur = sx_next; sy_cur = sy_next;
                 __syncthreads();

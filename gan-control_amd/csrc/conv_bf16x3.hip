@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
         }
     };
     auto commit = [&](int k0) {
+        wait_staged_loads();
         const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
@@ -194,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
         commit(0);
         __syncthreads();
         for (int k0 = 0; k0 < p.K; k0 += KCB) {
+            wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = k0 + KCB < p.K;
             if (more) prefetch(k0 + KCB);
             const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
@@ -225,7 +227,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
                 }
             }
             __syncthreads();
-            if (more) {
+            if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
+            {
                 commit(k0 + KCB);
                 __syncthreads();
             }
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
         split8(v, scale, h, l);
     };
     auto commit = [&]() {
+        wait_staged_loads();
         const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
@@ -418,6 +422,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
         __syncthreads();
         const int xa = (wk * 32 + l31) * C::CSX + hi, yb_ = (wn * 32 + l31) * C::CSY + hi;
         for (int tile = t_begin; tile < t_end; ++tile) {
+            wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
             if (more) prefetch(tile + 1);
 #pragma unroll
@@ -447,7 +452,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
                 }
             }
             __syncthreads();
-            if (more) {
+            if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
+            {
                 commit();
                 __syncthreads();
             }
@@ -588,6 +594,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
         }
     };
     auto commit = [&]() {
+        wait_staged_loads();
         const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
@@ -635,6 +642,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
         __syncthreads();
         const int xa = (wk * 32 + l31) * C::CSX + hi, yb_ = (wn * 32 + l31) * C::CSY + hi;
         for (int tile = t_begin; tile < t_end; ++tile) {
+            wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
             if (more) prefetch(tile + 1);
 #pragma unroll
@@ -664,7 +672,8 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
                 }
             }
             __syncthreads();
-            if (more) {
+            if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
+            {
                 commit();
                 __syncthreads();
             }
@@ -810,6 +819,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
         }
     };
     auto commit = [&](int k0) {
+        wait_staged_loads();
         const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
@@ -833,6 +843,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     commit(0);
     __syncthreads();
     for (int k0 = 0; k0 < p.K; k0 += KCB) {
+        wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
         const bool more = k0 + KCB < p.K;
         if (more) prefetch(k0 + KCB);
 #pragma unroll
@@ -869,7 +880,8 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
             }
         }
         __syncthreads();
-        if (more) {
+        if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
+        {
             commit(k0 + KCB);
             __syncthreads();
         }

@@ -81,6 +81,12 @@ __device__ __forceinline__ uint4 buf_load_u128(__amdgpu_buffer_rsrc_t r, unsigne
     return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 0));
 }
 
+// Retire every staged load on ALL paths before the next prefetch is issued.  If a loaded register is consumed only
+// under a branch, the compiler's wait-count model keeps it "pending" across the loop back-edge and plants
+// s_waitcnt vmcnt(N) in the middle of the NEXT prefetch; counted in hardware, that waits for the fresh loads and
+// serialises the pipeline.  simm16 = vmcnt(0) with expcnt / lgkmcnt left at their maxima.
+__device__ __forceinline__ void wait_staged_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
 // defined in conv.hip: dw[i] = sum_s ws[s][i] in fixed order (deterministic split reduction)
 int launch_wgrad_reduce(const float* ws, float* dw, size_t count, int parts, hipStream_t s);
 

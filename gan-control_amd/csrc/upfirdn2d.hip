@@ -97,6 +97,168 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// 4x4 taps, down = 2 (the decimating FIR of the ResBlock skip path, Downsample, and the adjoint of every up = 2 FIR).
+// A workgroup produces 16 x 128 outputs from a (34 x 258) input patch; each lane owns a 2 x 4 micro-tile fed from a
+// 6 x 10 register window.  Traffic: reads the input once, writes a quarter of it.
+constexpr int D_TH = 16, D_TW = 128;
+constexpr int D_PH = 2 * D_TH + 2, D_PW = 2 * D_TW + 2, D_PITCH = 260;
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void fir44_down2_kernel(
+    const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
+    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip) {
+    __shared__ __attribute__((aligned(16))) float patch[D_PH * D_PITCH];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * D_TW, oy0 = blockIdx.y * D_TH;
+    const size_t plane = blockIdx.z;
+    const float* xp = x + plane * (size_t)in_h * in_w;
+    float* yp = y + plane * (size_t)out_h * out_w;
+
+    float T[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) T[a][b] = flip ? taps[(3 - a) * 4 + (3 - b)] : taps[a * 4 + b];
+
+    const int iy0 = 2 * oy0 - pad_y0, ix0 = 2 * ox0 - pad_x0;
+    constexpr int NLD = (D_PH * D_PITCH + 255) / 256;
+    float stage[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + 256 * j;
+        const int r = idx / D_PITCH, c = idx - r * D_PITCH;
+        const int iy = iy0 + r, ix = ix0 + c;
+        float v = 0.f;
+        if (idx < D_PH * D_PITCH && c < D_PW && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(size_t)iy * in_w + ix];
+        stage[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < D_PH * D_PITCH) patch[idx] = stage[j];
+    }
+    __syncthreads();
+
+    const int cg = tid & 31, rg = tid >> 5;   // 32 column groups of 4 outputs x 8 row groups of 2 outputs
+    float acc[2][4];
+#pragma unroll
+    for (int r = 0; r < 2; ++r)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const float* row = &patch[(rg * 4 + i) * D_PITCH + cg * 8];
+        const float4 q0 = *reinterpret_cast<const float4*>(row), q1 = *reinterpret_cast<const float4*>(row + 4);
+        const float2 q2 = *reinterpret_cast<const float2*>(row + 8);
+        const float v[10] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y};
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int a = i - 2 * r;
+            if (a < 0 || a > 3) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) acc[r][j] = fmaf(T[a][b], v[2 * j + b], acc[r][j]);
+        }
+    }
+    const int ox = ox0 + cg * 4;
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int oy = oy0 + rg * 2 + r;
+        if (oy >= out_h) break;
+        float* dst = yp + (size_t)oy * out_w + ox;
+        if (VEC) {
+            if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ox + j < out_w) dst[j] = acc[r][j];
+        }
+    }
+}
+
+// 4x4 taps, up = 2 (Upsample of the RGB skip, and the adjoint of every down = 2 FIR).  An output sees only the 2 x 2
+// taps whose zero-stuffed coordinate is even, so a lane's 4 x 4 micro-tile needs a 4 x 4 input window.  With
+// P = (first output coordinate of the lane) - pad, the window starts at floor(P / 2) and the tap / window indices depend
+// only on the parity of P, which is uniform over the launch: EY / EX are template parameters.
+constexpr int U_TH = 32, U_TW = 128;
+constexpr int U_PH = U_TH / 2 + 3, U_PW = U_TW / 2 + 3, U_PITCH = 68;
+
+template <int EY, int EX, bool VEC>
+__global__ __launch_bounds__(256) void fir44_up2_kernel(
+    const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
+    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip) {
+    __shared__ __attribute__((aligned(16))) float patch[U_PH * U_PITCH];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * U_TW, oy0 = blockIdx.y * U_TH;
+    const size_t plane = blockIdx.z;
+    const float* xp = x + plane * (size_t)in_h * in_w;
+    float* yp = y + plane * (size_t)out_h * out_w;
+
+    float T[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) T[a][b] = flip ? taps[(3 - a) * 4 + (3 - b)] : taps[a * 4 + b];
+
+    const int iy0 = (oy0 - pad_y0) >> 1, ix0 = (ox0 - pad_x0) >> 1;    // floor: tile origins are even, parity = pad parity
+    constexpr int NLD = (U_PH * U_PITCH + 255) / 256;
+    float stage[NLD];
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + 256 * j;
+        const int r = idx / U_PITCH, c = idx - r * U_PITCH;
+        const int iy = iy0 + r, ix = ix0 + c;
+        float v = 0.f;
+        if (idx < U_PH * U_PITCH && c < U_PW && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(size_t)iy * in_w + ix];
+        stage[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < NLD; ++j) {
+        const int idx = tid + 256 * j;
+        if (idx < U_PH * U_PITCH) patch[idx] = stage[j];
+    }
+    __syncthreads();
+
+    const int cg = tid & 31, rg = tid >> 5;   // 4 x 4 outputs per lane, window origin (rg * 2, cg * 2) in the patch
+    float w[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float* row = &patch[(rg * 2 + i) * U_PITCH + cg * 2];
+        const float2 lo = *reinterpret_cast<const float2*>(row), hi = *reinterpret_cast<const float2*>(row + 2);
+        w[i][0] = lo.x; w[i][1] = lo.y; w[i][2] = hi.x; w[i][3] = hi.y;
+    }
+    const int ox = ox0 + cg * 4;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int a0 = (EY + r) & 1, qy = (EY + r + a0) >> 1;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b0 = (EX + j) & 1, qx = (EX + j + b0) >> 1;
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) s = fmaf(T[a0 + 2 * i][b0 + 2 * jj], w[qy + i][qx + jj], s);
+            o[j] = s;
+        }
+        const int oy = oy0 + rg * 4 + r;
+        if (oy < out_h) {
+            float* dst = yp + (size_t)oy * out_w + ox;
+            if (VEC) {
+                if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ox + j < out_w) dst[j] = o[j];
+            }
+        }
+    }
+}
+
 constexpr int MAX_GENERIC_TAPS = 1024;
 
 __global__ __launch_bounds__(256) void generic_kernel(
@@ -157,6 +319,28 @@ extern "C" int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
         else
             hipLaunchKernelGGL(fir44_tile_kernel<false>, grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps);
         return gc::check_launch("gc_upfirdn2d_f32(fir44_tile)");
+    }
+    const bool square44 = kh == 4 && kw == 4 && up_x == up_y && down_x == down_y && planes <= 65535 && out_w >= 64 && out_h >= 8;
+    const bool vec_ok = (out_w % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+    if (square44 && up_x == 1 && down_x == 2) {
+        dim3 grid(gc::ceil_div(out_w, D_TW), gc::ceil_div(out_h, D_TH), planes);
+        if (vec_ok)
+            hipLaunchKernelGGL(fir44_down2_kernel<true>, grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps);
+        else
+            hipLaunchKernelGGL(fir44_down2_kernel<false>, grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps);
+        return gc::check_launch("gc_upfirdn2d_f32(fir44_down2)");
+    }
+    if (square44 && up_x == 2 && down_x == 1) {
+        dim3 grid(gc::ceil_div(out_w, U_TW), gc::ceil_div(out_h, U_TH), planes);
+        const int ey = pad_y0 & 1, ex = pad_x0 & 1;     // parity of (tile origin - pad); tile origins are multiples of 4
+#define GC_UP2(EY, EX)                                                                                                             \
+        if (ey == EY && ex == EX) {                                                                                                \
+            if (vec_ok) hipLaunchKernelGGL((fir44_up2_kernel<EY, EX, true>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps); \
+            else hipLaunchKernelGGL((fir44_up2_kernel<EY, EX, false>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps);       \
+        }
+        GC_UP2(0, 0) GC_UP2(0, 1) GC_UP2(1, 0) GC_UP2(1, 1)
+#undef GC_UP2
+        return gc::check_launch("gc_upfirdn2d_f32(fir44_up2)");
     }
     if (kh * kw > MAX_GENERIC_TAPS) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_f32: %d x %d taps exceed %d", kh, kw, MAX_GENERIC_TAPS);
     const size_t total = (size_t)planes * out_h * out_w;

@@ -368,6 +368,20 @@ class ConvLayer(nn.Sequential):
                 raise NotImplementedError('ConvLayer: activation without bias (ScaledLeakyReLU) is not built')
             layers.append(FusedLeakyReLU(out_channel))
         super().__init__(*layers)
+        # Blur followed by a stride-2 1x1 conv only ever reads the even blur outputs: decimate INSIDE the FIR
+        # (upfirdn2d down=2, the same taps at the same positions) and run the 1x1 conv at stride 1 on a quarter
+        # of the pixels.  Same values as gan_model.py:844-890, a quarter of the FIR output / conv input traffic.
+        self._decimating_fir = downsample and kernel_size == 1
+
+    def forward(self, input):
+        if not self._decimating_fir:
+            return super().forward(input)
+        blur, conv = self[0], self[1]
+        out = upfirdn2d(input, blur.kernel, down=conv.stride, pad=blur.pad)
+        out = conv2d_gradfix.conv2d(out, conv.weight * conv.scale, bias=conv.bias, stride=1, padding=0)
+        for layer in list(self)[2:]:
+            out = layer(out)
+        return out
 
 
 class ResBlock(nn.Module):

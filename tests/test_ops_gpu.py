@@ -87,6 +87,31 @@ def test_upfirdn2d_generic_shapes(up, down, ksz):
             assert rel_err(out, ref) < 2e-6, (p0, p1, flip)
 
 
+@pytest.mark.parametrize('up,down', [(1, 2), (2, 1)])
+@pytest.mark.parametrize('shape', [(2, 3, 64, 130), (1, 2, 257, 255), (1, 1, 33, 513), (3, 1, 128, 128), (1, 2, 16, 140)])
+def test_upfirdn2d_resampling_tile_kernels(up, down, shape):
+    """4x4 taps with up = 2 or down = 2 on planes wide enough for the tile kernels (fir44_down2 / fir44_up2)."""
+    hip, emu = _be()
+    gen = torch.Generator().manual_seed(sum(shape) + up)
+    x = torch.randn(*shape, generator=gen)
+    k = torch.randn(4, 4, generator=gen)
+    for p0, p1 in [(1, 1), (2, 1), (2, 2), (0, 3), (3, 0), (-1, 2), (-2, -1)]:
+        oh, ow = (shape[2] * up + p0 + p1 - 4) // down + 1, (shape[3] * up + p0 + p1 - 4) // down + 1
+        if oh < 1 or ow < 1:
+            continue
+        for flip in (True, False):
+            ref = emu.upfirdn2d(x.double(), k.double(), up, down, p0, p0, oh, ow, flip)
+            out = hip.upfirdn2d(x.to(DEV), k.to(DEV), up, down, p0, p0, oh, ow, flip)
+            assert out.shape == ref.shape
+            assert rel_err(out, ref) < 2e-6, (p0, p1, flip)
+    # misaligned input base
+    xs = torch.empty(x.numel() + 1, device=DEV)[1:].view_as(x).copy_(x)
+    oh, ow = (shape[2] * up + 2 - 4) // down + 1, (shape[3] * up + 2 - 4) // down + 1
+    a = hip.upfirdn2d(xs, k.to(DEV), up, down, 1, 1, oh, ow, True)
+    b = hip.upfirdn2d(x.to(DEV), k.to(DEV), up, down, 1, 1, oh, ow, True)
+    assert torch.equal(a, b)
+
+
 CONV_CASES = [
     # b, K, N, h, w, k, up, down, pad
     (2, 8, 8, 4, 4, 3, 1, 1, 1), (2, 16, 130, 8, 8, 3, 1, 1, 1), (1, 40, 64, 16, 16, 3, 1, 1, 1),
