@@ -320,7 +320,7 @@ extern "C" int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
             hipLaunchKernelGGL(fir44_tile_kernel<false>, grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps);
         return gc::check_launch("gc_upfirdn2d_f32(fir44_tile)");
     }
-    const bool square44 = kh == 4 && kw == 4 && up_x == up_y && down_x == down_y && planes <= 65535 && out_w >= 64 && out_h >= 8;
+    const bool square44 = kh == 4 && kw == 4 && up_x == up_y && down_x == down_y && planes <= 65535 && out_w >= 32 && out_h >= 8;
     const bool vec_ok = (out_w % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
     if (square44 && up_x == 1 && down_x == 2) {
         dim3 grid(gc::ceil_div(out_w, D_TW), gc::ceil_div(out_h, D_TH), planes);

@@ -84,7 +84,7 @@ class EqualConv2d(nn.Module):
         self.bias = nn.Parameter(torch.zeros(out_channel)) if bias else None
 
     def forward(self, input):
-        return conv2d_gradfix.conv2d(input, self.weight * self.scale, bias=self.bias, stride=self.stride, padding=self.padding)
+        return conv2d_gradfix.conv2d(input, self.weight, bias=self.bias, stride=self.stride, padding=self.padding, weight_scale=self.scale)
 
     def __repr__(self):
         oc, ic, k, _ = self.weight.shape
@@ -378,7 +378,7 @@ class ConvLayer(nn.Sequential):
             return super().forward(input)
         blur, conv = self[0], self[1]
         out = upfirdn2d(input, blur.kernel, down=conv.stride, pad=blur.pad)
-        out = conv2d_gradfix.conv2d(out, conv.weight * conv.scale, bias=conv.bias, stride=1, padding=0)
+        out = conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=1, padding=0, weight_scale=conv.scale)
         for layer in list(self)[2:]:
             out = layer(out)
         return out

@@ -123,6 +123,25 @@ class HipBackend:
         _lib.check(rc, 'gc_plane_dot_f32')
         return partial.sum(2) if chunks > 1 else partial.reshape(batch, ch)
 
+    def weight_layout(self, src, taps, k, n, src_stride, dst_shape, dst_stride, flip, scale):
+        """dst[t',k,n] = scale * src[t,k,n] between two strided weight layouts; see gc_weight_layout_f32."""
+        import ctypes
+        dev = _lib.require_cuda_f32(src)
+        dst = torch.empty(dst_shape, dtype=src.dtype, device=dev)
+        if dst.numel() != taps * k * n or src.numel() != taps * k * n:
+            raise RuntimeError('weight_layout: %d x %d x %d elements expected, got src %d / dst %d' % (taps, k, n, src.numel(), dst.numel()))
+        lib = _lib.load()
+        i64x3 = ctypes.c_int64 * 3
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_weight_layout_f32(_lib.ptr(src), _lib.ptr(dst), taps, k, n, ctypes.byref(i64x3(*src_stride)), ctypes.byref(i64x3(*dst_stride)),
+                                          int(bool(flip)), float(scale), _lib.stream_of(src))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_weight_layout_f32')
+        return dst
+
     def channel_sum(self, x):
         """[B, C, *] -> [C]: sum over every dim but 1."""
         dev = _lib.require_cuda_f32(x)

@@ -11,13 +11,14 @@ autograd Functions that are each other's derivatives:
 
 d_GConv/dx is a _GConv with (up <-> down, flipped taps, swapped channel axes); d_GConv/dw is a
 _WGrad; both derivatives of _WGrad are _GConv's.  Weights travel as w_t = [kh, kw, K, N]
-(correlation order, N contiguous); the layout changes are ordinary differentiable torch ops.
+(correlation order, N contiguous); the layout changes are single fused passes (weight_layout.py).
 """
 import torch
 from torch.autograd import Function
 
 from . import _backend
 from ._backend import ConvGeom
+from .weight_layout import adjoint_layout, kernel_layout
 
 
 def _adjoint_geom(g, in_h, in_w):
@@ -26,8 +27,8 @@ def _adjoint_geom(g, in_h, in_w):
 
 
 def _adjoint_weight(w_t):
-    """[kh,kw,K,N] -> [kh,kw,N,K] with flipped taps."""
-    return w_t.flip(0, 1).transpose(2, 3).contiguous()
+    """[kh,kw,K,N] -> [kh,kw,N,K] with flipped taps (one fused pass)."""
+    return adjoint_layout(w_t)
 
 
 class _GConv(Function):
@@ -55,7 +56,7 @@ def _weight_grad(x, gy, g):
         return _WGrad.apply(x, gy, g)
     # transposed conv: correlate gy (as the "input", decimated by `up`) with x (as the "output gradient")
     swapped = ConvGeom(g.kh, g.kw, 1, g.up, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x, x.shape[2], x.shape[3])
-    return _WGrad.apply(gy, x, swapped).flip(0, 1).transpose(2, 3)
+    return adjoint_layout(_WGrad.apply(gy, x, swapped))
 
 
 class _WGrad(Function):
@@ -109,21 +110,22 @@ def conv_transpose2d_t(x, w_t, stride=1, padding=0):
     return _GConv.apply(x, w_t, ConvGeom(kh, kw, stride, 1, kh - 1 - padding, kw - 1 - padding, oh, ow))
 
 
-def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1):
-    """Same call signature as torch.nn.functional.conv2d (weight [OC, IC, kh, kw])."""
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_scale=1.0):
+    """Same call signature as torch.nn.functional.conv2d (weight [OC, IC, kh, kw]); weight_scale (an extension) folds
+    the equalised-learning-rate factor into the layout pass instead of a separate ``weight * scale``."""
     s, p = _check(input, weight, stride, padding, dilation, groups)
     if weight.shape[1] != input.shape[1]:
         raise ValueError(f'conv2d: weight expects {weight.shape[1]} input channels, got {input.shape[1]}')
-    y = conv2d_t(input, weight.permute(2, 3, 1, 0).contiguous(), s, p)
+    y = conv2d_t(input, kernel_layout(weight, weight_scale), s, p)
     return y if bias is None else y + bias.reshape(1, -1, 1, 1)
 
 
-def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1):
-    """Same call signature as torch.nn.functional.conv_transpose2d (weight [IC, OC, kh, kw])."""
+def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, weight_scale=1.0):
+    """Same call signature as torch.nn.functional.conv_transpose2d (weight [IC, OC, kh, kw]) plus weight_scale."""
     s, p = _check(input, weight, stride, padding, dilation, groups)
     if output_padding not in (0, (0, 0)):
         raise ValueError('conv_transpose2d: output_padding is not implemented on the HIP path')
     if weight.shape[0] != input.shape[1]:
         raise ValueError(f'conv_transpose2d: weight expects {weight.shape[0]} input channels, got {input.shape[1]}')
-    y = conv_transpose2d_t(input, weight.flip(2, 3).permute(2, 3, 0, 1).contiguous(), s, p)
+    y = conv_transpose2d_t(input, kernel_layout(weight, weight_scale, flip=True, in_major=True), s, p)
     return y if bias is None else y + bias.reshape(1, -1, 1, 1)

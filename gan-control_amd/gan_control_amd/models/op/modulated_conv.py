@@ -26,12 +26,13 @@ from torch.autograd import Function
 from . import _backend
 from ._backend import ConvGeom
 from .conv2d_gradfix import _adjoint_geom, _adjoint_weight
+from .weight_layout import kernel_layout
 from .upfirdn2d import upfirdn2d
 
 
 def demod_coefficients(weight, s, scale, eps=1e-8):
     """d[b,oc] = rsqrt(sum_{ic,k} (scale * W[oc,ic,k] * s[b,ic])^2 + eps); weight is [1,OC,IC,k,k], s is [B,IC]."""
-    wsq = weight[0].pow(2).sum([2, 3])                     # [OC, IC]
+    wsq = weight.view(weight.shape[1:]).pow(2).sum([2, 3])     # [OC, IC]  (view, not weight[0]: its backward is free)
     return torch.rsqrt((s.pow(2) @ wsq.t()) * (scale * scale) + eps)
 
 
@@ -92,7 +93,7 @@ def _mod_weight_grad(x, gy, si, so, g):
         return _ModWGrad.apply(x, gy, si, so, g)
     # transposed conv: correlate gy (as the "input", decimated by `up`) with x (as the "output gradient")
     swapped = ConvGeom(g.kh, g.kw, 1, g.up, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x, x.shape[2], x.shape[3])
-    return _ModWGrad.apply(gy, x, so, si, swapped).flip(0, 1).transpose(2, 3)
+    return _adjoint_weight(_ModWGrad.apply(gy, x, so, si, swapped))
 
 
 class _ModWGrad(Function):
@@ -136,13 +137,12 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
     _, oc, ic, k, _ = weight.shape
     scale = 1.0 / math.sqrt(ic * k * k)
     d = demod_coefficients(weight, s, scale) if demodulate else None
-    w = weight[0] * scale                                                  # [OC, IC, k, k]
     if upsample:
-        w_t = w.flip(2, 3).permute(2, 3, 1, 0).contiguous()                # correlation form, [k,k,IC,OC]
+        w_t = kernel_layout(weight.view(oc, ic, k, k), scale, flip=True)                   # correlation form, [k,k,IC,OC]
         oh, ow = (x.shape[2] - 1) * 2 + k, (x.shape[3] - 1) * 2 + k
         y = _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 2, 1, k - 1, k - 1, oh, ow))
         return upfirdn2d(y, blur_kernel, pad=blur_pad)
     pad = k // 2 if padding is None else padding
-    w_t = w.permute(2, 3, 1, 0).contiguous()
+    w_t = kernel_layout(weight.view(oc, ic, k, k), scale)
     oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1
     return _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow))

@@ -1,0 +1,47 @@
+"""Differentiable weight re-layouts on gc_weight_layout_f32 (one pass: scale + permute + optional tap mirror).
+
+The convolution kernels take weights as ``w_t = [kh, kw, K, N]`` in correlation order; parameters are stored the way the
+reference stores them (``[N, K, kh, kw]``, gan_model.py:139, or ``[1, N, K, kh, kw]``, gan_model.py:268).  Every re-layout
+is a scaled permutation P, so its gradient is the re-layout with source and destination swapped (P^T = P^-1 up to the
+scale) and the closure needed for R1 / path-length double-backward is immediate.
+"""
+from torch.autograd import Function
+
+from . import _backend
+
+
+class _Relayout(Function):
+    """spec = (taps, k, n, src_stride, dst_shape, dst_stride, flip); strides are for the logical axes (tap, k, n)."""
+
+    @staticmethod
+    def forward(ctx, src, spec, scale):
+        taps, k, n, src_stride, dst_shape, dst_stride, flip = spec
+        ctx.inverse = (taps, k, n, dst_stride, tuple(src.shape), src_stride, flip)
+        ctx.scale = scale
+        return _backend.get().weight_layout(src.contiguous(), taps, k, n, src_stride, dst_shape, dst_stride, flip, scale)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _Relayout.apply(g, ctx.inverse, ctx.scale), None, None
+
+
+def kernel_layout(weight, scale=1.0, flip=False, in_major=False):
+    """Parameter -> w_t [kh, kw, K, N] (times scale, taps mirrored if flip).
+
+    weight is [N, K, kh, kw] (F.conv2d layout) or, with in_major, [K, N, kh, kw] (F.conv_transpose2d layout).
+    """
+    d0, d1, kh, kw = weight.shape
+    taps = kh * kw
+    if in_major:
+        k, n = d0, d1
+        src_stride = (1, n * taps, taps)
+    else:
+        n, k = d0, d1
+        src_stride = (1, taps, k * taps)
+    return _Relayout.apply(weight, (taps, k, n, src_stride, (kh, kw, k, n), (k * n, n, 1), bool(flip)), float(scale))
+
+
+def adjoint_layout(w_t):
+    """[kh, kw, K, N] -> [kh, kw, N, K] with mirrored taps: the weights of d/dx of the convolution."""
+    kh, kw, k, n = w_t.shape
+    return _Relayout.apply(w_t, (kh * kw, k, n, (k * n, n, 1), (kh, kw, n, k), (n * k, 1, k), True), 1.0)

@@ -164,6 +164,24 @@ int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x, const floa
                                const float* in_scale, const float* out_scale, float* dw,
                                void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Weight re-layout: scale + permute + optional tap mirror in one pass.
+ *
+ *   dst[t' * dst_stride[0] + k * dst_stride[1] + n * dst_stride[2]]
+ *       = scale * src[t * src_stride[0] + k * src_stride[1] + n * src_stride[2]],   t' = flip_taps ? taps - 1 - t : t
+ *
+ * for t < taps (= kh*kw), k < in_ch, n < out_ch; strides in ELEMENTS, non-negative.  Replaces the ATen passes the
+ * reference spends per call on `self.weight * self.scale` (gan_model.py:154, 284), the transpose / view of the
+ * up-sampling branch (gan_model.py:295-303) and the permutes inside aten::convolution_backward:
+ *   parameter [N,K,taps] -> kernel layout [taps,K,N]      src_stride = {1, taps, K*taps}, dst_stride = {K*N, N, 1}
+ *   kernel layout -> input-gradient weights [taps',N,K]   src_stride = {K*N, N, 1},       dst_stride = {N*K, 1, K}, flip
+ *   weight gradient [taps,K,N] -> parameter layout        src_stride = {K*N, N, 1},       dst_stride = {1, taps, K*taps}
+ * src and dst must not overlap.
+ */
+int gc_weight_layout_f32(const float* src, float* dst, int taps, int k, int n,
+                         const int64_t src_stride[3], const int64_t dst_stride[3],
+                         int flip_taps, float scale, gc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

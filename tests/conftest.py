@@ -100,6 +100,14 @@ class EmulatedBackend:
     def channel_sum(self, x):
         return x.sum([d for d in range(x.ndim) if d != 1])
 
+    def weight_layout(self, src, taps, k, n, src_stride, dst_shape, dst_stride, flip, scale):
+        view = torch.as_strided(src.contiguous().reshape(-1), (taps, k, n), tuple(src_stride))
+        if flip:
+            view = view.flip(0)
+        dst = torch.empty(dst_shape, dtype=src.dtype)
+        torch.as_strided(dst.reshape(-1), (taps, k, n), tuple(dst_stride)).copy_(view * scale)
+        return dst
+
     def conv2d(self, x, w_t, in_scale, out_scale, geom):
         if in_scale is not None:
             x = x * in_scale[:, :, None, None]

@@ -112,6 +112,46 @@ def test_upfirdn2d_resampling_tile_kernels(up, down, shape):
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize('n,k,kh', [(512, 512, 3), (40, 70, 3), (3, 32, 1), (32, 3, 1), (33, 1, 3), (1, 65, 3), (130, 64, 5)])
+def test_weight_layout_kernel(n, k, kh):
+    """gc_weight_layout_f32 against strided torch views: parameter -> kernel layout, adjoint, and back; bit-exact for scale 1."""
+    hip, emu = _be()
+    gen = torch.Generator().manual_seed(n * 7 + k)
+    taps = kh * kh
+    w = torch.randn(n, k, kh, kh, generator=gen)
+    # (logical K, logical N, src strides for (tap, k, n), flip, scale)
+    specs = [(k, n, (1, taps, k * taps), False, 1.0),        # [N,K,kh,kw] parameter -> [t,k,n]
+             (k, n, (1, taps, k * taps), True, 0.37),        # ... mirrored, scaled
+             (n, k, (1, k * taps, taps), True, 1.0)]         # the same buffer read as [K',N',kh,kw] (conv_transpose2d layout)
+    for kk, nn, src_stride, flip, scale in specs:
+        dst_shape, dst_stride = (kh, kh, kk, nn), (kk * nn, nn, 1)
+        ref = emu.weight_layout(w, taps, kk, nn, src_stride, dst_shape, dst_stride, flip, scale)
+        out = hip.weight_layout(w.to(DEV), taps, kk, nn, src_stride, dst_shape, dst_stride, flip, scale)
+        assert torch.equal(out.cpu(), ref), (src_stride, flip, scale)
+    w_t = torch.randn(kh, kh, k, n, generator=gen)
+    ref = w_t.flip(0, 1).transpose(2, 3).contiguous()
+    out = hip.weight_layout(w_t.to(DEV), taps, k, n, (k * n, n, 1), (kh, kh, n, k), (n * k, 1, k), True, 1.0)
+    assert torch.equal(out.cpu(), ref)
+    back = hip.weight_layout(out, taps, n, k, (n * k, k, 1), (kh, kh, k, n), (k * n, 1, n), True, 1.0)
+    assert torch.equal(back.cpu(), w_t)
+
+
+def test_weight_layout_autograd_closure():
+    from gan_control_amd.models.op.weight_layout import kernel_layout, adjoint_layout
+    w = torch.randn(24, 40, 3, 3, device=DEV, dtype=torch.float32, requires_grad=True)
+    out = kernel_layout(w, 0.5, flip=True)
+    ref = (w * 0.5).flip(2, 3).permute(2, 3, 1, 0)
+    assert torch.equal(out, ref.contiguous())
+    g = torch.randn_like(out)
+    gw, = torch.autograd.grad(out, w, g, create_graph=True)
+    gref, = torch.autograd.grad(ref, w, g)
+    assert torch.allclose(gw, gref, rtol=0, atol=0)
+    adj = adjoint_layout(out)
+    assert torch.equal(adj, out.flip(0, 1).transpose(2, 3).contiguous())
+    gg, = torch.autograd.grad(adj, w, torch.ones_like(adj))
+    assert torch.allclose(gg, torch.full_like(gg, 0.5))
+
+
 CONV_CASES = [
     # b, K, N, h, w, k, up, down, pad
     (2, 8, 8, 4, 4, 3, 1, 1, 1), (2, 16, 130, 8, 8, 3, 1, 1, 1), (1, 40, 64, 16, 16, 3, 1, 1, 1),
