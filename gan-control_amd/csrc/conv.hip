@@ -67,6 +67,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[C::SMEM];
     float* wl = smem;                 // [tap][KC][OCT]
     float* patch = smem + C::WL;      // [KC][PH][PP]
+    __shared__ float s_so[OCT], s_bias[OCT];   // out_scale / bias of this workgroup's channels (see conv_epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -107,6 +108,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
 
     const float* xb = p.x + (size_t)b * p.K * p.in_h * p.in_w;
     const float* sib = p.si ? p.si + (size_t)b * p.K : nullptr;
+    for (int o = tid; o < OCT; o += 256) {     // read only in the epilogue
+        const int oc = min(n0 + o, p.N - 1);
+        s_so[o] = p.so ? p.so[(size_t)b * p.N + oc] : 1.f;
+        s_bias[o] = p.bias ? p.bias[oc] : 0.f;
+    }
+    __syncthreads();
     const bool wvec = (p.N % 4 == 0) && ((reinterpret_cast<uintptr_t>(p.w) & 15) == 0);
     const int chan = p.in_h * p.in_w;          // host guarantees K * H * W < 2^31
 
@@ -232,23 +239,21 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     }
 
     // ---- epilogue: demodulate and store; lanes 0..31 of a register are consecutive pixels ----
-    const float* sob = p.so ? p.so + (size_t)b * p.N : nullptr;
     float* yb = p.y + (size_t)b * p.N * p.out_h * p.out_w;
+    const EpilogueConsts ec = epilogue_consts(p);
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         const int qy = qy0 + (wave_px * WPX + j) * RPB + l31 / TPW, qx = qx0 + l31 % TPW;
         if (qy >= qh || qx >= qw) continue;
         const int oy = qy * UP + phy, ox = qx * UP + phx;
+        const float nz = p.noise ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
 #pragma unroll
         for (int i = 0; i < WOC; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int oc = n0 + (wave_oc * WOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (oc < p.N) {
-                    float v = acc[i][j][r];
-                    if (sob) v *= sob[oc];
-                    yb[((size_t)oc * p.out_h + oy) * p.out_w + ox] = v;
-                }
+                const int ocl = (wave_oc * WOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (n0 + ocl < p.N)
+                    yb[((size_t)(n0 + ocl) * p.out_h + oy) * p.out_w + ox] = conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz);
             }
         }
     }
@@ -552,14 +557,17 @@ int dispatch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,
-                             const float* in_scale, const float* out_scale, float* y, gc_stream_t stream) {
+extern "C" int gc_conv2d_fused_f32(const gc_conv_desc* d, const float* x, const float* w,
+                                   const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep,
+                                   float* y, gc_stream_t stream) {
     int rc = validate(d, "gc_conv2d_f32", false);
     if (rc) return rc;
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_f32: null pointer");
+    if ((rc = validate_epilogue(ep, "gc_conv2d_f32"))) return rc;
     if (d->batch == 0) return GC_OK;
     ConvArgs a{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
                d->pad_y, d->pad_x, 0, 0};
+    set_epilogue(a, ep);
     hipStream_t s = (hipStream_t)stream;
     if (d->kh == 3) {
         if (d->up == 2) return dispatch_conv<2, 1, 3>(a, s);
@@ -567,6 +575,11 @@ extern "C" int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float*
     }
     if (d->up == 2) return dispatch_conv<2, 1, 1>(a, s);
     return d->down == 2 ? dispatch_conv<1, 2, 1>(a, s) : dispatch_conv<1, 1, 1>(a, s);
+}
+
+extern "C" int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,
+                             const float* in_scale, const float* out_scale, float* y, gc_stream_t stream) {
+    return gc_conv2d_fused_f32(d, x, w, in_scale, out_scale, nullptr, y, stream);
 }
 
 extern "C" size_t gc_conv2d_wgrad_workspace(const gc_conv_desc* d) {

@@ -25,11 +25,13 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int KCB = 16;   // input channels per chunk = K of one bf16 MFMA
 constexpr int KG = 2;     // 8-channel groups per chunk
+constexpr int MAX_K_BF16X3 = 1024;   // in_scale of one sample is kept in LDS
 
 struct Bf16Args {
     ConvArgs c;
     const uint4* wh; const uint4* wl;   // packed weights [tap][ceil(K/8)][N] units of 8 bf16 (hi / lo parts)
     int kgroups;                        // ceil(K / 8)
+    int tpb, groups;                    // conv_bf16x3_kernel: pixel tiles per workgroup, workgroups per (sample, phase)
 };
 
 // wp[t][kg][n] = 8 x bf16 of w[t][kg*8 + q][n], q = 0..7 (zero beyond K); hi and lo parts
@@ -65,7 +67,29 @@ struct BCfg {
     static constexpr int PUNITS = KG * PLANE;
     static constexpr int SMEM_UNITS = 2 * (WUNITS + PUNITS);
     static constexpr int NWU = (WUNITS + 255) / 256;        // weight units prefetched per thread (x2: hi, lo)
-    static constexpr int NPU = (PLANE + 127) / 128;         // patch units per thread (half the block per channel group)
+    // Patch staging.  The texture-address unit spends ~16 cycles per wave-level load whatever its width, and at <= 64 input
+    // channels that -- not HBM, not the MFMAs -- bounds the kernel (measured: 37 % of a pipeline step issuing dword loads,
+    // 30 % waiting for them).  So a lane fetches FOUR consecutive pixels of a channel with one 16-byte load, eight channels
+    // = eight loads, and transposes them in registers into four channel-last units: 4x fewer load instructions.
+    // A patch row starts `lead` floats before a 128-byte boundary (lead = pad for 32-pixel tiles): its SEG_M aligned 32-float
+    // segments are cut into 16-byte groups ("main" tasks, all four pixels used), the EDGE columns left and right of them
+    // are "edge" tasks (same load, first pixel used).  Out-of-range dwords of a buffer load read as zero one by one
+    // (tools/micro/buf_oob.hip), so a group may straddle the end of the tensor; pixels past the end of an image ROW are
+    // masked at commit.
+    static constexpr int SEG_M = PWD % 32 == 0 ? PWD / 32 : (PWD - 1) / 32;
+    static constexpr int EDGE = PWD - 32 * SEG_M;
+    static constexpr int MAIN_T = PH * 8 * SEG_M, EDGE_T = PH * EDGE, TASKS = MAIN_T + EDGE_T;   // per 8-channel group
+    static constexpr int NT = (TASKS + 127) / 128;          // tasks per thread (128 threads per channel group)
+    struct Task { int row, col, used; };                    // patch row, first patch column, pixels used (0: no task)
+    __device__ static __forceinline__ Task task_of(int t, int lead) {
+        Task k;
+        if (t < MAIN_T) { k.row = t / (8 * SEG_M); k.col = lead + 4 * (t % (8 * SEG_M)); k.used = 4; return k; }
+        const int e = t - MAIN_T, ce = e % cmax(EDGE, 1);
+        k.row = e / cmax(EDGE, 1);
+        k.col = ce < lead ? ce : 32 * SEG_M + ce;
+        k.used = t < TASKS ? 1 : 0;
+        return k;
+    }
 };
 
 template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
@@ -79,25 +103,36 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     uint4* wl_l = wl_h + C::WUNITS;
     uint4* p_h = wl_l + C::WUNITS;              // [kg][PH][PWD]
     uint4* p_l = p_h + C::PUNITS;
+    __shared__ __attribute__((aligned(16))) float s_si[MAX_K_BF16X3 + KCB];     // in_scale of this sample, zero-padded past K
+    // out_scale and bias of this workgroup's channels.  They must NOT be fetched between the stores of the epilogue: a
+    // vector load there forces s_waitcnt vmcnt(0), which also waits for every store issued before it -- one full memory
+    // round trip per output row.
+    __shared__ __attribute__((aligned(16))) float s_so[OCT], s_bias[OCT];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wave_px = wave % WG_PX, wave_oc = wave / WG_PX;
+    const int wave_oc_u = __builtin_amdgcn_readfirstlane(wave_oc);
 
+    // A workgroup owns `tpb` consecutive pixel tiles of one (sample, phase, oc-block) and runs ONE software pipeline over all
+    // their channel chunks: the first chunk of the next tile is in flight during the last MFMA phase and the stores of the
+    // current tile, so neither the cold-start load latency nor the store drain is paid per tile (they dominate at K <= 64).
     int bid = blockIdx.x;
-    const int tile_x = bid % p.tiles_x; bid /= p.tiles_x;
-    const int tile_y = bid % p.tiles_y; bid /= p.tiles_y;
+    const int grp = bid % a.groups; bid /= a.groups;
     const int phase = bid % (UP * UP);
     const int b = bid / (UP * UP);
     const int phy = phase / UP, phx = phase % UP;
-    const int n0 = blockIdx.y * OCT;
+    const int n0 = blockIdx.y * OCT, n0_blk = n0;
     const int qh = (p.out_h - phy + UP - 1) / UP, qw = (p.out_w - phx + UP - 1) / UP;
-    const int qy0 = tile_y * TPH, qx0 = tile_x * 32;
-    if (qy0 >= qh || qx0 >= qw) return;
+    const int tile_begin = grp * a.tpb, tile_end = min(p.tiles_x * p.tiles_y, tile_begin + a.tpb);
+    if (UP > 1) {      // tpb == 1; phases other than 0 have a smaller sub-grid
+        if ((tile_begin / p.tiles_x) * TPH >= qh || (tile_begin % p.tiles_x) * 32 >= qw) return;
+    }
 
     const AxisTaps ay = axis_taps<UP, KS>(phy, p.pad_y), ax = axis_taps<UP, KS>(phx, p.pad_x);
     const int ntaps = ay.n * ax.n;
-    const int iy0 = qy0 * DOWN + ay.d0, ix0 = qx0 * DOWN + ax.d0;
+    // patch rows start at 32 * DOWN * tile_x + ax.d0: `lead` floats before an aligned 32-float segment
+    const int lead = gc::pos_mod(-ax.d0, 32);      // <= C::EDGE (checked on the host)
 
     f32x16 acc[WOC][WPX];
 #pragma unroll
@@ -117,16 +152,16 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     const int chan = p.in_h * p.in_w;
 
     uint4 wreg_h[C::NWU], wreg_l[C::NWU];
-    float preg[C::NPU][8];
-    float sreg[8];
+    uint4 preg[C::NT][8];                       // [task][channel] = 4 consecutive pixels
 
     // Buffer-descriptor loads: scalar channel offset + 32-bit lane offset, hardware zero-fill outside the image, and
     // nothing touches the results until commit(), so every load stays in flight across the MFMA block.
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)p.K * chan * 4u);
     const unsigned wbytes = (unsigned)(KS * KS) * a.kgroups * p.N * 16u;
     const __amdgpu_buffer_rsrc_t rwh = make_rsrc(a.wh, wbytes), rwl = make_rsrc(a.wl, wbytes);
-    auto prefetch = [&](int k0) {
+    auto prefetch = [&](int tile, int k0) {
         const int t_ = opaque(tid);
+        const int iy0 = (tile / p.tiles_x) * TPH * DOWN + ay.d0, ix0 = (tile % p.tiles_x) * 32 * DOWN + ax.d0;
         // weights: unit u -> (tap, kg, oc); plain 16-byte copies of the pre-split slab
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
@@ -141,120 +176,152 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
             wreg_h[j] = buf_load_u128(rwh, gb, 0);
             wreg_l[j] = buf_load_u128(rwl, gb, 0);
         }
-        // patch: waves 0,1 take channel group 0, waves 2,3 group 1; a unit = 8 channels of one pixel
-        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), pbase = t_ & 127;
+        // patch: waves 0,1 take channel group 0, waves 2,3 group 1
+        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), tb = t_ & 127;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const int k = k0 + kgl * 8 + q;
-            sreg[q] = sib ? sib[min(k, p.K - 1)] : 1.f;
-        }
-#pragma unroll
-        for (int j = 0; j < C::NPU; ++j) {
-            const int pos = pbase + 128 * j;
-            const int r = pos / PWD, c = pos % PWD;
-            const int iy = iy0 + r, ix = ix0 + c;
-            const bool ok = pos < PLANE && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        for (int j = 0; j < C::NT; ++j) {
+            const typename C::Task tk = C::task_of(tb + 128 * j, lead);
+            const int iy = iy0 + tk.row, ix = ix0 + tk.col;
+            const bool ok = tk.used > 0 && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
             const unsigned boff = ok ? (unsigned)(iy * p.in_w + ix) * 4u : OOB;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int k = min(k0 + kgl * 8 + q, p.K - 1);          // wave-uniform -> scalar offset
-                preg[j][q] = buf_load_f32(rx, boff, (unsigned)k * chan * 4u);
+                preg[j][q] = buf_load_u128(rx, boff, (unsigned)k * chan * 4u);
             }
         }
     };
-    auto commit = [&](int k0) {
-        wait_staged_loads();
+    auto commit = [&](int tile, int k0) {
         const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
             const int u = t_ + 256 * j;
             if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; wl_l[u] = wreg_l[j]; }
         }
-        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), pbase = t_ & 127;
+        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), tb = t_ & 127;
+        const int ix0 = (tile % p.tiles_x) * 32 * DOWN + ax.d0;
+        // per-sample input scales of this chunk (zero beyond K: a ragged last chunk contributes nothing)
+        const float4 sa = *reinterpret_cast<const float4*>(&s_si[k0 + kgl * 8]), sb = *reinterpret_cast<const float4*>(&s_si[k0 + kgl * 8 + 4]);
+        const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
 #pragma unroll
-        for (int j = 0; j < C::NPU; ++j) {
-            const int pos = pbase + 128 * j;
-            bf16x8 h, l;
+        for (int j = 0; j < C::NT; ++j) {
+            const typename C::Task tk = C::task_of(tb + 128 * j, lead);
+            const int inrow = p.in_w - (ix0 + tk.col);               // pixels of this group that are still inside the image row
+            uint4* dh = &p_h[kgl * PLANE + tk.row * PWD + tk.col];
+            uint4* dl = &p_l[kgl * PLANE + tk.row * PWD + tk.col];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const bool kok = k0 + kgl * 8 + q < p.K;               // only false in a ragged last chunk
-                const float v = kok ? preg[j][q] * sreg[q] : 0.f;
-                const __bf16 hh = (__bf16)v;
-                h[q] = hh;
-                l[q] = (__bf16)(v - (float)hh);
+            for (int i = 0; i < 4; ++i) {
+                bf16x8 h, l;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned raw = i == 0 ? preg[j][q].x : (i == 1 ? preg[j][q].y : (i == 2 ? preg[j][q].z : preg[j][q].w));
+                    const float v = i < inrow ? __uint_as_float(raw) * sc[q] : 0.f;
+                    const __bf16 hh = (__bf16)v;
+                    h[q] = hh;
+                    l[q] = (__bf16)(v - (float)hh);
+                }
+                if (i < tk.used) {
+                    dh[i] = *reinterpret_cast<uint4*>(&h);
+                    dl[i] = *reinterpret_cast<uint4*>(&l);
+                }
             }
-            if (pos < PLANE) {
-                p_h[kgl * PLANE + pos] = *reinterpret_cast<uint4*>(&h);
-                p_l[kgl * PLANE + pos] = *reinterpret_cast<uint4*>(&l);
+        }
+    };
+    auto mfma_phase = [&]() {
+        const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
+        for (int jy = 0; jy < nty; ++jy) {
+            for (int jx = 0; jx < ntx; ++jx) {
+                const int wbase = (jy * ntx + jx) * KG * OCT + aoff;
+                const int pbase = jy * PWD + jx;
+                bf16x8 ah[WOC], al[WOC], bh[WPX], bl[WPX];
+#pragma unroll
+                for (int i = 0; i < WOC; ++i) {
+                    const uint4 uh = wl_h[wbase + i * 32], ul = wl_l[wbase + i * 32];
+                    ah[i] = *reinterpret_cast<const bf16x8*>(&uh);
+                    al[i] = *reinterpret_cast<const bf16x8*>(&ul);
+                }
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) {
+                    const uint4 uh = p_h[pbase + boff[j]], ul = p_l[pbase + boff[j]];
+                    bh[j] = *reinterpret_cast<const bf16x8*>(&uh);
+                    bl[j] = *reinterpret_cast<const bf16x8*>(&ul);
+                }
+#pragma unroll
+                for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                    for (int j = 0; j < WPX; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                    }
+            }
+        }
+    };
+    const float* sob = p.so ? p.so + (size_t)b * p.N : nullptr;
+    // Output through a buffer descriptor as well: lane offset = pixel (+ the hi half's 4 channels), scalar offset = channel
+    // plane; channels >= N and pixels outside the plane fall beyond num_records and are dropped by the hardware.
+    const unsigned oplane = (unsigned)(p.out_h * p.out_w) * 4u;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + (size_t)b * p.N * p.out_h * p.out_w, (unsigned)p.N * oplane);
+    // store one finished tile (demodulation + fused epilogue) and clear the accumulators for the next
+    const EpilogueConsts ec = epilogue_consts(p);
+    auto finish_tile = [&](int tile) {
+        const int qy0 = (tile / p.tiles_x) * TPH, qx0 = (tile % p.tiles_x) * 32;
+        const int n0 = opaque_s(n0_blk);          // recompute the channel offsets here rather than carry 64 of them across the loop
+#pragma unroll
+        for (int j = 0; j < WPX; ++j) {
+            const int qy = qy0 + wave_px * WPX + j, qx = qx0 + l31;
+            const int oy = qy * UP + phy, ox = qx * UP + phx;
+            const bool inside = qy < qh && qx < qw;
+            const unsigned voff = inside ? (unsigned)(oy * p.out_w + ox) * 4u + (unsigned)(4 * hi) * oplane : OOB;
+            const float nz = (p.noise && inside) ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
+#pragma unroll
+            for (int i = 0; i < WOC; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    // a register row holds channel ocs in lanes 0..31 and ocs + 4 in lanes 32..63
+                    const int ocl = (wave_oc * WOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int ocs = n0 + (wave_oc_u * WOC + i) * 32 + (r & 3) + 8 * (r >> 2);
+                    const float v = conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff, (int)((unsigned)ocs * oplane), 0);
+                    acc[i][j][r] = 0.f;
+                }
             }
         }
     };
 
-    if (ntaps > 0) {
-        prefetch(0);
-        commit(0);
+    if (ntaps == 0) {       // a phase no tap reaches: zeros (+ epilogue)
+        for (int tile = tile_begin; tile < tile_end; ++tile) finish_tile(tile);
+        return;
+    }
+    const int nchunks = (p.K + KCB - 1) / KCB;
+    const int items = (tile_end - tile_begin) * nchunks;
+    int tile_n = tile_begin, k0_n = 0;        // cursor of the staging side (prefetch / commit)
+    int tile_c = tile_begin, k0_c = 0;        // cursor of the compute side (MFMA / stores)
+    prefetch(tile_n, k0_n);
+    for (int k = tid; k < ((p.K + KCB - 1) / KCB) * KCB; k += 256) s_si[k] = k < p.K ? (sib ? sib[k] : 1.f) : 0.f;
+    if (tid < OCT) {
+        const int oc = min(n0 + tid, p.N - 1);
+        s_so[tid] = sob ? sob[oc] : 1.f;
+        s_bias[tid] = p.bias ? p.bias[oc] : 0.f;
+    }
+    __syncthreads();
+    commit(tile_n, k0_n);
+    k0_n += KCB; if (k0_n >= p.K) { k0_n = 0; ++tile_n; }
+    __syncthreads();
+    // Steady state.  Every step is unconditional, so no control-flow path reaches the loop header with staged loads
+    // in flight and the compiler plants no wait inside the next prefetch; the last item is peeled below.
+    for (int it = 1; it < items; ++it) {
+        prefetch(tile_n, k0_n);
+        mfma_phase();
         __syncthreads();
-        for (int k0 = 0; k0 < p.K; k0 += KCB) {
-            wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
-            const bool more = k0 + KCB < p.K;
-            if (more) prefetch(k0 + KCB);
-            const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
-            for (int jy = 0; jy < nty; ++jy) {
-                for (int jx = 0; jx < ntx; ++jx) {
-                    const int wbase = (jy * ntx + jx) * KG * OCT + aoff;
-                    const int pbase = jy * PWD + jx;
-                    bf16x8 ah[WOC], al[WOC], bh[WPX], bl[WPX];
-#pragma unroll
-                    for (int i = 0; i < WOC; ++i) {
-                        const uint4 uh = wl_h[wbase + i * 32], ul = wl_l[wbase + i * 32];
-                        ah[i] = *reinterpret_cast<const bf16x8*>(&uh);
-                        al[i] = *reinterpret_cast<const bf16x8*>(&ul);
-                    }
-#pragma unroll
-                    for (int j = 0; j < WPX; ++j) {
-                        const uint4 uh = p_h[pbase + boff[j]], ul = p_l[pbase + boff[j]];
-                        bh[j] = *reinterpret_cast<const bf16x8*>(&uh);
-                        bl[j] = *reinterpret_cast<const bf16x8*>(&ul);
-                    }
-#pragma unroll
-                    for (int i = 0; i < WOC; ++i)
-#pragma unroll
-                        for (int j = 0; j < WPX; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        }
-                }
-            }
-            __syncthreads();
-            if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
-            {
-                commit(k0 + KCB);
-                __syncthreads();
-            }
-        }
+        commit(tile_n, k0_n);                               // retires the loads first: no store is outstanding yet
+        k0_n += KCB; if (k0_n >= p.K) { k0_n = 0; ++tile_n; }
+        if (k0_c + KCB >= p.K) finish_tile(tile_c);         // stores drain while the next MFMA phase runs
+        k0_c += KCB; if (k0_c >= p.K) { k0_c = 0; ++tile_c; }
+        __syncthreads();
     }
-
-    const float* sob = p.so ? p.so + (size_t)b * p.N : nullptr;
-    float* yb = p.y + (size_t)b * p.N * p.out_h * p.out_w;
-#pragma unroll
-    for (int j = 0; j < WPX; ++j) {
-        const int qy = qy0 + wave_px * WPX + j, qx = qx0 + l31;
-        if (qy >= qh || qx >= qw) continue;
-        const int oy = qy * UP + phy, ox = qx * UP + phx;
-#pragma unroll
-        for (int i = 0; i < WOC; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int oc = n0 + (wave_oc * WOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (oc < p.N) {
-                    float v = acc[i][j][r];
-                    if (sob) v *= sob[oc];
-                    yb[((size_t)oc * p.out_h + oy) * p.out_w + ox] = v;
-                }
-            }
-        }
-    }
+    mfma_phase();
+    finish_tile(tile_c);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -738,7 +805,10 @@ struct TCfg {
     static constexpr int NWU = (WUNITS + 255) / 256, NPU = (PLANE + 127) / 128;
 };
 
-template <int WG_OC, int WG_PX, int WPX, int TPW>
+// EPI: 0 = store the accumulators as they are (input-gradient launches), 1 = out_scale only (modulated up-sampling
+// convolution), 2 = the full fused epilogue.  The epilogue is ~6 VALU instructions per output element on 256 elements per
+// lane; compiled out where the launch does not need it (bare stores are 10 % faster at <= 128 input channels).
+template <int WG_OC, int WG_PX, int WPX, int TPW, int EPI>
 __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) {
     using C = TCfg<WG_OC, WG_PX, WPX, TPW>;
     static_assert(WG_OC * WG_PX == 4, "4 waves per workgroup");
@@ -749,6 +819,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     uint4* wl_l = wl_h + C::WUNITS;
     uint4* p_h = wl_l + C::WUNITS;              // [kg][PH][PWD]
     uint4* p_l = p_h + C::PUNITS;
+    __shared__ float s_so[OCT], s_bias[OCT];    // out_scale / bias of this workgroup's channels (see conv_epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -759,6 +830,11 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     const int tile_y = bid % p.tiles_y;
     const int b = bid / p.tiles_y;
     const int n0 = blockIdx.y * OCT;
+    if (EPI > 0 && tid < OCT) {                 // read in the epilogue, many barriers later
+        const int oc = min(n0 + tid, p.N - 1);
+        s_so[tid] = p.so ? p.so[(size_t)b * p.N + oc] : 1.f;
+        s_bias[tid] = p.bias ? p.bias[oc] : 0.f;
+    }
     const int qy0 = tile_y * TQH, qx0 = tile_x * TPW;
 
     f32x16 acc[4][WPX];
@@ -887,8 +963,8 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
         }
     }
 
-    const float* sob = p.so ? p.so + (size_t)b * p.N : nullptr;
     float* yb = p.y + (size_t)b * p.N * p.out_h * p.out_w;
+    const EpilogueConsts ec = epilogue_consts(p);
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         const int qy = qy0 + (wave_px * WPX + j) * RPB + l31 / TPW, qx = qx0 + l31 % TPW;
@@ -896,13 +972,15 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
         for (int ph = 0; ph < 4; ++ph) {
             const int oy = 2 * qy + (ph >> 1), ox = 2 * qx + (ph & 1);
             if (oy >= p.out_h || ox >= p.out_w) continue;
+            const float nz = p.noise ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int oc = n0 + wave_oc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (oc < p.N) {
+                const int ocl = wave_oc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (n0 + ocl < p.N) {
                     float v = acc[ph][j][r];
-                    if (sob) v *= sob[oc];
-                    yb[((size_t)oc * p.out_h + oy) * p.out_w + ox] = v;
+                    if (EPI == 1) v *= s_so[ocl];
+                    if (EPI == 2) v = conv_epilogue(ec, v, s_so[ocl], s_bias[ocl], nz);
+                    yb[((size_t)(n0 + ocl) * p.out_h + oy) * p.out_w + ox] = v;
                 }
             }
         }
@@ -918,7 +996,10 @@ int launch_t(Bf16Args a, hipStream_t s) {
     const long long gx = (long long)a.c.tiles_x * a.c.tiles_y * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
     dim3 grid((unsigned)gx, gc::ceil_div(a.c.N, C::OCT));
-    hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW>), grid, dim3(256), 0, s, a);
+    const int epi = (a.c.bias || a.c.noise || a.c.act) ? 2 : (a.c.so ? 1 : 0);
+    if (epi == 2)      hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 2>), grid, dim3(256), 0, s, a);
+    else if (epi == 1) hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 1>), grid, dim3(256), 0, s, a);
+    else               hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 0>), grid, dim3(256), 0, s, a);
     return gc::check_launch("gc_conv2d_bf16x3_f32(fused transposed)");
 }
 
@@ -936,9 +1017,21 @@ int launch(Bf16Args a, hipStream_t s) {
     const int qh = gc::ceil_div(a.c.out_h, UP), qw = gc::ceil_div(a.c.out_w, UP);
     a.c.tiles_y = gc::ceil_div(qh, C::TPH);
     a.c.tiles_x = gc::ceil_div(qw, 32);
-    const long long gx = (long long)a.c.tiles_x * a.c.tiles_y * UP * UP * a.c.B;
+    const int tiles = a.c.tiles_x * a.c.tiles_y, ocb = gc::ceil_div(a.c.N, C::OCT);
+    // tiles per workgroup: as many as keep >= 8 workgroups per CU-slot pair (2048 on 256 CUs x 2) in the launch, at most 8;
+    // few channel chunks per tile is where the per-tile latencies dominate, many chunks need no help
+    a.tpb = 1;
+    if (UP == 1) {
+        const long long wgs = (long long)tiles * a.c.B * ocb;
+        const int nchunks = gc::ceil_div(a.c.K, KCB);
+        int want = nchunks <= 2 ? 8 : (nchunks <= 4 ? 4 : (nchunks <= 8 ? 2 : 1));
+        while (want > 1 && wgs / want < 2048) want >>= 1;
+        a.tpb = want;
+    }
+    a.groups = gc::ceil_div(tiles, a.tpb);
+    const long long gx = (long long)a.groups * UP * UP * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
-    dim3 grid((unsigned)gx, gc::ceil_div(a.c.N, C::OCT));
+    dim3 grid((unsigned)gx, ocb);
     hipLaunchKernelGGL((conv_bf16x3_kernel<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>), grid, dim3(256), 0, s, a);
     return gc::check_launch("gc_conv2d_bf16x3_f32");
 }
@@ -950,7 +1043,7 @@ int dispatch(const Bf16Args& a, hipStream_t s) {
         if (a.c.N <= 32) return launch<1, 4, 1, 1, UP, DOWN, KS>(a, s);
         return launch<1, 4, 2, 1, UP, DOWN, KS>(a, s);
     } else {
-        if (a.c.N <= 32) return launch<1, 4, 1, 4, UP, DOWN, KS>(a, s);     // 32oc x (16 rows x 32 px)
+        if (a.c.N <= 32) return launch<1, 4, 1, 2, UP, DOWN, KS>(a, s);     // 32oc x (8 rows x 32 px)
         // 64oc x (8 rows x 32 px) unless that leaves most CUs idle (32x32 / 64x64 planes at batch 4): 4-row tiles
         const int qw = gc::ceil_div(a.c.out_w, UP), qh = gc::ceil_div(a.c.out_h, UP);
         const long long big = (long long)gc::ceil_div(qw, 32) * gc::ceil_div(qh, 8) * UP * UP * a.c.B * gc::ceil_div(a.c.N, 64);
@@ -962,7 +1055,13 @@ int dispatch(const Bf16Args& a, hipStream_t s) {
 // shapes the split-bf16 kernel is built for; everything else runs on the exact fp32 kernel
 bool eligible(const gc_conv_desc* d) {
     const int qw = gc::ceil_div(d->out_w, d->up);
-    return d->in_ch >= 16 && qw > 16;
+    if (d->in_ch < 16 || d->in_ch > MAX_K_BF16X3 || qw <= 16) return false;
+    // the staging scheme wants the patch rows to start at most EDGE floats before a 32-float boundary (see BCfg)
+    if (d->up == 1) {
+        const int pwd = 31 * d->down + d->kw, edge = pwd - 32 * (pwd % 32 == 0 ? pwd / 32 : (pwd - 1) / 32);
+        return d->pad_x >= 0 && d->pad_x <= edge;
+    }
+    return d->pad_x >= 1 && d->pad_x <= 2;      // up = 2: phase rows start 0 or 1 floats before the boundary only for these
 }
 
 }  // namespace
@@ -973,14 +1072,15 @@ extern "C" size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d) {
     return 2 * units * sizeof(uint4);
 }
 
-extern "C" int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
-                                    const float* in_scale, const float* out_scale, float* y,
-                                    void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+extern "C" int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
+                                          const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
+                                          void* workspace, size_t workspace_bytes, gc_stream_t stream) {
     int rc = validate(d, "gc_conv2d_bf16x3_f32", false);
     if (rc) return rc;
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_bf16x3_f32: null pointer");
     if (d->batch == 0) return GC_OK;
-    if (!eligible(d)) return gc_conv2d_f32(d, x, w, in_scale, out_scale, y, stream);
+    if ((rc = validate_epilogue(ep, "gc_conv2d_bf16x3_f32"))) return rc;
+    if (!eligible(d)) return gc_conv2d_fused_f32(d, x, w, in_scale, out_scale, ep, y, stream);
     const size_t need = gc_conv2d_bf16x3_workspace(d);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
         return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_bf16x3_f32: workspace %zu < %zu bytes (or not 16-byte aligned)", workspace_bytes, need);
@@ -994,7 +1094,8 @@ extern "C" int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const
     rc = gc::check_launch("gc_conv2d_bf16x3_f32(pack)");
     if (rc) return rc;
     Bf16Args a{{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
-                d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups};
+                d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups, 1, 1};
+    set_epilogue(a.c, ep);
     if (d->kh == 3) {
         if (d->up == 2 && d->pad_y == 2 && d->pad_x == 2) return dispatch_t(a, s);
         if (d->up == 2) return dispatch<2, 1, 3>(a, s);
@@ -1002,6 +1103,12 @@ extern "C" int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const
     }
     if (d->up == 2) return dispatch<2, 1, 1>(a, s);
     return d->down == 2 ? dispatch<1, 2, 1>(a, s) : dispatch<1, 1, 1>(a, s);
+}
+
+extern "C" int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
+                                    const float* in_scale, const float* out_scale, float* y,
+                                    void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    return gc_conv2d_fused_bf16x3_f32(d, x, w, in_scale, out_scale, nullptr, y, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t gc_conv2d_wgrad_bf16x3_workspace(const gc_conv_desc* d) {

@@ -10,7 +10,45 @@ struct ConvArgs {
     const float* x; const float* w; const float* si; const float* so; float* y;
     int B, K, N, in_h, in_w, out_h, out_w, pad_y, pad_x;
     int tiles_x, tiles_y;     // pixel tiles per phase sub-grid (sized for phase 0, the largest)
+    // fused epilogue (gc_conv_epilogue): y = act(so * acc + noise_w * noise[b, pixel] + bias[n])
+    const float* bias; const float* noise; const float* noise_w;
+    float slope, gain; int act;
 };
+
+inline void set_epilogue(ConvArgs& a, const gc_conv_epilogue* ep) {
+    a.bias = ep ? ep->bias : nullptr;
+    a.noise = ep ? ep->noise : nullptr;
+    a.noise_w = ep ? ep->noise_w : nullptr;
+    a.slope = ep ? ep->slope : 1.f;
+    a.gain = ep ? ep->gain : 1.f;
+    a.act = ep ? ep->activate : 0;
+}
+
+inline int validate_epilogue(const gc_conv_epilogue* ep, const char* who) {
+    if (ep && (ep->noise == nullptr) != (ep->noise_w == nullptr))
+        return gc::fail(GC_ERR_BAD_ARG, "%s: epilogue noise and noise_w must both be set or both be null", who);
+    return GC_OK;
+}
+
+// Same arithmetic, in the same order, as bias_act_plane_kernel (bias_act.hip): the fused and the two-pass results are
+// bit-identical.  Everything is a VALUE fetched before the store loop and the function is branch-free:
+//  * so / bias: 1 / 0 when absent; nw = nz = 0 without noise; slope = gain = 1 without activation -- all exact no-ops;
+//  * a vector load between two stores would make the compiler wait for vmcnt(0), i.e. for every store issued so far
+//    (one memory round trip per output row), and a uniform branch per element keeps it from batching the stores.
+struct EpilogueConsts { float nw, slope, gain; };
+__device__ __forceinline__ EpilogueConsts epilogue_consts(const ConvArgs& p) {
+    EpilogueConsts e;
+    e.nw = p.noise ? p.noise_w[0] : 0.f;
+    e.slope = p.act ? p.slope : 1.f;
+    e.gain = p.act ? p.gain : 1.f;
+    return e;
+}
+__device__ __forceinline__ float conv_epilogue(const EpilogueConsts& e, float acc, float so, float bias, float nz) {
+    float v = acc * so;
+    v = fmaf(e.nw, nz, v);
+    v += bias;
+    return (v > 0.f ? v : v * e.slope) * e.gain;
+}
 
 // Taps of one output phase along one axis: tap index t0 + j*up, source offset d0 + j, j < n.
 struct AxisTaps { int t0, n, d0; };
@@ -22,6 +60,13 @@ __device__ __forceinline__ AxisTaps axis_taps(int phase, int pad) {
     a.n = a.t0 < KS ? (KS - a.t0 + UP - 1) / UP : 0;
     a.d0 = gc::floor_div(phase + a.t0 - pad, UP);
     return a;
+}
+
+// The scalar twin: keeps loop-invariant address arithmetic of a per-tile epilogue from being hoisted out of the tile loop
+// (where it would sit in dozens of registers across the MFMA phases and spill).
+__device__ __forceinline__ int opaque_s(int v) {
+    asm volatile("" : "+s"(v));
+    return v;
 }
 
 constexpr int cmax(int a, int b) { return a > b ? a : b; }

@@ -24,6 +24,11 @@ class ConvDesc(ctypes.Structure):
                                     'kh', 'kw', 'up', 'down', 'pad_y', 'pad_x')]
 
 
+class ConvEpilogue(ctypes.Structure):
+    """Mirror of ``gc_conv_epilogue``."""
+    _fields_ = [('bias', _vp), ('noise', _vp), ('noise_w', _vp), ('slope', _f32), ('gain', _f32), ('activate', _i32)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every exported symbol
 SIGNATURES = {
     'gc_abi_version': (_i32, []),
@@ -37,6 +42,8 @@ SIGNATURES = {
     'gc_channel_sum_workspace': (_sz, [_i32, _i32, _i64]),
     'gc_channel_sum_f32': (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _sz, _vp]),
     'gc_conv2d_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
+    'gc_conv2d_fused_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp]),
+    'gc_conv2d_fused_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
     'gc_conv2d_bf16x3_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),

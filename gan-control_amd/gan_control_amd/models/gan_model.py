@@ -16,6 +16,8 @@ import torch
 from torch import nn, autograd
 from torch.nn import functional as F
 
+import os
+_FUSE_EPILOGUE = os.environ.get('GANCONTROL_FUSE_EPILOGUE', '1') != '0'   # debugging knob: 0 = convolution and activation as two launches
 from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix, modulated_conv2d
 
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
@@ -372,16 +374,22 @@ class ConvLayer(nn.Sequential):
         # (upfirdn2d down=2, the same taps at the same positions) and run the 1x1 conv at stride 1 on a quarter
         # of the pixels.  Same values as gan_model.py:844-890, a quarter of the FIR output / conv input traffic.
         self._decimating_fir = downsample and kernel_size == 1
+        self._has_blur, self._activate = downsample, activate
 
     def forward(self, input):
-        if not self._decimating_fir:
-            return super().forward(input)
-        blur, conv = self[0], self[1]
-        out = upfirdn2d(input, blur.kernel, down=conv.stride, pad=blur.pad)
-        out = conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=1, padding=0, weight_scale=conv.scale)
-        for layer in list(self)[2:]:
-            out = layer(out)
-        return out
+        out, idx = input, 0
+        if self._has_blur:
+            blur, idx = self[0], 1
+            out = upfirdn2d(out, blur.kernel, down=2, pad=blur.pad) if self._decimating_fir else blur(out)
+        conv = self[idx]
+        stride = 1 if self._decimating_fir else conv.stride
+        if self._activate and _FUSE_EPILOGUE:
+            # EqualConv2d -> FusedLeakyReLU in one launch: bias + leaky-ReLU run in the convolution's epilogue
+            act = self[idx + 1]
+            return conv2d_gradfix.conv2d_bias_act(out, conv.weight, act.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale,
+                                                  negative_slope=act.negative_slope, scale=act.scale)
+        out = conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale)
+        return self[idx + 1](out) if self._activate else out
 
 
 class ResBlock(nn.Module):

@@ -5,6 +5,7 @@ implementation shipped is ``HipBackend`` (ctypes -> libgancontrol_hip.so).  Test
 emulation of the same interface to validate the autograd wiring on machines without a GPU;
 the product never does.
 """
+import ctypes
 import os
 from collections import namedtuple
 
@@ -125,7 +126,6 @@ class HipBackend:
 
     def weight_layout(self, src, taps, k, n, src_stride, dst_shape, dst_stride, flip, scale):
         """dst[t',k,n] = scale * src[t,k,n] between two strided weight layouts; see gc_weight_layout_f32."""
-        import ctypes
         dev = _lib.require_cuda_f32(src)
         dst = torch.empty(dst_shape, dtype=src.dtype, device=dev)
         if dst.numel() != taps * k * n or src.numel() != taps * k * n:
@@ -167,8 +167,11 @@ class HipBackend:
         b, k, h, w = x.shape
         return _lib.ConvDesc(b, k, n_out, h, w, geom.out_h, geom.out_w, geom.kh, geom.kw, geom.up, geom.down, geom.pad_y, geom.pad_x)
 
-    def conv2d(self, x, w_t, in_scale, out_scale, geom):
-        """x [B,K,H,W], w_t [kh,kw,K,N] -> [B,N,out_h,out_w]; see gc_conv2d_f32."""
+    def conv2d(self, x, w_t, in_scale, out_scale, geom, epilogue=None):
+        """x [B,K,H,W], w_t [kh,kw,K,N] -> [B,N,out_h,out_w]; see gc_conv2d_fused_f32.
+
+        epilogue = (bias [N] | None, noise [B,1,oh,ow] | None, noise_w [1] | None, slope, gain, activate) or None.
+        """
         dev = _lib.require_cuda_f32(x, w_t, in_scale, out_scale)
         n_out = w_t.shape[3]
         y = torch.empty((x.shape[0], n_out, geom.out_h, geom.out_w), dtype=x.dtype, device=dev)
@@ -176,6 +179,15 @@ class HipBackend:
             return y
         desc = self._desc(x, n_out, geom)
         lib = _lib.load()
+        ep = None
+        if epilogue is not None:
+            bias, noise, noise_w, slope, gain, activate = epilogue
+            _lib.require_cuda_f32(x, bias, noise, noise_w)
+            if bias is not None and bias.numel() != n_out:
+                raise RuntimeError('conv2d epilogue: bias has %d elements, expected %d' % (bias.numel(), n_out))
+            if noise is not None and noise.numel() != x.shape[0] * geom.out_h * geom.out_w:
+                raise RuntimeError('conv2d epilogue: noise has %d elements, expected %d' % (noise.numel(), x.shape[0] * geom.out_h * geom.out_w))
+            ep = ctypes.byref(_lib.ConvEpilogue(_lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), float(slope), float(gain), int(bool(activate))))
         ws = None
         if self.conv_mode == 'bf16x3':
             nbytes = lib.gc_conv2d_bf16x3_workspace(desc)
@@ -187,13 +199,13 @@ class HipBackend:
         if g: g.__enter__()
         try:
             if ws is None:
-                rc = lib.gc_conv2d_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(y), _lib.stream_of(x))
+                rc = lib.gc_conv2d_fused_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y), _lib.stream_of(x))
             else:
-                rc = lib.gc_conv2d_bf16x3_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(y),
-                                              _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
+                rc = lib.gc_conv2d_fused_bf16x3_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y),
+                                                    _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
         finally:
             if g: g.__exit__(None, None, None)
-        _lib.check(rc, 'gc_conv2d_f32')
+        _lib.check(rc, 'gc_conv2d_fused_f32')
         if t0 is not None:
             from ...utils.profiling import conv_variant, conv_flops
             self.timer.stop(conv_variant(geom, n_out, x.shape[0], x.shape[1], self.conv_mode), t0, conv_flops(x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom))

@@ -79,6 +79,40 @@ class _WGrad(Function):
         return gx, ggy, None
 
 
+class _GConvAct(Function):
+    """out = gain * lrelu(gconv(x, w_t) + bias): the activation runs in the convolution's epilogue (gc_conv_epilogue), so
+    the pre-activation tensor is never written.  Backward = FusedLeakyReLU's (mask from the sign of the OUTPUT, bias
+    gradient reduced in the same pass) followed by _GConv's; every piece is a differentiable Function, so R1 closes."""
+
+    @staticmethod
+    def forward(ctx, x, w_t, bias, geom, slope, gain):
+        out = _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None, None, geom, epilogue=(bias, None, None, slope, gain, True))
+        ctx.geom, ctx.cfg = geom, (slope, gain)
+        ctx.in_hw = (x.shape[2], x.shape[3])
+        ctx.save_for_backward(x, w_t, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .fused_act import _BiasActGrad, _BiasActGradReduce
+        x, w_t, out = ctx.saved_tensors
+        g = ctx.geom
+        slope, gain = ctx.cfg
+        gx = gw = gb = None
+        if not any(ctx.needs_input_grad[:3]):
+            return None, None, None, None, None, None
+        if ctx.needs_input_grad[2]:
+            g_pre, psum, _ = _BiasActGradReduce.apply(gy, out, None, slope, gain)
+            gb = psum.sum((0, 2))
+        else:
+            g_pre = _BiasActGrad.apply(gy, out, slope, gain)
+        if ctx.needs_input_grad[0]:
+            gx = _GConv.apply(g_pre, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw))
+        if ctx.needs_input_grad[1]:
+            gw = _weight_grad(x, g_pre, g)
+        return gx, gw, gb, None, None, None
+
+
 def _pair(v):
     return (int(v), int(v)) if not isinstance(v, (tuple, list)) else (int(v[0]), int(v[1]))
 
@@ -118,6 +152,21 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
         raise ValueError(f'conv2d: weight expects {weight.shape[1]} input channels, got {input.shape[1]}')
     y = conv2d_t(input, kernel_layout(weight, weight_scale), s, p)
     return y if bias is None else y + bias.reshape(1, -1, 1, 1)
+
+
+def conv2d_bias_act(input, weight, bias, stride=1, padding=0, weight_scale=1.0, negative_slope=0.2, scale=2 ** 0.5):
+    """scale * leaky_relu(conv2d(input, weight * weight_scale) + bias): EqualConv2d -> FusedLeakyReLU (ConvLayer,
+    gan_model.py:844-890) as ONE kernel launch."""
+    s, p = _check(input, weight, stride, padding, 1, 1)
+    if weight.shape[1] != input.shape[1]:
+        raise ValueError(f'conv2d: weight expects {weight.shape[1]} input channels, got {input.shape[1]}')
+    if bias.numel() != weight.shape[0]:
+        raise ValueError(f'conv2d_bias_act: bias has {bias.numel()} elements, weight has {weight.shape[0]} output channels')
+    kh, kw = weight.shape[2], weight.shape[3]
+    oh = (input.shape[2] + 2 * p - kh) // s + 1
+    ow = (input.shape[3] + 2 * p - kw) // s + 1
+    return _GConvAct.apply(input, kernel_layout(weight, weight_scale), bias.reshape(-1).contiguous(),
+                           ConvGeom(kh, kw, 1, s, p, p, oh, ow), float(negative_slope), float(scale))
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, weight_scale=1.0):

@@ -132,6 +132,27 @@ typedef struct gc_conv_desc {
 int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,
                   const float* in_scale, const float* out_scale, float* y, gc_stream_t stream);
 
+/* Fused epilogue: the (noise +) bias + leaky-ReLU pass K2 that follows every convolution of the path (EqualConv2d ->
+ * FusedLeakyReLU in ConvLayer gan_model.py:844-890; ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU in StyledConv
+ * gan_model.py:402-408; `+ self.bias` in ToRGB gan_model.py:430) applied to the accumulators before they are stored:
+ *
+ *   y[b,n,o] = A( out_scale[b,n] * sum(...) + noise_w[0] * noise[b,o] + bias[n] ),  A(v) = activate ? gain * lrelu(v, slope) : v
+ *
+ * with the arithmetic of gc_bias_act_f32 in the same order, so conv + epilogue equals gc_conv2d_f32 followed by
+ * gc_bias_act_f32 bit for bit while saving one write and one read of the activation tensor.  ep == NULL: plain convolution.
+ */
+typedef struct gc_conv_epilogue {
+    const float* bias;     /* [out_ch] or NULL */
+    const float* noise;    /* [batch, out_h * out_w] or NULL */
+    const float* noise_w;  /* DEVICE scalar; set exactly when noise is */
+    float slope, gain;     /* used when activate != 0 */
+    int32_t activate;
+} gc_conv_epilogue;
+
+int gc_conv2d_fused_f32(const gc_conv_desc* d, const float* x, const float* w,
+                        const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep,
+                        float* y, gc_stream_t stream);
+
 /* The same contraction on the bf16 matrix cores with split-bf16 ("bf16x3") arithmetic: every fp32
  * operand is split into bf16 hi + lo parts and a*b is formed as hi*hi + hi*lo + lo*hi with fp32
  * accumulation (~5e-6 relative error per layer, 5.3x the fp32 MFMA rate).  Inputs and outputs stay
@@ -142,6 +163,10 @@ size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d);
 int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
                          const float* in_scale, const float* out_scale, float* y,
                          void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
+int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
+                               const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
+                               void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
 /* Weight gradient of the same contraction (up must be 1):
  *

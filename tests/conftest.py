@@ -108,7 +108,7 @@ class EmulatedBackend:
         torch.as_strided(dst.reshape(-1), (taps, k, n), tuple(dst_stride)).copy_(view * scale)
         return dst
 
-    def conv2d(self, x, w_t, in_scale, out_scale, geom):
+    def conv2d(self, x, w_t, in_scale, out_scale, geom, epilogue=None):
         if in_scale is not None:
             x = x * in_scale[:, :, None, None]
         u = self._stuff_pad(x, geom.up, geom.pad_y, geom.pad_x, (geom.out_h - 1) * geom.down + geom.kh,
@@ -117,6 +117,14 @@ class EmulatedBackend:
         assert y.shape[2:] == (geom.out_h, geom.out_w)
         if out_scale is not None:
             y = y * out_scale[:, :, None, None]
+        if epilogue is not None:
+            bias, noise, noise_w, slope, gain, activate = epilogue
+            if noise is not None:
+                y = y + noise_w * noise.reshape(y.shape[0], 1, *y.shape[2:])
+            if bias is not None:
+                y = y + bias.reshape(1, -1, 1, 1)
+            if activate:
+                y = F.leaky_relu(y, slope) * gain
         return y
 
     def conv2d_wgrad(self, x, dy, in_scale, out_scale, geom):

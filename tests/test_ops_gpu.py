@@ -295,6 +295,67 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
             assert rel_err(out, ref) < 5e-5, ('wgrad', use_scales)
 
 
+EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3][::2]
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
+@pytest.mark.parametrize('case', EPILOGUE_CASES)
+def test_conv2d_fused_epilogue(case, mode):
+    """gc_conv2d_fused_*: (noise +) bias + leaky-ReLU in the convolution epilogue == convolution followed by gc_bias_act_f32, bit for bit."""
+    from gan_control_amd.models.op._backend import ConvGeom
+    hip, emu = _be()
+    prev, hip.conv_mode = hip.conv_mode, mode
+    try:
+        b, K, N, h, w, k, up, down, pad = case
+        gen = torch.Generator().manual_seed(hash(case) & 0xFFF)
+        x = torch.randn(b, K, h, w, generator=gen).to(DEV)
+        wt = torch.randn(k, k, K, N, generator=gen).to(DEV)
+        si, so = torch.randn(b, K, generator=gen).to(DEV), (torch.rand(b, N, generator=gen) + 0.5).to(DEV)
+        oh, ow = _out_size(h, k, up, down, pad, up > 1), _out_size(w, k, up, down, pad, up > 1)
+        geom = ConvGeom(k, k, up, down, pad, pad, oh, ow)
+        bias = torch.randn(N, generator=gen).to(DEV)
+        nz, nw = torch.randn(b, 1, oh, ow, generator=gen).to(DEV), torch.randn(1, generator=gen).to(DEV)
+        for scales in ((None, None), (si, so)):
+            plain = hip.conv2d(x, wt, *scales, geom)
+            fused = hip.conv2d(x, wt, *scales, geom, epilogue=(bias, None, None, 0.2, 2 ** 0.5, True))
+            assert torch.equal(fused, hip.bias_act(plain, bias, None, None, 0.2, 2 ** 0.5))
+            fused = hip.conv2d(x, wt, *scales, geom, epilogue=(bias, nz, nw, 0.2, 2 ** 0.5, True))
+            assert torch.equal(fused, hip.bias_act(plain, bias, nz, nw, 0.2, 2 ** 0.5))
+            fused = hip.conv2d(x, wt, *scales, geom, epilogue=(bias, None, None, 1.0, 1.0, False))
+            assert torch.equal(fused, plain + bias.reshape(1, -1, 1, 1))
+            fused = hip.conv2d(x, wt, *scales, geom, epilogue=(None, None, None, 0.2, 2 ** 0.5, True))
+            assert torch.equal(fused, hip.bias_act(plain, None, None, None, 0.2, 2 ** 0.5))
+        # against the independent emulation in fp64
+        ref = emu.conv2d(x.cpu().double(), wt.cpu().double(), si.cpu().double(), so.cpu().double(), geom,
+                         epilogue=(bias.cpu().double(), nz.cpu().double(), nw.cpu().double(), 0.2, 2 ** 0.5, True))
+        out = hip.conv2d(x, wt, si, so, geom, epilogue=(bias, nz, nw, 0.2, 2 ** 0.5, True))
+        assert rel_err(out, ref) < (5e-6 if mode == 'f32' else 5e-5)
+    finally:
+        hip.conv_mode = prev
+
+
+def test_conv2d_bias_act_autograd_matches_two_pass():
+    """conv2d_bias_act (one launch) and conv2d -> fused_leaky_relu (two) give the same values and first / second-order gradients."""
+    from gan_control_amd.models.op import conv2d_gradfix, fused_leaky_relu
+    gen = torch.Generator().manual_seed(11)
+    x = torch.randn(2, 24, 33, 40, generator=gen).to(DEV).requires_grad_(True)
+    w = torch.randn(40, 24, 3, 3, generator=gen).to(DEV).requires_grad_(True)
+    b = torch.randn(40, generator=gen).to(DEV).requires_grad_(True)
+    for stride, pad in [(1, 1), (2, 0)]:
+        outs = []
+        for fused in (True, False):
+            if fused:
+                y = conv2d_gradfix.conv2d_bias_act(x, w, b, stride=stride, padding=pad, weight_scale=0.1)
+            else:
+                y = fused_leaky_relu(conv2d_gradfix.conv2d(x, w, stride=stride, padding=pad, weight_scale=0.1), b)
+            g1 = torch.autograd.grad(y.square().mean(), [x, w, b], retain_graph=True)
+            gx, = torch.autograd.grad(y.sum() + (y * y).sum(), x, create_graph=True)
+            g2 = torch.autograd.grad(gx.pow(2).sum(), [x, w, b])
+            outs.append([y.detach(), gx.detach(), *g1, *g2])
+        for a, c in zip(*outs):
+            assert rel_err(a, c) < 1e-5
+
+
 @pytest.mark.parametrize('size', [64, 256])
 def test_network_golden_bf16x3(size, bf16x3_mode):
     oc.check_network(size, DEV)
