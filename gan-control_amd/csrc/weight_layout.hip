@@ -9,61 +9,116 @@
 //     dst[t' * dt + k * dk + n * dn] = scale * src[t * st + k * sk + n * sn],   t' = flip ? T - 1 - t : t
 //
 // A workgroup moves a 32(k) x 32(n) x (<= 9 taps) tile through LDS: it is read in the memory order of `src` and written
-// in the memory order of `dst`, so both sides are coalesced whatever the two layouts are.
+// in the memory order of `dst`, so both sides are coalesced.  The layout pairs the model uses are compiled with constant
+// index arithmetic (weight_layout_kernel<read order, write order, taps>); anything else takes a plain gather kernel.
 #include <algorithm>
 
 #include "common.h"
 
 namespace {
 
-constexpr int TILE = 32, TAPS = 9, PITCH = TILE + 1;
+constexpr int TILE = 32;
 
 struct LayoutArgs {
     const float* src; float* dst;
     int T, K, N;
     long long st, sk, sn, dt, dk, dn;
-    int r0, r1, r2;     // axis ids (0 = tap, 1 = k, 2 = n) of the read phase, slowest -> fastest in src memory
-    int w0, w1, w2;     // same for the write phase / dst memory
     int flip; float scale;
 };
 
-__device__ __forceinline__ int pick(int which, int a, int b, int c) { return which == 0 ? a : (which == 1 ? b : c); }
+// Memory order of a layout, slowest -> fastest axis (t = tap, k, n).  The four orders the model needs:
+//   NKT  parameter [N,K,taps]           KNT  conv_transpose2d parameter [K,N,taps]
+//   TKN  kernel layout [taps,K,N]       TNK  input-gradient layout [taps,N,K]
+enum Order { NKT = 0, KNT = 1, TKN = 2, TNK = 3 };
 
+// Coordinates (t, k, n) of the e-th element of a full 32 x 32 x TT tile walked in memory order ORD (constant divisors only).
+template <int ORD, int TT>
+__device__ __forceinline__ void decode(int e, int& t, int& k, int& n) {
+    if (ORD == NKT) { t = e % TT; k = (e / TT) % TILE; n = e / (TT * TILE); }
+    if (ORD == KNT) { t = e % TT; n = (e / TT) % TILE; k = e / (TT * TILE); }
+    if (ORD == TKN) { n = e % TILE; k = (e / TILE) % TILE; t = e / (TILE * TILE); }
+    if (ORD == TNK) { k = e % TILE; n = (e / TILE) % TILE; t = e / (TILE * TILE); }
+}
+
+// The tile sits in LDS in the READ order, with odd strides for the middle and slow axes so that the write phase -- whose
+// lanes run along a different axis -- is bank-conflict free as well.
+template <int ORD, int TT>
+struct TileLds {
+    static constexpr int FAST = (ORD == NKT || ORD == KNT) ? TT : TILE;
+    static constexpr int MID = TILE;
+    static constexpr int SLOW = (ORD == NKT || ORD == KNT) ? TILE : TT;
+    static constexpr int MIDS = FAST | 1;
+    static constexpr int SLOWS = (MID * MIDS) | 1;
+    static constexpr int SIZE = SLOW * SLOWS;
+    __device__ static __forceinline__ int at(int t, int k, int n) {
+        if (ORD == NKT) return n * SLOWS + k * MIDS + t;
+        if (ORD == KNT) return k * SLOWS + n * MIDS + t;
+        if (ORD == TKN) return t * SLOWS + k * MIDS + n;
+        return t * SLOWS + n * MIDS + k;
+    }
+};
+
+template <int RORD, int WORD, int TT>
 __global__ __launch_bounds__(256) void weight_layout_kernel(LayoutArgs a) {
-    __shared__ float tile[TAPS * TILE * PITCH];
-    const int k0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE, t0 = blockIdx.z * TAPS;
-    const int ke = min(TILE, a.K - k0), ne = min(TILE, a.N - n0), te = min(TAPS, a.T - t0);
-    const int total = te * ke * ne;
-    {
-        const int e1 = pick(a.r1, te, ke, ne), e2 = pick(a.r2, te, ke, ne);
-        for (int e = threadIdx.x; e < total; e += 256) {
-            const int c2 = e % e2, r = e / e2, c1 = r % e1, c0 = r / e1;
-            // coordinate of axis X = the c_i whose r_i == X
-            const int t = a.r0 == 0 ? c0 : (a.r1 == 0 ? c1 : c2);
-            const int k = a.r0 == 1 ? c0 : (a.r1 == 1 ? c1 : c2);
-            const int n = a.r0 == 2 ? c0 : (a.r1 == 2 ? c1 : c2);
-            tile[(t * TILE + k) * PITCH + n] = a.src[(t0 + t) * a.st + (k0 + k) * a.sk + (n0 + n) * a.sn];
-        }
+    using L = TileLds<RORD, TT>;
+    __shared__ float tile[L::SIZE];
+    const int k0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE, t0 = blockIdx.z * TT;
+    const int ke = min(TILE, a.K - k0), ne = min(TILE, a.N - n0), te = min(TT, a.T - t0);
+    constexpr int TOTAL = TT * TILE * TILE, PER = TOTAL / 256;
+    // all loads of the lane first (36 in flight for 3x3 taps): a weight tensor is at most a few hundred tiles, so the
+    // launch has no other parallelism to hide the memory latency with
+    float v[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int t, k, n;
+        decode<RORD, TT>(threadIdx.x + 256 * i, t, k, n);
+        v[i] = (t < te && k < ke && n < ne) ? a.src[(t0 + t) * a.st + (k0 + k) * a.sk + (n0 + n) * a.sn] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int t, k, n;
+        decode<RORD, TT>(threadIdx.x + 256 * i, t, k, n);
+        tile[L::at(t, k, n)] = v[i];
     }
     __syncthreads();
-    {
-        const int e1 = pick(a.w1, te, ke, ne), e2 = pick(a.w2, te, ke, ne);
-        for (int e = threadIdx.x; e < total; e += 256) {
-            const int c2 = e % e2, r = e / e2, c1 = r % e1, c0 = r / e1;
-            const int t = a.w0 == 0 ? c0 : (a.w1 == 0 ? c1 : c2);
-            const int k = a.w0 == 1 ? c0 : (a.w1 == 1 ? c1 : c2);
-            const int n = a.w0 == 2 ? c0 : (a.w1 == 2 ? c1 : c2);
+#pragma unroll 4
+    for (int e = threadIdx.x; e < TOTAL; e += 256) {
+        int t, k, n;
+        decode<WORD, TT>(e, t, k, n);
+        if (t < te && k < ke && n < ne) {
             const int td = a.flip ? a.T - 1 - (t0 + t) : t0 + t;
-            a.dst[td * a.dt + (k0 + k) * a.dk + (n0 + n) * a.dn] = a.scale * tile[(t * TILE + k) * PITCH + n];
+            a.dst[td * a.dt + (k0 + k) * a.dk + (n0 + n) * a.dn] = a.scale * tile[L::at(t, k, n)];
         }
     }
 }
 
-// axis ids sorted by stride, largest first (ties: keep tap, k, n order -- extents of 1 make the stride irrelevant)
-void memory_order(const int64_t s[3], int out[3]) {
-    int idx[3] = {0, 1, 2};
-    std::stable_sort(idx, idx + 3, [&](int x, int y) { return s[x] > s[y]; });
-    out[0] = idx[0]; out[1] = idx[1]; out[2] = idx[2];
+// any other pair of layouts: one element per lane, gathered reads (correct for every stride triple, not fast)
+__global__ __launch_bounds__(256) void weight_layout_generic_kernel(LayoutArgs a) {
+    const long long total = (long long)a.T * a.K * a.N;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const int n = (int)(e % a.N);
+        const long long r = e / a.N;
+        const int k = (int)(r % a.K), t = (int)(r / a.K);
+        const int td = a.flip ? a.T - 1 - t : t;
+        a.dst[td * a.dt + k * a.dk + n * a.dn] = a.scale * a.src[t * a.st + k * a.sk + n * a.sn];
+    }
+}
+
+// which of the four orders a stride triple is (for extents > 1); -1 if none
+int order_of(const int64_t s[3], int T, int K, int N) {
+    const int64_t t = s[0], k = s[1], n = s[2];
+    if (t == 1 && k == T && n == (int64_t)K * T) return NKT;
+    if (t == 1 && n == T && k == (int64_t)N * T) return KNT;
+    if (n == 1 && k == N && t == (int64_t)K * N) return TKN;
+    if (k == 1 && n == K && t == (int64_t)N * K) return TNK;
+    return -1;
+}
+
+template <int RORD, int WORD>
+void launch_tt(const LayoutArgs& a, hipStream_t s) {
+    dim3 grid(gc::ceil_div(a.K, TILE), gc::ceil_div(a.N, TILE), a.T == 1 ? 1 : gc::ceil_div(a.T, 9));
+    if (a.T == 1) hipLaunchKernelGGL((weight_layout_kernel<RORD, WORD, 1>), grid, dim3(256), 0, s, a);
+    else          hipLaunchKernelGGL((weight_layout_kernel<RORD, WORD, 9>), grid, dim3(256), 0, s, a);
 }
 
 }  // namespace
@@ -75,18 +130,22 @@ extern "C" int gc_weight_layout_f32(const float* src, float* dst, int taps, int 
     if (taps <= 0 || k <= 0 || n <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_weight_layout_f32: non-positive extent");
     for (int i = 0; i < 3; ++i)
         if (src_stride[i] < 0 || dst_stride[i] < 0) return gc::fail(GC_ERR_BAD_ARG, "gc_weight_layout_f32: negative stride");
-    if (gc::ceil_div(n, TILE) > 65535 || gc::ceil_div(taps, TAPS) > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_weight_layout_f32: extent too large");
+    if (gc::ceil_div(n, TILE) > 65535 || gc::ceil_div(taps, 9) > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_weight_layout_f32: extent too large");
     LayoutArgs a;
     a.src = src; a.dst = dst; a.T = taps; a.K = k; a.N = n;
     a.st = src_stride[0]; a.sk = src_stride[1]; a.sn = src_stride[2];
     a.dt = dst_stride[0]; a.dk = dst_stride[1]; a.dn = dst_stride[2];
-    int r[3], w[3];
-    memory_order(src_stride, r);
-    memory_order(dst_stride, w);
-    a.r0 = r[0]; a.r1 = r[1]; a.r2 = r[2];
-    a.w0 = w[0]; a.w1 = w[1]; a.w2 = w[2];
     a.flip = flip_taps ? 1 : 0; a.scale = scale;
-    dim3 grid(gc::ceil_div(k, TILE), gc::ceil_div(n, TILE), gc::ceil_div(taps, TAPS));
-    hipLaunchKernelGGL(weight_layout_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t s = (hipStream_t)stream;
+    const int ro = order_of(src_stride, taps, k, n), wo = order_of(dst_stride, taps, k, n);
+    if (ro == NKT && wo == TKN)      launch_tt<NKT, TKN>(a, s);     // parameter -> kernel layout
+    else if (ro == KNT && wo == TKN) launch_tt<KNT, TKN>(a, s);     // conv_transpose2d parameter -> kernel layout
+    else if (ro == TKN && wo == TNK) launch_tt<TKN, TNK>(a, s);     // kernel layout -> input-gradient weights
+    else if (ro == TKN && wo == NKT) launch_tt<TKN, NKT>(a, s);     // weight gradient -> parameter layout
+    else if (ro == TKN && wo == KNT) launch_tt<TKN, KNT>(a, s);
+    else {
+        const long long total = (long long)taps * k * n;
+        hipLaunchKernelGGL(weight_layout_generic_kernel, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, s, a);
+    }
     return gc::check_launch("gc_weight_layout_f32");
 }
