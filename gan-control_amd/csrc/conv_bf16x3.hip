@@ -370,7 +370,7 @@ struct WgCfg {
 };
 
 template <int WK, int WN, int WP, int TR, int KS>
-__global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
+__global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
     using C = WgCfg<WK, WN, WP, TR, KS>;
     static_assert(WK * WN * WP == 4, "4 waves per workgroup");
     static_assert((2 * TR) % WP == 0, "pixel steps split evenly over the pixel waves");
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_kernel(WgArgs p) {
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
             if (more) prefetch(tile + 1);
-#pragma unroll
+#pragma unroll 1
             for (int step = 0; step < 2 * TR / WP; ++step) {
                 {
                     const int sidx = step * WP + wp;            // this wave's pixel step: row r, half-row st
@@ -594,8 +594,10 @@ struct WgS2Cfg {
     static constexpr int NT = KS * KS;
 };
 
+// TR = 2: 110 KB of LDS, one workgroup per CU with the whole register file; TR = 1: 64 KB, two per CU (the second hides the
+// staging phases of the first, but every input row is fetched 3 instead of 2.5 times): better on planes <= 128 wide.
 template <int TR, int KS>
-__global__ __launch_bounds__(256, 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
+__global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
     using C = WgS2Cfg<TR, KS>;
     constexpr int KT = C::KT, NTL = C::NTL, PH = C::PH, XE = C::XE, RU = C::RU, YU = C::YU, NI = C::NI, NT = C::NT;
     __shared__ uint4 smem[C::SMEM_UNITS];
@@ -712,9 +714,9 @@ __global__ __launch_bounds__(256, 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
             if (more) prefetch(tile + 1);
-#pragma unroll
+#pragma unroll (TR == 1 ? 1 : 2)
             for (int r = 0; r < TR; ++r) {
-#pragma unroll
+#pragma unroll (TR == 1 ? 1 : 2)
                 for (int st = 0; st < 2; ++st) {
                     const uint4 ubh = yh[yb_ + r * YU + 2 * st], ubl = yl[yb_ + r * YU + 2 * st];
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&ubh), bl = *reinterpret_cast<const bf16x8*>(&ubl);
@@ -770,6 +772,7 @@ WgPlan plan_wg(const gc_conv_desc* d) {
     pl.small = d->down == 1 && !(d->in_ch >= 64 && d->out_ch >= 64);
     pl.ct = pl.small ? 32 : 64;
     pl.tr = pl.small ? 4 : 2;
+    if (d->down == 2 && d->out_w <= 128) pl.tr = 1;     // stride 2, small planes: one output row per tile, two workgroups per CU
     pl.tiles_x = gc::ceil_div(d->out_w, 32);
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
@@ -1137,8 +1140,13 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
              d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
     dim3 grid(gc::ceil_div(d->in_ch, pl.ct), gc::ceil_div(d->out_ch, pl.ct), pl.splits);
     if (d->down == 2) {
-        if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 3>), grid, dim3(256), 0, s, a);
-        else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 1>), grid, dim3(256), 0, s, a);
+        if (pl.tr == 1) {
+            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 3>), grid, dim3(256), 0, s, a);
+            else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 1>), grid, dim3(256), 0, s, a);
+        } else {
+            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 3>), grid, dim3(256), 0, s, a);
+            else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 1>), grid, dim3(256), 0, s, a);
+        }
     } else if (pl.small) {
         if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 4, 3>), grid, dim3(256), 0, s, a);
         else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 4, 1>), grid, dim3(256), 0, s, a);
