@@ -176,13 +176,16 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
         }
     };
 
+    // channel range of this workgroup (the whole of K unless the launch splits it over blockIdx.z)
+    const int kz0 = p.k_per_split ? blockIdx.z * p.k_per_split : 0;
+    const int kz1 = p.k_per_split ? min(p.K, kz0 + p.k_per_split) : p.K;
     if (ntaps > 0) {
-        prefetch(0);
+        prefetch(kz0);
         commit();
         __syncthreads();
-        for (int k0 = 0; k0 < p.K; k0 += KC) {
+        for (int k0 = kz0; k0 < kz1; k0 += KC) {
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
-            const bool more = k0 + KC < p.K;
+            const bool more = k0 + KC < kz1;
             if (more) prefetch(k0 + KC);
             // ---- MFMA over taps x channel pairs ----
             const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
@@ -239,8 +242,8 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
     }
 
     // ---- epilogue: demodulate and store; lanes 0..31 of a register are consecutive pixels ----
-    float* yb = p.y + (size_t)b * p.N * p.out_h * p.out_w;
-    const EpilogueConsts ec = epilogue_consts(p);
+    float* yb = (p.k_per_split ? p.part + (size_t)blockIdx.z * p.B * p.N * p.out_h * p.out_w : p.y) + (size_t)b * p.N * p.out_h * p.out_w;
+    const EpilogueConsts ec = epilogue_consts(p);        // identity for a split launch (the host clears the epilogue fields)
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         const int qy = qy0 + (wave_px * WPX + j) * RPB + l31 / TPW, qx = qx0 + l31 % TPW;
@@ -494,9 +497,43 @@ int launch_conv(ConvArgs a, hipStream_t s) {
     a.tiles_x = gc::ceil_div(qw, TPW);
     const long long gx = (long long)a.tiles_x * a.tiles_y * UP * UP * a.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_f32: grid too large");
-    dim3 grid((unsigned)gx, gc::ceil_div(a.N, C::OCT));
+    const int slices = a.k_per_split ? gc::ceil_div(a.K, a.k_per_split) : 1;
+    dim3 grid((unsigned)gx, gc::ceil_div(a.N, C::OCT), slices);
     hipLaunchKernelGGL((conv_mfma_kernel<WG_OC, WG_PX, KSPLIT, KCT, WOC, WPX, TPW, UP, DOWN, KS>), grid, dim3(256), 0, s, a);
     return gc::check_launch("gc_conv2d_f32");
+}
+
+// Planes up to 16 pixels wide (the 4x4 .. 16x16 layers, 512 channels): a launch has only B * N / 32 workgroups, each
+// walking all of K chunk by chunk with nothing to hide the load latency behind -- 70..120 us for a few GFLOP.  Splitting K
+// over blockIdx.z fills the chip and shortens the dependent chain; the slices are summed in a fixed order by
+// splitk_finish_kernel, which also applies out_scale and the fused epilogue.
+struct SplitPlan { int slices, k_per_split; };
+SplitPlan plan_splitk(const gc_conv_desc* d) {
+    SplitPlan sp{1, 0};
+    const int qw = gc::ceil_div(d->out_w, d->up), qh = gc::ceil_div(d->out_h, d->up);
+    if (qw > 16 || d->in_ch < 128) return sp;
+    const int tpw = qw <= 4 ? 4 : (qw <= 8 ? 8 : 16), rows = 32 / tpw;
+    const long long wgs = (long long)gc::ceil_div(qw, tpw) * gc::ceil_div(qh, rows) * d->up * d->up * d->batch * gc::ceil_div(d->out_ch, 32);
+    int want = (int)std::min<long long>(std::max<long long>(512 / std::max<long long>(wgs, 1), 1), d->in_ch / 64);
+    if (want <= 1) return sp;
+    sp.k_per_split = gc::ceil_div(gc::ceil_div(d->in_ch, want), 32) * 32;
+    sp.slices = gc::ceil_div(d->in_ch, sp.k_per_split);
+    if (sp.slices <= 1) { sp.slices = 1; sp.k_per_split = 0; }
+    return sp;
+}
+
+__global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p, int slices, long long per_slice) {
+    const EpilogueConsts ec = epilogue_consts(p);
+    const long long plane = (long long)p.out_h * p.out_w;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_slice; i += (long long)gridDim.x * 256) {
+        float acc = 0.f;
+        for (int z = 0; z < slices; ++z) acc += p.part[z * per_slice + i];
+        const long long bn = i / plane, o = i - bn * plane;
+        const int n = (int)(bn % p.N), b = (int)(bn / p.N);
+        const float so = p.so ? p.so[(size_t)b * p.N + n] : 1.f, bias = p.bias ? p.bias[n] : 0.f;
+        const float nz = p.noise ? p.noise[(size_t)b * plane + o] : 0.f;
+        p.y[i] = conv_epilogue(ec, acc, so, bias, nz);
+    }
 }
 
 // tile configuration: by phase sub-grid width, output channels and how many workgroups result
@@ -557,9 +594,14 @@ int dispatch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
 
 }  // namespace
 
-extern "C" int gc_conv2d_fused_f32(const gc_conv_desc* d, const float* x, const float* w,
-                                   const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep,
-                                   float* y, gc_stream_t stream) {
+size_t gcconv::conv2d_f32_workspace(const gc_conv_desc* d) {
+    if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->up <= 0) return 0;
+    const SplitPlan sp = plan_splitk(d);
+    return sp.slices > 1 ? (size_t)sp.slices * d->batch * d->out_ch * d->out_h * d->out_w * sizeof(float) : 0;
+}
+
+int gcconv::conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w, const float* in_scale, const float* out_scale,
+                          const gc_conv_epilogue* ep, float* y, void* workspace, size_t workspace_bytes, gc_stream_t stream) {
     int rc = validate(d, "gc_conv2d_f32", false);
     if (rc) return rc;
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_f32: null pointer");
@@ -568,13 +610,36 @@ extern "C" int gc_conv2d_fused_f32(const gc_conv_desc* d, const float* x, const 
     ConvArgs a{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
                d->pad_y, d->pad_x, 0, 0};
     set_epilogue(a, ep);
+    a.k_per_split = 0; a.part = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (d->kh == 3) {
-        if (d->up == 2) return dispatch_conv<2, 1, 3>(a, s);
-        return d->down == 2 ? dispatch_conv<1, 2, 3>(a, s) : dispatch_conv<1, 1, 3>(a, s);
+    const SplitPlan sp = plan_splitk(d);
+    const size_t need = conv2d_f32_workspace(d);
+    const bool split = sp.slices > 1 && workspace && workspace_bytes >= need;
+    ConvArgs fin = a;
+    if (split) {        // raw partial sums now, out_scale + epilogue in the finish pass
+        a.so = nullptr;
+        set_epilogue(a, nullptr);
+        a.k_per_split = sp.k_per_split;
+        a.part = static_cast<float*>(workspace);
     }
-    if (d->up == 2) return dispatch_conv<2, 1, 1>(a, s);
-    return d->down == 2 ? dispatch_conv<1, 2, 1>(a, s) : dispatch_conv<1, 1, 1>(a, s);
+    if (d->kh == 3) {
+        if (d->up == 2) rc = dispatch_conv<2, 1, 3>(a, s);
+        else rc = d->down == 2 ? dispatch_conv<1, 2, 3>(a, s) : dispatch_conv<1, 1, 3>(a, s);
+    } else {
+        if (d->up == 2) rc = dispatch_conv<2, 1, 1>(a, s);
+        else rc = d->down == 2 ? dispatch_conv<1, 2, 1>(a, s) : dispatch_conv<1, 1, 1>(a, s);
+    }
+    if (rc || !split) return rc;
+    fin.part = static_cast<float*>(workspace);
+    const long long per_slice = (long long)d->batch * d->out_ch * d->out_h * d->out_w;
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)std::min<long long>((per_slice + 255) / 256, 2048)), dim3(256), 0, s, fin, sp.slices, per_slice);
+    return gc::check_launch("gc_conv2d_f32(split-K finish)");
+}
+
+extern "C" int gc_conv2d_fused_f32(const gc_conv_desc* d, const float* x, const float* w,
+                                   const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep,
+                                   float* y, gc_stream_t stream) {
+    return gcconv::conv2d_f32_ws(d, x, w, in_scale, out_scale, ep, y, nullptr, 0, stream);
 }
 
 extern "C" int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,

@@ -1071,6 +1071,7 @@ bool eligible(const gc_conv_desc* d) {
 
 extern "C" size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d) {
     if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
+    if (!eligible(d)) return conv2d_f32_workspace(d);        // runs on the fp32 kernel: split-K partial sums (small planes) or nothing
     const size_t units = (size_t)d->kh * d->kw * ((d->in_ch + 7) / 8) * d->out_ch;
     return 2 * units * sizeof(uint4);
 }
@@ -1083,7 +1084,7 @@ extern "C" int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x,
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_bf16x3_f32: null pointer");
     if (d->batch == 0) return GC_OK;
     if ((rc = validate_epilogue(ep, "gc_conv2d_bf16x3_f32"))) return rc;
-    if (!eligible(d)) return gc_conv2d_fused_f32(d, x, w, in_scale, out_scale, ep, y, stream);
+    if (!eligible(d)) return conv2d_f32_ws(d, x, w, in_scale, out_scale, ep, y, workspace, workspace_bytes, stream);
     const size_t need = gc_conv2d_bf16x3_workspace(d);
     if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
         return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_bf16x3_f32: workspace %zu < %zu bytes (or not 16-byte aligned)", workspace_bytes, need);

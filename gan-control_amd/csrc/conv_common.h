@@ -13,6 +13,9 @@ struct ConvArgs {
     // fused epilogue (gc_conv_epilogue): y = act(so * acc + noise_w * noise[b, pixel] + bias[n])
     const float* bias; const float* noise; const float* noise_w;
     float slope, gain; int act;
+    // grid-level split over the input channels (conv_mfma_kernel, small planes): slice z handles channels
+    // [z * k_per_split, min(K, (z + 1) * k_per_split)) and writes its raw partial sums to part + z * B*N*out_h*out_w
+    int k_per_split; float* part;
 };
 
 inline void set_epilogue(ConvArgs& a, const gc_conv_epilogue* ep) {
@@ -131,6 +134,11 @@ __device__ __forceinline__ uint4 buf_load_u128(__amdgpu_buffer_rsrc_t r, unsigne
 // s_waitcnt vmcnt(N) in the middle of the NEXT prefetch; counted in hardware, that waits for the fresh loads and
 // serialises the pipeline.  simm16 = vmcnt(0) with expcnt / lgkmcnt left at their maxima.
 __device__ __forceinline__ void wait_staged_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
+
+// defined in conv.hip: the fp32 convolution with an optional workspace (split-K over the input channels on small planes)
+size_t conv2d_f32_workspace(const gc_conv_desc* d);
+int conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w, const float* in_scale, const float* out_scale,
+                  const gc_conv_epilogue* ep, float* y, void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
 // defined in conv.hip: dw[i] = sum_s ws[s][i] in fixed order (deterministic split reduction)
 int launch_wgrad_reduce(const float* ws, float* dw, size_t count, int parts, hipStream_t s);
