@@ -376,7 +376,8 @@ class ConvLayer(nn.Sequential):
         self._decimating_fir = downsample and kernel_size == 1
         self._has_blur, self._activate = downsample, activate
 
-    def forward(self, input):
+    def forward(self, input, out_gain=1.0):
+        """out_gain multiplies the layer's output; it is folded into the activation gain / the weight scale (no extra pass)."""
         out, idx = input, 0
         if self._has_blur:
             blur, idx = self[0], 1
@@ -387,9 +388,14 @@ class ConvLayer(nn.Sequential):
             # EqualConv2d -> FusedLeakyReLU in one launch: bias + leaky-ReLU run in the convolution's epilogue
             act = self[idx + 1]
             return conv2d_gradfix.conv2d_bias_act(out, conv.weight, act.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale,
-                                                  negative_slope=act.negative_slope, scale=act.scale)
-        out = conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale)
-        return self[idx + 1](out) if self._activate else out
+                                                  negative_slope=act.negative_slope, scale=act.scale * out_gain)
+        if self._activate:
+            out = conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale)
+            act = self[idx + 1]
+            return fused_leaky_relu(out, act.bias, act.negative_slope, act.scale * out_gain)
+        if conv.bias is not None and out_gain != 1.0:
+            raise NotImplementedError('ConvLayer: out_gain with a plain bias is not built')
+        return conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale * out_gain)
 
 
 class ResBlock(nn.Module):
@@ -404,8 +410,10 @@ class ResBlock(nn.Module):
         self.skip = ConvLayer(in_channel, out_channel, 1, downsample=True, activate=False, bias=False)
 
     def forward(self, input):
-        out = self.conv2(self.conv1(input))
-        return (out + self.skip(input)) / math.sqrt(2)
+        # (conv2(conv1(x)) + skip(x)) / sqrt(2) with the 1/sqrt(2) folded into conv2's activation gain and the skip conv's
+        # weight scale: one elementwise pass (the add) instead of two
+        rs = 1.0 / math.sqrt(2)
+        return self.conv2(self.conv1(input), out_gain=rs) + self.skip(input, out_gain=rs)
 
 
 def minibatch_stddev(x, group_size=4, feat=1):

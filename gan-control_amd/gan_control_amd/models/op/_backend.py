@@ -46,8 +46,15 @@ class HipBackend:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_upfirdn2d_f32')
         if t0 is not None:
-            fast = up == 1 and down == 1 and tuple(taps.shape) == (4, 4) and out_w >= 64 and out_h >= 16
-            self.timer.stop('fir44_tile_kernel' if fast else 'upfirdn2d_generic_kernel', t0, 4.0 * (x.numel() + y.numel()))
+            name = 'upfirdn2d_generic_kernel'          # mirrors the dispatch of gc_upfirdn2d_f32
+            if tuple(taps.shape) == (4, 4) and n * c <= 65535:
+                if up == 1 and down == 1 and out_w >= 64 and out_h >= 16:
+                    name = 'fir44_tile_kernel'
+                elif (up, down) == (1, 2) and out_w >= 32 and out_h >= 8:
+                    name = 'fir44_down2_kernel'
+                elif (up, down) == (2, 1) and out_w >= 32 and out_h >= 8:
+                    name = 'fir44_up2_kernel'
+            self.timer.stop(name, t0, 4.0 * (x.numel() + y.numel()))
         return y
 
     def bias_act(self, x, bias, noise, noise_w, slope, gain):

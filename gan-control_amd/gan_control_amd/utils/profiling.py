@@ -21,12 +21,17 @@ def conv_variant(geom, n_out, batch=1, k_in=64, mode='f32'):
     """
     qw, qh = -(-geom.out_w // geom.up), -(-geom.out_h // geom.up)
     geo = '|up%d,down%d,k%d' % (geom.up, geom.down, geom.kh)
-    if mode == 'bf16x3' and k_in >= 16 and qw > 16:
+    if mode == 'bf16x3' and 16 <= k_in <= 1024 and qw > 16:
+        if geom.up == 2 and geom.kh == 3 and geom.pad_y == 2 and geom.pad_x == 2:
+            # convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, EPI> (dispatch_t): the four output phases in one workgroup
+            tq = -(-geom.out_w // 2)
+            tpw = 16 if -(-tq // 16) * 16 < -(-tq // 32) * 32 else 32
+            return ('convt_fused_bf16x3_kernel<1,4,2,%d>' % tpw if n_out <= 32 else 'convt_fused_bf16x3_kernel<2,2,2,%d>' % tpw) + geo
         # conv_bf16x3_kernel<WG_OC, WG_PX, WOC, WPX> (csrc/conv_bf16x3.hip, dispatch)
         if geom.down == 2:
             return ('conv_bf16x3_kernel<1,4,1,1>' if n_out <= 32 else 'conv_bf16x3_kernel<1,4,2,1>') + geo
         if n_out <= 32:
-            return 'conv_bf16x3_kernel<1,4,1,4>' + geo
+            return 'conv_bf16x3_kernel<1,4,1,2>' + geo
         big = -(-qw // 32) * -(-qh // 8) * geom.up * geom.up * batch * -(-n_out // 64)
         return ('conv_bf16x3_kernel<1,4,2,1>' if big < 512 else 'conv_bf16x3_kernel<1,4,2,2>') + geo
     if qw <= 16:
