@@ -100,28 +100,41 @@ __device__ __forceinline__ float block_sum(float v, float* lds) {
 //   dx = dy * mask(y_ref);  psum[plane][chunk] = sum_chunk dx;  pdot[plane][chunk] = sum_chunk dx * noise[b, :]
 // (bias gradient = sum of psum over batch and chunks; noise-strength gradient = sum of pdot).  One read of dy and
 // y_ref, one write of dx -- the separate channel-sum / product passes over dx disappear.
-template <bool NOISE>
+// SELF adds pself[plane][chunk] = sum_chunk dx * x_pre, where x_pre = act^-1(y_ref) - bias[c] - noise_w * noise[b, :] is
+// the activation's INPUT rebuilt from its output (leaky-ReLU is invertible): the out_scale gradient of a convolution whose
+// activation ran in the epilogue (the pre-activation tensor was never written), with no pass of its own.
+template <bool NOISE, bool SELF>
 __global__ __launch_bounds__(256) void bias_act_bwd_reduce_kernel(
-    const float* __restrict__ dy, const float* __restrict__ yref, const float* __restrict__ noise, float* __restrict__ dx,
-    float* __restrict__ psum, float* __restrict__ pdot, int channels, int64_t inner, int chunks, int64_t chunk_len, float pos, float neg) {
+    const float* __restrict__ dy, const float* __restrict__ yref, const float* __restrict__ noise, const float* __restrict__ bias,
+    const float* __restrict__ noise_w, float* __restrict__ dx, float* __restrict__ psum, float* __restrict__ pdot, float* __restrict__ pself,
+    int channels, int64_t inner, int chunks, int64_t chunk_len, float pos, float neg) {
     __shared__ float lds[4];
     const int plane = blockIdx.y, j = blockIdx.x;
-    const int b = plane / channels;
+    const int b = plane / channels, c = plane % channels;
     const size_t base = (size_t)plane * inner;
     const float* np = NOISE ? noise + (size_t)b * inner : nullptr;
+    const float bv = (SELF && bias) ? bias[c] : 0.f, nw = (SELF && NOISE) ? noise_w[0] : 0.f;
+    const float ipos = 1.f / pos, ineg = 1.f / neg;
     const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
-    float s = 0.f, d = 0.f;
+    float s = 0.f, d = 0.f, q = 0.f;
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const float g = dy[base + i] * (yref[base + i] > 0.f ? pos : neg);
+        const float y = yref[base + i];
+        const float g = dy[base + i] * (y > 0.f ? pos : neg);
         dx[base + i] = g;
         s += g;
-        if (NOISE) d = fmaf(g, np[i], d);
+        const float nz = NOISE ? np[i] : 0.f;
+        if (NOISE) d = fmaf(g, nz, d);
+        if (SELF) q = fmaf(g, y * (y > 0.f ? ipos : ineg) - bv - nw * nz, q);
     }
     const float rs = block_sum(s, lds);
     if (threadIdx.x == 0) psum[(size_t)plane * chunks + j] = rs;
     if (NOISE) {
         const float rd = block_sum(d, lds);
         if (threadIdx.x == 0) pdot[(size_t)plane * chunks + j] = rd;
+    }
+    if (SELF) {
+        const float rq = block_sum(q, lds);
+        if (threadIdx.x == 0) pself[(size_t)plane * chunks + j] = rq;
     }
 }
 
@@ -251,22 +264,31 @@ extern "C" int gc_bias_act_bwd_chunks(int64_t inner) {
     return chunks;
 }
 
-extern "C" int gc_bias_act_bwd_reduce_f32(const float* dy, const float* y_ref, const float* noise, float* dx,
-                                          float* psum, float* pdot, int batch, int channels, int64_t inner,
-                                          float slope, float gain, gc_stream_t stream) {
+extern "C" int gc_bias_act_bwd_reduce_self_f32(const float* dy, const float* y_ref, const float* noise, const float* bias, const float* noise_w,
+                                               float* dx, float* psum, float* pdot, float* pself, int batch, int channels, int64_t inner,
+                                               float slope, float gain, gc_stream_t stream) {
     if (!dy || !y_ref || !dx || !psum) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_f32: null pointer");
     if ((noise == nullptr) != (pdot == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_f32: noise and pdot go together");
+    if (pself && noise && !noise_w) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_f32: pself with noise needs noise_w");
+    if (pself && (slope == 0.f || gain == 0.f)) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_f32: pself needs an invertible activation (slope, gain != 0)");
     if (batch <= 0 || channels <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_f32: bad extents");
     if ((int64_t)batch * channels > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_f32: more than 65535 planes");
     hipStream_t s = (hipStream_t)stream;
     int chunks; int64_t len;
     channel_sum_plan(inner, &chunks, &len);
     dim3 grid(chunks, batch * channels);
-    if (noise)
-        hipLaunchKernelGGL(bias_act_bwd_reduce_kernel<true>, grid, dim3(256), 0, s, dy, y_ref, noise, dx, psum, pdot, channels, inner, chunks, len, gain, gain * slope);
-    else
-        hipLaunchKernelGGL(bias_act_bwd_reduce_kernel<false>, grid, dim3(256), 0, s, dy, y_ref, noise, dx, psum, pdot, channels, inner, chunks, len, gain, gain * slope);
+#define GC_LAUNCH(N, S) hipLaunchKernelGGL((bias_act_bwd_reduce_kernel<N, S>), grid, dim3(256), 0, s, dy, y_ref, noise, bias, noise_w, dx, psum, pdot, pself, \
+                                           channels, inner, chunks, len, gain, gain * slope)
+    if (noise) { if (pself) GC_LAUNCH(true, true); else GC_LAUNCH(true, false); }
+    else       { if (pself) GC_LAUNCH(false, true); else GC_LAUNCH(false, false); }
+#undef GC_LAUNCH
     return gc::check_launch("gc_bias_act_bwd_reduce_f32");
+}
+
+extern "C" int gc_bias_act_bwd_reduce_f32(const float* dy, const float* y_ref, const float* noise, float* dx,
+                                          float* psum, float* pdot, int batch, int channels, int64_t inner,
+                                          float slope, float gain, gc_stream_t stream) {
+    return gc_bias_act_bwd_reduce_self_f32(dy, y_ref, noise, nullptr, nullptr, dx, psum, pdot, nullptr, batch, channels, inner, slope, gain, stream);
 }
 
 extern "C" int gc_plane_dot_f32(const float* a, const float* b, float* partial, int planes, int64_t inner, gc_stream_t stream) {

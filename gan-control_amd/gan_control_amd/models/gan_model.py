@@ -18,7 +18,7 @@ from torch.nn import functional as F
 
 import os
 _FUSE_EPILOGUE = os.environ.get('GANCONTROL_FUSE_EPILOGUE', '1') != '0'   # debugging knob: 0 = convolution and activation as two launches
-from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix, modulated_conv2d
+from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix, modulated_conv2d, modulated_conv2d_act
 
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
 
@@ -187,7 +187,18 @@ class StyledConv(nn.Module):
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, input, style, noise=None):
-        out = self.conv(input, style)
+        conv = self.conv
+        if _FUSE_EPILOGUE and not conv.upsample:
+            # conv -> noise -> bias + leaky-ReLU in one launch (the activation runs in the convolution's epilogue)
+            if noise is None:
+                b, _, h, w = input.shape
+                pad = conv.padding
+                noise = input.new_empty(b, 1, h + 2 * pad - conv.kernel_size + 1, w + 2 * pad - conv.kernel_size + 1).normal_()
+            act = self.activate
+            return modulated_conv2d_act(input, conv.weight, conv.modulation(style), act.bias, noise, self.noise.weight,
+                                        demodulate=conv.demodulate, padding=conv.padding,
+                                        negative_slope=act.negative_slope, act_scale=act.scale)
+        out = conv(input, style)
         if noise is None:
             b, _, h, w = out.shape
             noise = out.new_empty(b, 1, h, w).normal_()

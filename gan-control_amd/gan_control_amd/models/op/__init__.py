@@ -8,7 +8,7 @@ identical signatures, plus the convolutions the north star adds behind the same 
 from .fused_act import FusedLeakyReLU, fused_leaky_relu, fused_noise_bias_act
 from .upfirdn2d import upfirdn2d
 from . import conv2d_gradfix
-from .modulated_conv import modulated_conv2d, demod_coefficients
+from .modulated_conv import modulated_conv2d, modulated_conv2d_act, demod_coefficients
 
 __all__ = ['FusedLeakyReLU', 'fused_leaky_relu', 'fused_noise_bias_act', 'upfirdn2d', 'conv2d_gradfix',
-           'modulated_conv2d', 'demod_coefficients']
+           'modulated_conv2d', 'modulated_conv2d_act', 'demod_coefficients']

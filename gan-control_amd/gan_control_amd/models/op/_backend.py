@@ -94,8 +94,12 @@ class HipBackend:
         _lib.check(rc, 'gc_bias_act_bwd_f32')
         return dx
 
-    def bias_act_bwd_reduce(self, dy, y_ref, noise, slope, gain):
-        """-> (dx, psum [B, C, chunks], pdot [B, C, chunks] or None); see gc_bias_act_bwd_reduce_f32."""
+    def bias_act_bwd_reduce(self, dy, y_ref, noise, slope, gain, self_dot=None):
+        """-> (dx, psum [B, C, chunks], pdot [B, C, chunks] or None, pself [B, C, chunks] or None).
+
+        self_dot = (bias [C] | None, noise_w [1] | None) additionally requests pself = chunk sums of dx * (pre-activation
+        rebuilt from y_ref); see gc_bias_act_bwd_reduce_self_f32.
+        """
         dev = _lib.require_cuda_f32(dy, y_ref, noise)
         batch, ch = dy.shape[0], dy.shape[1]
         inner = dy.numel() // (batch * ch)
@@ -104,15 +108,21 @@ class HipBackend:
         dx = torch.empty_like(dy)
         psum = torch.empty((batch, ch, chunks), dtype=dy.dtype, device=dev)
         pdot = torch.empty((batch, ch, chunks), dtype=dy.dtype, device=dev) if noise is not None else None
+        pself = bias = noise_w = None
+        if self_dot is not None:
+            bias, noise_w = self_dot
+            _lib.require_cuda_f32(dy, bias, noise_w)
+            pself = torch.empty((batch, ch, chunks), dtype=dy.dtype, device=dev)
         g = self._guard(dev)
         if g: g.__enter__()
         try:
-            rc = lib.gc_bias_act_bwd_reduce_f32(_lib.ptr(dy), _lib.ptr(y_ref), _lib.ptr(noise), _lib.ptr(dx), _lib.ptr(psum), _lib.ptr(pdot),
-                                                batch, ch, inner, slope, gain, _lib.stream_of(dy))
+            rc = lib.gc_bias_act_bwd_reduce_self_f32(_lib.ptr(dy), _lib.ptr(y_ref), _lib.ptr(noise), _lib.ptr(bias), _lib.ptr(noise_w),
+                                                     _lib.ptr(dx), _lib.ptr(psum), _lib.ptr(pdot), _lib.ptr(pself),
+                                                     batch, ch, inner, slope, gain, _lib.stream_of(dy))
         finally:
             if g: g.__exit__(None, None, None)
-        _lib.check(rc, 'gc_bias_act_bwd_reduce_f32')
-        return dx, psum, pdot
+        _lib.check(rc, 'gc_bias_act_bwd_reduce_self_f32')
+        return dx, psum, pdot, pself
 
     def plane_dot(self, a, b):
         """[B, C, *] x [B, C, *] -> [B, C]: sum over the trailing dims of a * b."""

@@ -102,7 +102,7 @@ class _GConvAct(Function):
         if not any(ctx.needs_input_grad[:3]):
             return None, None, None, None, None, None
         if ctx.needs_input_grad[2]:
-            g_pre, psum, _ = _BiasActGradReduce.apply(gy, out, None, slope, gain)
+            g_pre, psum = _BiasActGradReduce.apply(gy, out, None, slope, gain)[:2]
             gb = psum.sum((0, 2))
         else:
             g_pre = _BiasActGrad.apply(gy, out, slope, gain)

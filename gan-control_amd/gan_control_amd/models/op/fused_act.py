@@ -51,7 +51,7 @@ class _BiasAct(Function):
         want_nw = ctx.has_noise and ctx.needs_input_grad[3]
         if (want_b or want_nw) and not want_n:
             # one pass: activation gradient + per-plane partial sums for the bias / noise-strength gradients
-            gx, psum, pdot = _BiasActGradReduce.apply(gy, y, noise if want_nw else None, slope, gain)
+            gx, psum, pdot = _BiasActGradReduce.apply(gy, y, noise if want_nw else None, slope, gain)[:3]
             if want_b:
                 gb = psum.sum((0, 2))
             if want_nw:
@@ -74,34 +74,73 @@ class _BiasAct(Function):
 REDUCE_CHUNK = 16384      # elements of one plane summed per workgroup (channel_sum_plan in csrc/bias_act.hip)
 
 
+def _spread(partial, like):
+    """[B, C, chunks] cotangent of a per-chunk sum -> one value per element of `like`."""
+    b, c = like.shape[0], like.shape[1]
+    inner = like.numel() // (b * c)
+    return partial.repeat_interleave(REDUCE_CHUNK, dim=2)[:, :, :inner].reshape(like.shape)
+
+
 class _BiasActGradReduce(Function):
-    """(gx, psum, pdot) = gc_bias_act_bwd_reduce_f32; every output is linear in gy."""
+    """(gx, psum, pdot, pself) = gc_bias_act_bwd_reduce_self_f32; every output is linear in gy.
+
+    pself (only with self_dot = True) = chunk sums of gx * x_pre, x_pre = the activation's input rebuilt from its output:
+    x_pre = lrelu^-1(y / gain) - bias - noise_w * noise.  It makes the out_scale gradient of a convolution with a fused
+    activation epilogue without the pre-activation tensor ever existing (see modulated_conv._ModConvAct).
+    """
 
     @staticmethod
-    def forward(ctx, gy, y, noise, slope, gain):
-        ctx.save_for_backward(y, noise if noise is not None else y.new_empty(0))
+    def forward(ctx, gy, y, noise, slope, gain, bias=None, noise_w=None, self_dot=False):
         ctx.cfg = (slope, gain)
-        ctx.has_noise = noise is not None
-        gx, psum, pdot = _backend.get().bias_act_bwd_reduce(gy.contiguous(), y, None if noise is None else noise.contiguous(), slope, gain)
+        ctx.has_noise, ctx.self_dot, ctx.has_bias = noise is not None, bool(self_dot), bias is not None
+        nz = None if noise is None else noise.contiguous()
+        gx, psum, pdot, pself = _backend.get().bias_act_bwd_reduce(gy.contiguous(), y, nz, slope, gain,
+                                                                    self_dot=(bias, noise_w if noise is not None else None) if self_dot else None)
+        empty = y.new_empty(0)
+        ctx.save_for_backward(y, noise if noise is not None else empty, bias if (self_dot and bias is not None) else empty,
+                              noise_w if (self_dot and noise is not None) else empty, gx if self_dot else empty)
+        dead = []
         if pdot is None:
             pdot = psum.new_empty(0)
-            ctx.mark_non_differentiable(pdot)
-        return gx, psum, pdot
+            dead.append(pdot)
+        if pself is None:
+            pself = psum.new_empty(0)
+            dead.append(pself)
+        if dead:
+            ctx.mark_non_differentiable(*dead)
+        return gx, psum, pdot, pself
 
     @staticmethod
-    def backward(ctx, ggx, gpsum, gpdot):
-        y, noise = ctx.saved_tensors
+    def backward(ctx, ggx, gpsum, gpdot, gpself):
+        y, noise, bias, noise_w, gx = ctx.saved_tensors
         slope, gain = ctx.cfg
-        if not ctx.needs_input_grad[0]:
-            return None, None, None, None, None
-        b, c = y.shape[0], y.shape[1]
-        inner = y.numel() // (b * c)
+        b = y.shape[0]
+        noise4 = noise.reshape(b, 1, *y.shape[2:]) if ctx.has_noise else None
         total = torch.zeros_like(y) if ggx is None else ggx
         if gpsum is not None:
-            total = total + gpsum.repeat_interleave(REDUCE_CHUNK, dim=2)[:, :, :inner].reshape(y.shape)
+            total = total + _spread(gpsum, y)
         if ctx.has_noise and gpdot is not None and gpdot.numel() > 0:
-            total = total + gpdot.repeat_interleave(REDUCE_CHUNK, dim=2)[:, :, :inner].reshape(y.shape) * noise.reshape(b, 1, *y.shape[2:])
-        return _BiasActGrad.apply(total, y, slope, gain), None, None, None, None
+            total = total + _spread(gpdot, y) * noise4
+        g_y = g_bias = g_nw = None
+        if ctx.self_dot and gpself is not None and gpself.numel() > 0:
+            # x_pre materialised with ATen: this branch only runs in double-backward (path-length regularisation)
+            w_self = _spread(gpself, y)
+            x_pre = torch.where(y > 0, y / gain, y / (gain * slope))
+            if ctx.has_bias:
+                x_pre = x_pre - bias.reshape([1, -1] + [1] * (y.ndim - 2))
+            if ctx.has_noise:
+                x_pre = x_pre - noise_w * noise4
+            total = total + w_self * x_pre
+            wg = w_self * gx
+            # d x_pre / d y = 1 / (gain * mask) and gx = gy * gain * mask  =>  wg * d x_pre / d y = w_self * gy
+            if ctx.needs_input_grad[1]:
+                g_y = torch.where(y > 0, wg / gain, wg / (gain * slope))
+            if ctx.has_bias and ctx.needs_input_grad[5]:
+                g_bias = -wg.sum([d for d in range(y.ndim) if d != 1])
+            if ctx.has_noise and ctx.needs_input_grad[6]:
+                g_nw = -(wg * noise4).sum().reshape(noise_w.shape)
+        g_gy = _BiasActGrad.apply(total, y, slope, gain) if ctx.needs_input_grad[0] else None
+        return g_gy, g_y, None, None, None, g_bias, g_nw, None
 
 
 class _BiasActGrad(Function):

@@ -88,6 +88,59 @@ class _ModConv(Function):
         return (gx if ctx.needs_input_grad[0] else None), gw, gsi, gso, None
 
 
+class _ModConvAct(Function):
+    """out = gain * lrelu(so * gconv(si * x, w_t) + noise_w * noise + bias): modulated convolution, noise injection and
+    FusedLeakyReLU (StyledConv, gan_model.py:402-408) as ONE kernel; the pre-activation tensor is never written.
+
+    Backward: the activation gradient pass (which reads gy and `out` anyway) also returns the bias / noise-strength sums
+    and -- through x_pre = lrelu^-1(out / gain) - bias - noise_w * noise -- the plane sums of g_pre * x_pre, i.e. the
+    out_scale gradient, so neither the pre-activation nor a _PlaneDot over it is needed.  The rest is _ModConv's backward.
+    """
+
+    @staticmethod
+    def forward(ctx, x, w_t, si, so, bias, noise, noise_w, geom, slope, gain):
+        out = _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None if si is None else si.contiguous(),
+                                    None if so is None else so.contiguous(), geom,
+                                    epilogue=(bias, None if noise is None else noise.contiguous(), noise_w, slope, gain, True))
+        ctx.geom, ctx.in_hw, ctx.cfg = geom, (x.shape[2], x.shape[3]), (slope, gain)
+        ctx.has = (si is not None, so is not None, bias is not None, noise is not None)
+        empty = x.new_empty(0)
+        ctx.save_for_backward(x, w_t, *[t if t is not None else empty for t in (si, so, bias, noise, noise_w)], out)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .fused_act import _BiasActGrad, _BiasActGradReduce
+        x, w_t, si, so, bias, noise, noise_w, out = ctx.saved_tensors
+        has_si, has_so, has_bias, has_noise = ctx.has
+        si, so, bias = (si if has_si else None), (so if has_so else None), (bias if has_bias else None)
+        noise, noise_w = (noise, noise_w) if has_noise else (None, None)
+        g, (slope, gain) = ctx.geom, ctx.cfg
+        need = ctx.needs_input_grad
+        gx = gw = gsi = gso = gb = gnw = None
+        if not any(need[:7]):
+            return (None,) * 10
+        want_so = has_so and need[3]
+        if (has_bias and need[4]) or (has_noise and need[6]) or want_so:
+            g_pre, psum, pdot, pself = _BiasActGradReduce.apply(gy, out, noise, slope, gain, bias, noise_w, want_so)
+            if has_bias and need[4]:
+                gb = psum.sum((0, 2))
+            if has_noise and need[6]:
+                gnw = pdot.sum().reshape(noise_w.shape)
+            if want_so:
+                gso = pself.sum(2) / _safe(so)
+        else:
+            g_pre = _BiasActGrad.apply(gy, out, slope, gain)
+        need_si = has_si and need[2]
+        if need[0] or need_si:
+            gx = _ModConv.apply(g_pre, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw))
+        if need[1]:
+            gw = _mod_weight_grad(x, g_pre, si, so, g)
+        if need_si:
+            gsi = _PlaneDot.apply(x, gx) / _safe(si)
+        return (gx if need[0] else None), gw, gsi, gso, gb, None, gnw, None, None, None
+
+
 def _mod_weight_grad(x, gy, si, so, g):
     if g.up == 1:
         return _ModWGrad.apply(x, gy, si, so, g)
@@ -146,3 +199,17 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
     w_t = kernel_layout(weight.view(oc, ic, k, k), scale)
     oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1
     return _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow))
+
+
+def modulated_conv2d_act(x, weight, s, bias, noise, noise_weight, demodulate=True, padding=None, negative_slope=0.2, act_scale=2 ** 0.5):
+    """modulated_conv2d (plain branch) -> + noise_weight * noise -> FusedLeakyReLU(bias), in one kernel launch."""
+    _, oc, ic, k, _ = weight.shape
+    scale = 1.0 / math.sqrt(ic * k * k)
+    d = demod_coefficients(weight, s, scale) if demodulate else None
+    pad = k // 2 if padding is None else padding
+    w_t = kernel_layout(weight.view(oc, ic, k, k), scale)
+    oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1
+    if noise.shape[0] != x.shape[0] or noise.numel() != x.shape[0] * oh * ow:
+        raise ValueError(f'noise shape {tuple(noise.shape)} does not match the output [{x.shape[0]}, {oc}, {oh}, {ow}]')
+    return _ModConvAct.apply(x, w_t, s, d, bias.reshape(-1).contiguous(), noise, noise_weight.reshape(-1).contiguous(),
+                             ConvGeom(k, k, 1, 1, pad, pad, oh, ow), float(negative_slope), float(act_scale))

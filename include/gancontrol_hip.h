@@ -93,6 +93,17 @@ int gc_bias_act_bwd_reduce_f32(const float* dy, const float* y_ref, const float*
                                float* psum, float* pdot, int batch, int channels, int64_t inner,
                                float slope, float gain, gc_stream_t stream);
 
+/* The same pass with one more reduction, for a convolution whose activation ran in its epilogue (gc_conv_epilogue) so
+ * that the pre-activation tensor was never written:
+ *   pself[(b*C + c)*chunks + j] = sum over chunk j of dx[b,c,:] * x_pre[b,c,:],
+ *   x_pre = lrelu^-1(y_ref / gain) - bias[c] - noise_w[0] * noise[b,:]      (the activation's input, rebuilt from its output)
+ * Summed over the chunks and divided by out_scale[b,c] this is the out_scale (demodulation) gradient of K3, which would
+ * otherwise need gc_plane_dot_f32 over (dx, pre-activation).  bias / noise / noise_w / pdot / pself may be NULL
+ * (noise_w is required with noise when pself is requested); slope and gain must be non-zero for pself. */
+int gc_bias_act_bwd_reduce_self_f32(const float* dy, const float* y_ref, const float* noise, const float* bias, const float* noise_w,
+                                    float* dx, float* psum, float* pdot, float* pself, int batch, int channels, int64_t inner,
+                                    float slope, float gain, gc_stream_t stream);
+
 /* partial[p*chunks + j] = sum over chunk j of a[p,:] * b[p,:], chunks = gc_bias_act_bwd_chunks(inner); planes = B*C.
  * Gradients of the per-sample modulation / demodulation factors of K3 (sum_hw x * dx and sum_hw dy * y). */
 int gc_plane_dot_f32(const float* a, const float* b, float* partial, int planes, int64_t inner, gc_stream_t stream);

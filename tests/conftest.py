@@ -80,19 +80,30 @@ class EmulatedBackend:
     def bias_act_bwd(self, dy, y_ref, slope, gain):
         return dy * torch.where(y_ref > 0, torch.full_like(dy, gain), torch.full_like(dy, gain * slope))
 
-    def bias_act_bwd_reduce(self, dy, y_ref, noise, slope, gain):
+    def bias_act_bwd_reduce(self, dy, y_ref, noise, slope, gain, self_dot=None):
         dx = self.bias_act_bwd(dy, y_ref, slope, gain)
         b, c = dy.shape[0], dy.shape[1]
         inner = dy.numel() // (b * c)
         chunk = 16384
         chunks = -(-inner // chunk)
-        flat = F.pad(dx.reshape(b, c, inner), [0, chunks * chunk - inner]).reshape(b, c, chunks, chunk)
+
+        def chunked(t):
+            return F.pad(t.reshape(t.shape[0], t.shape[1], inner), [0, chunks * chunk - inner]).reshape(t.shape[0], t.shape[1], chunks, chunk)
+
+        flat = chunked(dx)
         psum = flat.sum(3)
-        pdot = None
+        pdot = pself = None
         if noise is not None:
-            nz = F.pad(noise.reshape(b, 1, inner), [0, chunks * chunk - inner]).reshape(b, 1, chunks, chunk)
-            pdot = (flat * nz).sum(3)
-        return dx, psum, pdot
+            pdot = (flat * chunked(noise.reshape(b, 1, inner))).sum(3)
+        if self_dot is not None:
+            bias, noise_w = self_dot
+            pre = torch.where(y_ref > 0, y_ref / gain, y_ref / (gain * slope))
+            if bias is not None:
+                pre = pre - bias.reshape([1, -1] + [1] * (y_ref.ndim - 2))
+            if noise is not None:
+                pre = pre - noise_w * noise.reshape(b, 1, *y_ref.shape[2:])
+            pself = (flat * chunked(pre)).sum(3)
+        return dx, psum, pdot, pself
 
     def plane_dot(self, a, b):
         return (a * b).reshape(a.shape[0], a.shape[1], -1).sum(2)

@@ -152,6 +152,61 @@ def test_weight_layout_autograd_closure():
     assert torch.allclose(gg, torch.full_like(gg, 0.5))
 
 
+@pytest.mark.parametrize('shape', [(2, 6, 40, 70), (1, 5, 129, 131), (3, 8, 16, 16)])
+def test_bias_act_bwd_reduce_self_dot(shape):
+    """gc_bias_act_bwd_reduce_self_f32: the plane sums of dx * (pre-activation rebuilt from the activation output)."""
+    hip, emu = _be()
+    gen = torch.Generator().manual_seed(shape[2])
+    x = torch.randn(*shape, generator=gen)
+    bias, nz, nw = torch.randn(shape[1], generator=gen), torch.randn(shape[0], 1, *shape[2:], generator=gen), torch.randn(1, generator=gen)
+    dy = torch.randn(*shape, generator=gen)
+    for use_noise in (True, False):
+        n_, w_ = (nz, nw) if use_noise else (None, None)
+        y = emu.bias_act(x.double(), bias.double(), None if n_ is None else n_.double(), None if w_ is None else w_.double(), 0.2, 2 ** 0.5)
+        ref = emu.bias_act_bwd_reduce(dy.double(), y, None if n_ is None else n_.double(), 0.2, 2 ** 0.5,
+                                      self_dot=(bias.double(), None if w_ is None else w_.double()))
+        # the rebuilt pre-activation is x itself: pself must equal sum(dx * x)
+        assert rel_err(ref[3].sum(2), (ref[0] * x.double()).reshape(shape[0], shape[1], -1).sum(2)) < 1e-12
+        out = hip.bias_act_bwd_reduce(dy.to(DEV), y.float().to(DEV), None if n_ is None else n_.to(DEV), 0.2, 2 ** 0.5,
+                                      self_dot=(bias.to(DEV), None if w_ is None else w_.to(DEV)))
+        for a, b in zip(out, ref):
+            if b is not None:
+                assert rel_err(a, b) < 2e-5, use_noise
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
+def test_modulated_conv2d_act_matches_two_pass(mode):
+    """One-launch StyledConv (conv + noise + bias + leaky-ReLU) vs modulated_conv2d -> FusedLeakyReLU: values and gradients up to second order."""
+    from gan_control_amd.models.op import modulated_conv2d, modulated_conv2d_act, fused_noise_bias_act
+    hip, _ = _be()
+    prev, hip.conv_mode = hip.conv_mode, mode
+    try:
+        gen = torch.Generator().manual_seed(3)
+        x = torch.randn(2, 24, 33, 40, generator=gen).to(DEV).requires_grad_(True)
+        w = torch.randn(1, 40, 24, 3, 3, generator=gen).to(DEV).requires_grad_(True)
+        s = (torch.randn(2, 24, generator=gen) + 1.5).to(DEV).requires_grad_(True)
+        b = torch.randn(40, generator=gen).to(DEV).requires_grad_(True)
+        nw = torch.randn(1, generator=gen).to(DEV).requires_grad_(True)
+        nz = torch.randn(2, 1, 33, 40, generator=gen).to(DEV)
+        probe = torch.randn(2, 40, 33, 40, generator=gen).to(DEV)
+        outs = []
+        for fused in (True, False):
+            if fused:
+                y = modulated_conv2d_act(x, w, s, b, nz, nw)
+            else:
+                y = fused_noise_bias_act(modulated_conv2d(x, w, s), b, nz, nw)
+            leaves = [x, w, s, b, nw]
+            g1 = torch.autograd.grad((y * probe).sum(), leaves, retain_graph=True)
+            gs, gxx = torch.autograd.grad((y * probe).sum() + y.square().sum(), [s, x], create_graph=True)     # path-length style: grad w.r.t. the style
+            g2 = torch.autograd.grad(gs.square().sum() + gxx.square().mean(), leaves)
+            outs.append([y.detach(), *g1, gs.detach(), *g2])
+        tol = 2e-5 if mode == 'f32' else 3e-4
+        for i, (a, c) in enumerate(zip(*outs)):
+            assert rel_err(a, c) < tol, i
+    finally:
+        hip.conv_mode = prev
+
+
 CONV_CASES = [
     # b, K, N, h, w, k, up, down, pad
     (2, 8, 8, 4, 4, 3, 1, 1, 1), (2, 16, 130, 8, 8, 3, 1, 1, 1), (1, 40, 64, 16, 16, 3, 1, 1, 1),
