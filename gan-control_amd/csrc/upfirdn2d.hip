@@ -18,10 +18,17 @@ constexpr int TH = 32, TW = 128;          // output tile of the fast kernel
 constexpr int PH = TH + 3, PW = TW + 3;   // input patch (4x4 taps)
 constexpr int PITCH = 132;                // patch row pitch in floats (multiple of 4: 16-B aligned rows)
 
-template <bool VEC>
+// Optional epilogue of the up = down = 1 kernel (gc_upfirdn2d_act_f32): the NoiseInjection + FusedLeakyReLU that follow
+// the Blur of an up-sampling StyledConv (gan_model.py:402-408), in the arithmetic order of bias_act_plane_kernel.
+struct FirEpilogue {
+    const float* bias; const float* noise; const float* noise_w;
+    float slope, gain; int channels;
+};
+
+template <bool VEC, bool EPI>
 __global__ __launch_bounds__(256) void fir44_tile_kernel(
     const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
-    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip) {
+    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip, FirEpilogue ep) {
     __shared__ __attribute__((aligned(16))) float patch[PH * PITCH];
     const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
@@ -82,6 +89,28 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
     }
 
     const int ox = ox0 + cg * 4;
+    if (EPI) {
+        // every noise value of the micro-tile is fetched before the first store (a load between stores costs a full
+        // memory round trip: vmcnt counts the stores too)
+        const int c = (int)(plane % ep.channels);
+        const size_t b = plane / ep.channels;
+        const float bv = ep.bias ? ep.bias[c] : 0.f, nw = ep.noise ? ep.noise_w[0] : 0.f;
+        float nz[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int oy = oy0 + rg * 4 + r;
+                nz[r][j] = (ep.noise && oy < out_h && ox + j < out_w) ? ep.noise[(b * out_h + oy) * out_w + ox + j] : 0.f;
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float v = fmaf(nw, nz[r][j], acc[r][j]) + bv;
+                acc[r][j] = (v > 0.f ? v : v * ep.slope) * ep.gain;
+            }
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int oy = oy0 + rg * 4 + r;
@@ -299,10 +328,12 @@ __global__ __launch_bounds__(256) void generic_kernel(
 
 }  // namespace
 
-extern "C" int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
-                                int planes, int in_h, int in_w, int out_h, int out_w,
-                                int kh, int kw, int up_x, int up_y, int down_x, int down_y,
-                                int pad_x0, int pad_y0, int flip_taps, gc_stream_t stream) {
+namespace {
+
+int upfirdn2d_impl(const float* x, const float* taps, float* y,
+                   int planes, int in_h, int in_w, int out_h, int out_w,
+                   int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                   int pad_x0, int pad_y0, int flip_taps, const FirEpilogue* ep, gc_stream_t stream) {
     if (!x || !taps || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: null pointer");
     if (planes < 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0 || up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
         return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: non-positive extent or factor");
@@ -311,13 +342,15 @@ extern "C" int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
     hipStream_t s = (hipStream_t)stream;
     const bool fast = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 &&
                       out_w >= 64 && out_h >= 16 && planes <= 65535;
+    if (ep && !fast) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_act_f32: the fused epilogue needs the 4x4, up = down = 1 tile kernel (planes >= 64 x 16)");
     if (fast) {
         dim3 grid(gc::ceil_div(out_w, TW), gc::ceil_div(out_h, TH), planes);
         const bool vec = (out_w % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
-        if (vec)
-            hipLaunchKernelGGL(fir44_tile_kernel<true>, grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps);
-        else
-            hipLaunchKernelGGL(fir44_tile_kernel<false>, grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps);
+        const FirEpilogue none{nullptr, nullptr, nullptr, 1.f, 1.f, 1};
+#define GC_FIR(V, E) hipLaunchKernelGGL((fir44_tile_kernel<V, E>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, ep ? *ep : none)
+        if (ep) { if (vec) GC_FIR(true, true); else GC_FIR(false, true); }
+        else    { if (vec) GC_FIR(true, false); else GC_FIR(false, false); }
+#undef GC_FIR
         return gc::check_launch("gc_upfirdn2d_f32(fir44_tile)");
     }
     const bool square44 = kh == 4 && kw == 4 && up_x == up_y && down_x == down_y && planes <= 65535 && out_w >= 32 && out_h >= 8;
@@ -348,4 +381,24 @@ extern "C" int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
     hipLaunchKernelGGL(generic_kernel, dim3(blocks), dim3(256), 0, s, x, taps, y, planes, in_h, in_w, out_h, out_w, kh, kw,
                        up_x, up_y, down_x, down_y, pad_x0, pad_y0, flip_taps);
     return gc::check_launch("gc_upfirdn2d_f32(generic)");
+}
+
+}  // namespace
+
+extern "C" int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
+                                int planes, int in_h, int in_w, int out_h, int out_w,
+                                int kh, int kw, int up_x, int up_y, int down_x, int down_y,
+                                int pad_x0, int pad_y0, int flip_taps, gc_stream_t stream) {
+    return upfirdn2d_impl(x, taps, y, planes, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, flip_taps, nullptr, stream);
+}
+
+extern "C" int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,
+                                    int batch, int channels, int in_h, int in_w, int out_h, int out_w,
+                                    int kh, int kw, int pad_x0, int pad_y0, int flip_taps,
+                                    const float* bias, const float* noise, const float* noise_w, float slope, float gain,
+                                    gc_stream_t stream) {
+    if ((noise == nullptr) != (noise_w == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_act_f32: noise and noise_w must both be set or both be null");
+    if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_act_f32: bad batch / channels");
+    const FirEpilogue ep{bias, noise, noise_w, slope, gain, channels};
+    return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, &ep, stream);
 }

@@ -34,6 +34,7 @@ SIGNATURES = {
     'gc_abi_version': (_i32, []),
     'gc_last_error': (ctypes.c_char_p, []),
     'gc_upfirdn2d_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 14 + [_vp]),
+    'gc_upfirdn2d_act_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 11 + [_vp, _vp, _vp, _f32, _f32, _vp]),
     'gc_bias_act_f32': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _f32, _f32, _vp]),
     'gc_bias_act_bwd_f32': (_i32, [_vp, _vp, _vp, _i64, _f32, _f32, _vp]),
     'gc_bias_act_bwd_chunks': (_i32, [_i64]),

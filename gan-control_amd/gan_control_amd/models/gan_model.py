@@ -18,7 +18,8 @@ from torch.nn import functional as F
 
 import os
 _FUSE_EPILOGUE = os.environ.get('GANCONTROL_FUSE_EPILOGUE', '1') != '0'   # debugging knob: 0 = convolution and activation as two launches
-from .op import FusedLeakyReLU, fused_leaky_relu, upfirdn2d, conv2d_gradfix, modulated_conv2d, modulated_conv2d_act
+from .op import (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, upfirdn2d_bias_act, conv2d_gradfix, modulated_conv2d,
+                 modulated_conv2d_act)
 
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
 
@@ -198,6 +199,16 @@ class StyledConv(nn.Module):
             return modulated_conv2d_act(input, conv.weight, conv.modulation(style), act.bias, noise, self.noise.weight,
                                         demodulate=conv.demodulate, padding=conv.padding,
                                         negative_slope=act.negative_slope, act_scale=act.scale)
+        if _FUSE_EPILOGUE and conv.upsample:
+            # transposed conv, then Blur -> noise -> bias + leaky-ReLU in one launch (the activation runs in the FIR's epilogue)
+            out = modulated_conv2d(input, conv.weight, conv.modulation(style), demodulate=conv.demodulate, upsample=True, apply_blur=False)
+            if noise is None:
+                b, _, h, w = out.shape
+                p0, p1 = conv.blur.pad
+                kh, kw = conv.blur.kernel.shape
+                noise = out.new_empty(b, 1, h + p0 + p1 - kh + 1, w + p0 + p1 - kw + 1).normal_()
+            act = self.activate
+            return upfirdn2d_bias_act(out, conv.blur.kernel, conv.blur.pad, act.bias, noise, self.noise.weight, act.negative_slope, act.scale)
         out = conv(input, style)
         if noise is None:
             b, _, h, w = out.shape

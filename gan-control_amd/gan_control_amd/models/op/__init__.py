@@ -6,9 +6,9 @@ non_leaking.py:6, a package it does not ship).  This package provides those thre
 identical signatures, plus the convolutions the north star adds behind the same boundary.
 """
 from .fused_act import FusedLeakyReLU, fused_leaky_relu, fused_noise_bias_act
-from .upfirdn2d import upfirdn2d
+from .upfirdn2d import upfirdn2d, upfirdn2d_bias_act
 from . import conv2d_gradfix
 from .modulated_conv import modulated_conv2d, modulated_conv2d_act, demod_coefficients
 
-__all__ = ['FusedLeakyReLU', 'fused_leaky_relu', 'fused_noise_bias_act', 'upfirdn2d', 'conv2d_gradfix',
+__all__ = ['FusedLeakyReLU', 'fused_leaky_relu', 'fused_noise_bias_act', 'upfirdn2d', 'upfirdn2d_bias_act', 'conv2d_gradfix',
            'modulated_conv2d', 'modulated_conv2d_act', 'demod_coefficients']

@@ -57,6 +57,33 @@ class HipBackend:
             self.timer.stop(name, t0, 4.0 * (x.numel() + y.numel()))
         return y
 
+    @staticmethod
+    def upfirdn2d_act_supported(taps, up, down, out_h, out_w, planes):
+        """Shapes gc_upfirdn2d_act_f32 takes (the 4x4 tile kernel); everything else runs FIR and activation as two launches."""
+        return tuple(taps.shape) == (4, 4) and up == 1 and down == 1 and out_w >= 64 and out_h >= 16 and planes <= 65535
+
+    def upfirdn2d_act(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, bias, noise, noise_w, slope, gain):
+        """gain * lrelu(FIR(x) + noise_w * noise + bias); see gc_upfirdn2d_act_f32."""
+        dev = _lib.require_cuda_f32(x, taps, bias, noise, noise_w)
+        n, c, h, w = x.shape
+        y = torch.empty((n, c, out_h, out_w), dtype=x.dtype, device=dev)
+        if y.numel() == 0:
+            return y
+        lib = _lib.load()
+        g = self._guard(dev)
+        t0 = self.timer.start('fir44') if self.timer else None
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_upfirdn2d_act_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n, c, h, w, out_h, out_w, taps.shape[0], taps.shape[1],
+                                          pad_x0, pad_y0, int(flip), _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), float(slope), float(gain),
+                                          _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_upfirdn2d_act_f32')
+        if t0 is not None:
+            self.timer.stop('fir44_tile_kernel', t0, 4.0 * (x.numel() + y.numel()))
+        return y
+
     def bias_act(self, x, bias, noise, noise_w, slope, gain):
         """y = gain * lrelu(x + bias[c] + noise_w * noise[b, :]); x is [B, C, *]."""
         dev = _lib.require_cuda_f32(x, bias, noise, noise_w)

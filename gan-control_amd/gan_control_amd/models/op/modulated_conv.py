@@ -181,7 +181,7 @@ class _ModWGrad(Function):
         return (gx if ctx.needs_input_grad[0] else None), (ggy if ctx.needs_input_grad[1] else None), gsi, gso, None
 
 
-def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=None, blur_pad=None, padding=None):
+def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=None, blur_pad=None, padding=None, apply_blur=True):
     """x [B,IC,H,W]; weight [1,OC,IC,k,k] (the reference parameter layout); s [B,IC] = modulation(style).
 
     plain:    conv2d(padding = k // 2)                                    gan_model.py:325-329
@@ -194,7 +194,7 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
         w_t = kernel_layout(weight.view(oc, ic, k, k), scale, flip=True)                   # correlation form, [k,k,IC,OC]
         oh, ow = (x.shape[2] - 1) * 2 + k, (x.shape[3] - 1) * 2 + k
         y = _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 2, 1, k - 1, k - 1, oh, ow))
-        return upfirdn2d(y, blur_kernel, pad=blur_pad)
+        return upfirdn2d(y, blur_kernel, pad=blur_pad) if apply_blur else y     # apply_blur=False: the caller fuses the Blur with what follows
     pad = k // 2 if padding is None else padding
     w_t = kernel_layout(weight.view(oc, ic, k, k), scale)
     oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1

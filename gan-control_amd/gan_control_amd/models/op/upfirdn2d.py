@@ -53,3 +53,60 @@ class _UpFirDn2dAdjoint(Function):
 
 def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
     return _UpFirDn2d.apply(input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
+
+
+class _UpFirDn2dAct(Function):
+    """out = gain * lrelu(FIR(x) + noise_w * noise + bias) in one launch (gc_upfirdn2d_act_f32): Blur -> NoiseInjection ->
+    FusedLeakyReLU of an up-sampling StyledConv.  Backward = FusedLeakyReLU's (mask from the output, bias / noise-strength
+    sums in the same pass) followed by the FIR adjoint; every piece is a differentiable Function."""
+
+    @staticmethod
+    def forward(ctx, x, kernel, p0, p1, bias, noise, noise_w, slope, gain):
+        kh, kw = kernel.shape
+        n, c, h, w = x.shape
+        oh, ow = _out_size(h, kh, 1, 1, p0, p1), _out_size(w, kw, 1, 1, p0, p1)
+        out = _backend.get().upfirdn2d_act(x.contiguous(), kernel, p0, p0, oh, ow, True, bias, None if noise is None else noise.contiguous(), noise_w, slope, gain)
+        ctx.cfg, ctx.act = (1, 1, p0, p1, h, w), (slope, gain)
+        ctx.has_bias, ctx.has_noise = bias is not None, noise is not None
+        empty = x.new_empty(0)
+        ctx.save_for_backward(kernel, out, noise if noise is not None else empty, noise_w if noise_w is not None else empty)
+        return out
+
+    @staticmethod
+    def backward(ctx, gy):
+        from .fused_act import _BiasActGrad, _BiasActGradReduce
+        kernel, out, noise, noise_w = ctx.saved_tensors
+        slope, gain = ctx.act
+        need = ctx.needs_input_grad
+        gx = gb = gnw = None
+        want_b, want_nw = ctx.has_bias and need[4], ctx.has_noise and need[6]
+        if not (need[0] or want_b or want_nw):
+            return (None,) * 9
+        if want_b or want_nw:
+            g_pre, psum, pdot = _BiasActGradReduce.apply(gy, out, noise if want_nw else None, slope, gain)[:3]
+            if want_b:
+                gb = psum.sum((0, 2))
+            if want_nw:
+                gnw = pdot.sum().reshape(noise_w.shape)
+        else:
+            g_pre = _BiasActGrad.apply(gy, out, slope, gain)
+        if need[0]:
+            gx = _UpFirDn2dAdjoint.apply(g_pre, kernel, ctx.cfg)
+        return gx, None, None, None, gb, None, gnw, None, None
+
+
+def upfirdn2d_bias_act(input, kernel, pad, bias, noise=None, noise_weight=None, negative_slope=0.2, scale=2 ** 0.5):
+    """scale * lrelu(upfirdn2d(input, kernel, pad=pad) + noise_weight * noise + bias): one launch where the tile kernel applies,
+    otherwise upfirdn2d followed by fused_noise_bias_act."""
+    from .fused_act import fused_noise_bias_act
+    p0, p1 = int(pad[0]), int(pad[1])
+    kh, kw = kernel.shape
+    oh, ow = _out_size(input.shape[2], kh, 1, 1, p0, p1), _out_size(input.shape[3], kw, 1, 1, p0, p1)
+    if oh >= 1 and ow >= 1 and _backend.get().upfirdn2d_act_supported(kernel, 1, 1, oh, ow, input.shape[0] * input.shape[1]):
+        if (noise is None) != (noise_weight is None):
+            raise ValueError('noise and noise_weight go together')
+        if noise is not None and (noise.shape[0] != input.shape[0] or noise.numel() != input.shape[0] * oh * ow):
+            raise ValueError(f'noise shape {tuple(noise.shape)} does not match the output [{input.shape[0]}, {input.shape[1]}, {oh}, {ow}]')
+        return _UpFirDn2dAct.apply(input, kernel, p0, p1, None if bias is None else bias.reshape(-1).contiguous(), noise,
+                                   None if noise_weight is None else noise_weight.reshape(-1).contiguous(), float(negative_slope), float(scale))
+    return fused_noise_bias_act(upfirdn2d(input, kernel, pad=pad), bias, noise, noise_weight, negative_slope, scale)

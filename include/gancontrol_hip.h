@@ -60,6 +60,20 @@ int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
                      int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                      int pad_x0, int pad_y0, int flip_taps, gc_stream_t stream);
 
+/* K1 with the NoiseInjection + FusedLeakyReLU that follow the Blur of an up-sampling StyledConv
+ * (gan_model.py:295-307 then :402-408) applied before the result is stored:
+ *
+ *   y[b,c,o] = gain * lrelu( FIR(x)[b,c,o] + noise_w[0] * noise[b,o] + bias[c], slope )
+ *
+ * in the arithmetic order of gc_bias_act_f32 (bit-identical to the two-pass result, one write + one read of the tensor
+ * saved).  4x4 taps, up = down = 1, planes at least 64 x 16: GC_ERR_UNSUPPORTED otherwise (callers then run K1 + K2).
+ * bias ([channels]) may be NULL; noise ([batch, out_h*out_w]) and noise_w go together. */
+int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,
+                         int batch, int channels, int in_h, int in_w, int out_h, int out_w,
+                         int kh, int kw, int pad_x0, int pad_y0, int flip_taps,
+                         const float* bias, const float* noise, const float* noise_w, float slope, float gain,
+                         gc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * K2  fused (noise +) bias + leaky-ReLU * gain.
  *

@@ -68,6 +68,13 @@ class EmulatedBackend:
         y = F.conv2d(u.reshape(n * c, 1, u.shape[2], u.shape[3]), t.reshape(1, 1, kh, kw), stride=down)
         return y.reshape(n, c, out_h, out_w)
 
+    @staticmethod
+    def upfirdn2d_act_supported(taps, up, down, out_h, out_w, planes):
+        return tuple(taps.shape) == (4, 4) and up == 1 and down == 1 and out_w >= 64 and out_h >= 16 and planes <= 65535
+
+    def upfirdn2d_act(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, bias, noise, noise_w, slope, gain):
+        return self.bias_act(self.upfirdn2d(x, taps, 1, 1, pad_x0, pad_y0, out_h, out_w, flip), bias, noise, noise_w, slope, gain)
+
     def bias_act(self, x, bias, noise, noise_w, slope, gain):
         shape = [1, -1] + [1] * (x.ndim - 2)
         v = x

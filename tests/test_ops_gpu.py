@@ -207,6 +207,34 @@ def test_modulated_conv2d_act_matches_two_pass(mode):
         hip.conv_mode = prev
 
 
+@pytest.mark.parametrize('shape,pad', [((2, 5, 67, 131), (1, 1)), ((1, 3, 129, 129), (2, 2)), ((2, 4, 64, 64), (2, 1))])
+def test_upfirdn2d_fused_activation(shape, pad):
+    """gc_upfirdn2d_act_f32 == gc_upfirdn2d_f32 followed by gc_bias_act_f32, bit for bit; autograd equals the two-pass composition."""
+    from gan_control_amd.models.op import upfirdn2d, upfirdn2d_bias_act, fused_noise_bias_act
+    hip, _ = _be()
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=gen).to(DEV)
+    k = torch.randn(4, 4, generator=gen).to(DEV)
+    oh, ow = shape[2] + pad[0] + pad[1] - 3, shape[3] + pad[0] + pad[1] - 3
+    bias, nz, nw = torch.randn(shape[1], generator=gen).to(DEV), torch.randn(shape[0], 1, oh, ow, generator=gen).to(DEV), torch.randn(1, generator=gen).to(DEV)
+    plain = hip.upfirdn2d(x, k, 1, 1, pad[0], pad[0], oh, ow, True)
+    assert torch.equal(hip.upfirdn2d_act(x, k, pad[0], pad[0], oh, ow, True, bias, nz, nw, 0.2, 2 ** 0.5), hip.bias_act(plain, bias, nz, nw, 0.2, 2 ** 0.5))
+    assert torch.equal(hip.upfirdn2d_act(x, k, pad[0], pad[0], oh, ow, True, bias, None, None, 0.2, 2 ** 0.5), hip.bias_act(plain, bias, None, None, 0.2, 2 ** 0.5))
+    xs = [x.clone().requires_grad_(True) for _ in range(2)]
+    bs = [bias.clone().requires_grad_(True) for _ in range(2)]
+    ws = [nw.clone().requires_grad_(True) for _ in range(2)]
+    res = []
+    for i, fused in enumerate((True, False)):
+        y = upfirdn2d_bias_act(xs[i], k, pad, bs[i], nz, ws[i]) if fused else fused_noise_bias_act(upfirdn2d(xs[i], k, pad=pad), bs[i], nz, ws[i])
+        g1 = torch.autograd.grad(y.square().mean(), [xs[i], bs[i], ws[i]], retain_graph=True)
+        gx, = torch.autograd.grad(y.sum() + y.square().sum(), xs[i], create_graph=True)
+        g2 = torch.autograd.grad(gx.square().sum(), [xs[i], bs[i], ws[i]], allow_unused=True)
+        res.append([y.detach(), *g1, gx.detach()] + [t for t in g2 if t is not None])
+    assert len(res[0]) == len(res[1])
+    for a, c in zip(*res):
+        assert rel_err(a, c) < 1e-5
+
+
 CONV_CASES = [
     # b, K, N, h, w, k, up, down, pad
     (2, 8, 8, 4, 4, 3, 1, 1, 1), (2, 16, 130, 8, 8, 3, 1, 1, 1), (1, 40, 64, 16, 16, 3, 1, 1, 1),
