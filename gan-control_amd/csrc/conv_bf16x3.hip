@@ -581,9 +581,9 @@ __device__ __forceinline__ void split8v(const float (&v)[8], const float (&sc)[8
     *l = *reinterpret_cast<uint4*>(&ll);
 }
 
-template <int TR, int KS>
+template <int TR, int KS, int WK>
 struct WgS2Cfg {
-    static constexpr int KT = 64, NTL = 64;
+    static constexpr int KT = 32 * WK, NTL = 64;       // WK = 2: 64k x 64n, one 32 x 32 block per wave; WK = 1: 32k x 64n, two pixel-waves per block
     static constexpr int PH = (TR - 1) * 2 + KS;
     static constexpr int XE = KS == 3 ? 5 : 4, XO = KS == 3 ? 4 : 0, RU = XE + XO, YU = 4;
     static constexpr int NI = XE;                                    // 16-column staging items per row
@@ -596,9 +596,10 @@ struct WgS2Cfg {
 
 // TR = 2: 110 KB of LDS, one workgroup per CU with the whole register file; TR = 1: 64 KB, two per CU (the second hides the
 // staging phases of the first, but every input row is fetched 3 instead of 2.5 times): better on planes <= 128 wide.
-template <int TR, int KS>
-__global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
-    using C = WgS2Cfg<TR, KS>;
+template <int TR, int KS, int WK>
+__global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
+    using C = WgS2Cfg<TR, KS, WK>;
+    constexpr int WP = 2 / WK;              // waves sharing a (k, n) block: they split the half-rows and are summed at the end
     constexpr int KT = C::KT, NTL = C::NTL, PH = C::PH, XE = C::XE, RU = C::RU, YU = C::YU, NI = C::NI, NT = C::NT;
     __shared__ uint4 smem[C::SMEM_UNITS];
     uint4* xh = smem;
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void wgrad_bf16x3_s2_kernel(W
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wk = wave >> 1, wn = wave & 1;
+    const int wn = wave & 1, wk = WK == 2 ? wave >> 1 : 0, wp = WK == 2 ? 0 : wave >> 1;
     const int k0 = blockIdx.x * KT, n0 = blockIdx.y * NTL, split = blockIdx.z;
 
     f32x16 acc[NT];
@@ -714,10 +715,11 @@ __global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void wgrad_bf16x3_s2_kernel(W
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
             if (more) prefetch(tile + 1);
-#pragma unroll (TR == 1 ? 1 : 2)
+#pragma unroll ((TR == 1 || WK == 1) ? 1 : 2)
             for (int r = 0; r < TR; ++r) {
-#pragma unroll (TR == 1 ? 1 : 2)
-                for (int st = 0; st < 2; ++st) {
+#pragma unroll ((TR == 1 || WK == 1) ? 1 : 2)
+                for (int st_ = 0; st_ < 2 / WP; ++st_) {
+                    const int st = WP == 2 ? wp : st_;          // two pixel-waves: each takes one half-row
                     const uint4 ubh = yh[yb_ + r * YU + 2 * st], ubl = yl[yb_ + r * YU + 2 * st];
                     const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&ubh), bl = *reinterpret_cast<const bf16x8*>(&ubl);
 #pragma unroll
@@ -749,6 +751,23 @@ __global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void wgrad_bf16x3_s2_kernel(W
         }
     }
 
+    if (WP == 2) {
+        // the two pixel-waves of a (k, n) block hold partial sums: add them through LDS (the staging buffers are free now)
+        float* red = reinterpret_cast<float*>(smem) + wn * 16 * 64;
+        for (int t = 0; t < NT; ++t) {
+            __syncthreads();
+            if (wp == 1) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[r * 64 + lane] = acc[t][r];
+            }
+            __syncthreads();
+            if (wp == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[t][r] += red[r * 64 + lane];
+            }
+        }
+        if (wp != 0) return;
+    }
     float* out = p.ws + (size_t)split * NT * p.K * p.N;
     const int n = n0 + wn * 32 + l31;
     if (n < p.N) {
@@ -763,7 +782,7 @@ __global__ __launch_bounds__(256, TR == 1 ? 2 : 1) void wgrad_bf16x3_s2_kernel(W
     }
 }
 
-struct WgPlan { int small, ct, tr, splits, tiles_per_split, tiles_x, tiles_y; };
+struct WgPlan { int small, ct, kt, tr, splits, tiles_per_split, tiles_x, tiles_y; };
 
 // 64k x 64n tiles (2 rows per pixel tile) when both channel counts reach 64, else 32k x 32n tiles with the four
 // waves splitting the pixel steps of a 4-row tile
@@ -771,12 +790,13 @@ WgPlan plan_wg(const gc_conv_desc* d) {
     WgPlan pl;
     pl.small = d->down == 1 && !(d->in_ch >= 64 && d->out_ch >= 64);
     pl.ct = pl.small ? 32 : 64;
+    pl.kt = (d->down == 2 && d->in_ch < 64) ? 32 : pl.ct;      // stride 2 with 32..63 input channels: 32k x 64n tiles
     pl.tr = pl.small ? 4 : 2;
-    if (d->down == 2 && d->out_w <= 128) pl.tr = 1;     // stride 2, small planes: one output row per tile, two workgroups per CU
+    if (d->down == 2 && d->out_w <= 128 && pl.kt == 64) pl.tr = 1;     // stride 2, small planes: one output row per tile, two workgroups per CU
     pl.tiles_x = gc::ceil_div(d->out_w, 32);
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
-    const int ctiles = gc::ceil_div(d->in_ch, pl.ct) * gc::ceil_div(d->out_ch, pl.ct);
+    const int ctiles = gc::ceil_div(d->in_ch, pl.kt) * gc::ceil_div(d->out_ch, pl.ct);
     int want = gc::ceil_div(512, ctiles);      // one workgroup per CU is resident (512 registers per lane): two rounds
     if (want > total) want = total;
     if (want < 1) want = 1;
@@ -788,7 +808,7 @@ WgPlan plan_wg(const gc_conv_desc* d) {
 bool wg_eligible(const gc_conv_desc* d) {
     if (d->up != 1 || d->out_w <= 16) return false;
     if (d->down == 1) return d->in_ch >= 32 && d->out_ch >= 32 && d->pad_x >= 0 && d->pad_x <= 1;
-    return d->in_ch >= 64 && d->out_ch >= 64 && d->pad_x == 0 && d->pad_y == 0;      // stride-2 kernel: 64 x 64 tiles, no padding
+    return d->in_ch >= 32 && d->out_ch >= 64 && d->pad_x == 0 && d->pad_y == 0;      // stride-2 kernel: 64 (or 32) k x 64 n tiles, no padding
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1139,14 +1159,17 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
     hipStream_t s = (hipStream_t)stream;
     WgArgs a{x, dy, in_scale, out_scale, pl.splits == 1 ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch,
              d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
-    dim3 grid(gc::ceil_div(d->in_ch, pl.ct), gc::ceil_div(d->out_ch, pl.ct), pl.splits);
+    dim3 grid(gc::ceil_div(d->in_ch, pl.kt), gc::ceil_div(d->out_ch, pl.ct), pl.splits);
     if (d->down == 2) {
-        if (pl.tr == 1) {
-            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 3>), grid, dim3(256), 0, s, a);
-            else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 1>), grid, dim3(256), 0, s, a);
+        if (pl.kt == 32) {
+            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 3, 1>), grid, dim3(256), 0, s, a);
+            else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 1, 1>), grid, dim3(256), 0, s, a);
+        } else if (pl.tr == 1) {
+            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 3, 2>), grid, dim3(256), 0, s, a);
+            else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 1, 2>), grid, dim3(256), 0, s, a);
         } else {
-            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 3>), grid, dim3(256), 0, s, a);
-            else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 1>), grid, dim3(256), 0, s, a);
+            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 3, 2>), grid, dim3(256), 0, s, a);
+            else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 1, 2>), grid, dim3(256), 0, s, a);
         }
     } else if (pl.small) {
         if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 4, 3>), grid, dim3(256), 0, s, a);

@@ -348,6 +348,7 @@ BF16_CASES = CONV_CASES + [
     (1, 64, 40, 32, 48, 3, 2, 1, 2), (2, 24, 70, 20, 33, 3, 2, 1, 2), (2, 16, 5, 40, 40, 1, 2, 1, 0), (1, 513, 40, 40, 40, 3, 1, 1, 1),
     (1, 32, 32, 30, 30, 3, 2, 1, 0), (1, 24, 40, 40, 33, 3, 2, 1, 1), (2, 64, 64, 64, 64, 3, 2, 1, 2), (1, 128, 32, 33, 70, 3, 2, 1, 2),
     (1, 64, 64, 63, 63, 1, 1, 2, 0), (2, 64, 96, 41, 77, 3, 1, 2, 0), (1, 128, 64, 129, 65, 3, 1, 2, 0), (1, 32, 32, 64, 96, 3, 1, 1, 1),
+    (1, 32, 64, 65, 97, 3, 1, 2, 0), (2, 48, 70, 41, 77, 3, 1, 2, 0), (1, 40, 64, 63, 63, 1, 1, 2, 0), (1, 32, 64, 257, 259, 3, 1, 2, 0),
 ]
 
 
