@@ -607,6 +607,7 @@ int gcconv::conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w,
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_f32: null pointer");
     if ((rc = validate_epilogue(ep, "gc_conv2d_f32"))) return rc;
     if (d->batch == 0) return GC_OK;
+    if (pointwise_thin(d)) return pointwise_conv(d, x, w, in_scale, out_scale, ep, y, stream);
     ConvArgs a{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
                d->pad_y, d->pad_x, 0, 0};
     set_epilogue(a, ep);
@@ -649,6 +650,7 @@ extern "C" int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float*
 
 extern "C" size_t gc_conv2d_wgrad_workspace(const gc_conv_desc* d) {
     if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->out_h <= 0 || d->out_w <= 0) return 0;
+    if (pointwise_thin(d)) return pointwise_wgrad_workspace(d);
     const WgradPlan pl = plan_wgrad(d);
     return (size_t)pl.parts * d->kh * d->kw * d->in_ch * d->out_ch * sizeof(float);
 }
@@ -668,6 +670,7 @@ extern "C" int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const 
     const WgradPlan pl = plan_wgrad(d);
     const size_t need = gc_conv2d_wgrad_workspace(d);
     if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+    if (pointwise_thin(d)) return pointwise_wgrad(d, x, dy, in_scale, out_scale, dw, workspace, stream);
     WgradArgs a{x, dy, in_scale, out_scale, pl.parts == 1 ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w,
                 d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
     if (d->kh == 3) rc = d->down == 2 ? dispatch_wgrad<2, 3>(a, pl, s) : dispatch_wgrad<1, 3>(a, pl, s);

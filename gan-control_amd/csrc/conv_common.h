@@ -135,6 +135,14 @@ __device__ __forceinline__ uint4 buf_load_u128(__amdgpu_buffer_rsrc_t r, unsigne
 // serialises the pipeline.  simm16 = vmcnt(0) with expcnt / lgkmcnt left at their maxima.
 __device__ __forceinline__ void wait_staged_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
+// defined in pointwise.hip: 1x1 convolutions with <= 4 channels on one side (ToRGB / FromRGB) on the vector ALUs
+bool pointwise_thin(const gc_conv_desc* d);
+int pointwise_conv(const gc_conv_desc* d, const float* x, const float* w, const float* in_scale, const float* out_scale,
+                   const gc_conv_epilogue* ep, float* y, gc_stream_t stream);
+size_t pointwise_wgrad_workspace(const gc_conv_desc* d);
+int pointwise_wgrad(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale,
+                    float* dw, void* workspace, gc_stream_t stream);
+
 // defined in conv.hip: the fp32 convolution with an optional workspace (split-K over the input channels on small planes)
 size_t conv2d_f32_workspace(const gc_conv_desc* d);
 int conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w, const float* in_scale, const float* out_scale,

@@ -1,0 +1,254 @@
+// K3/K4 for 1x1 convolutions with at most 4 channels on one side: ToRGB (C -> 3, gan_model.py:411-435), the discriminator's
+// FromRGB ConvLayer (3 -> C, gan_model.py:955) and their gradients.  A matrix tile would be >= 87 % padding there and these
+// layers are pure HBM streams (the wide side is a [B, C, 1024, 1024] tensor), so they run on the vector ALUs: one lane owns
+// 4 consecutive pixels (16-byte loads / stores), the <= 4 x C weights come through the scalar cache.
+//   pw_narrow_kernel   y[b,j,p] = A(so[b,j] * sum_k w[k,j] si[b,k] x[b,k,p] + ...)      j < NOUT <= 4   (read-bound)
+//   pw_widen_kernel    y[b,n,p] = A(so[b,n] * sum_j w[j,n] si[b,j] x[b,j,p] + ...)      j < KIN <= 4    (write-bound)
+//   pw_wgrad_kernel    dw[k,n]  = sum_{b,p} si[b,k] x[b,k,p] so[b,n] dy[b,n,p]          min(K, N) <= 4  (read-bound)
+// All three keep the fused epilogue of gc_conv_epilogue; the weight gradient is reduced in a fixed order (no atomics).
+#include <algorithm>
+
+#include "conv_common.h"
+
+namespace {
+
+using namespace gcconv;
+
+constexpr int MAXS = 4;          // channels on the thin side
+constexpr int CHUNK = 16;        // wide-side channels whose loads are in flight together
+
+struct PwArgs {
+    ConvArgs c;
+    long long plane;             // pixels per channel plane
+    int vec;                     // planes are multiples of 4 pixels and 16-byte aligned
+};
+
+template <bool VEC>
+__device__ __forceinline__ float4 ld4(const float* p, long long i, long long n) {
+    if (VEC) return *reinterpret_cast<const float4*>(p + i);
+    return make_float4(i < n ? p[i] : 0.f, i + 1 < n ? p[i + 1] : 0.f, i + 2 < n ? p[i + 2] : 0.f, i + 3 < n ? p[i + 3] : 0.f);
+}
+template <bool VEC>
+__device__ __forceinline__ void st4(float* p, long long i, long long n, float4 v) {
+    if (VEC) { *reinterpret_cast<float4*>(p + i) = v; return; }
+    if (i < n) p[i] = v.x;
+    if (i + 1 < n) p[i + 1] = v.y;
+    if (i + 2 < n) p[i + 2] = v.z;
+    if (i + 3 < n) p[i + 3] = v.w;
+}
+__device__ __forceinline__ float4 fma4(float s, float4 a, float4 c) {
+    return make_float4(fmaf(s, a.x, c.x), fmaf(s, a.y, c.y), fmaf(s, a.z, c.z), fmaf(s, a.w, c.w));
+}
+
+// grid: (pixel groups, batch); w is [K, N] (1x1 taps)
+template <bool VEC>
+__global__ __launch_bounds__(256) void pw_narrow_kernel(PwArgs a) {
+    const ConvArgs& p = a.c;
+    const int b = blockIdx.y;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= a.plane) return;
+    const float* xb = p.x + (size_t)b * p.K * a.plane;
+    float4 acc[MAXS];
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k0 = 0; k0 < p.K; k0 += CHUNK) {
+        float4 v[CHUNK];
+#pragma unroll
+        for (int q = 0; q < CHUNK; ++q) v[q] = ld4<VEC>(xb + (size_t)min(k0 + q, p.K - 1) * a.plane, i, a.plane);     // clamped: the scale below is 0 past K
+#pragma unroll
+        for (int q = 0; q < CHUNK; ++q) {
+            const int k = min(k0 + q, p.K - 1);
+            const float s = (k0 + q < p.K) ? (p.si ? p.si[(size_t)b * p.K + k] : 1.f) : 0.f;
+#pragma unroll
+            for (int j = 0; j < MAXS; ++j)
+                if (j < p.N) acc[j] = fma4(p.w[(size_t)k * p.N + j] * s, v[q], acc[j]);
+        }
+    }
+    const EpilogueConsts ec = epilogue_consts(p);
+    const float4 nz = p.noise ? ld4<VEC>(p.noise + (size_t)b * a.plane, i, a.plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float so[MAXS], bs[MAXS];
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+        so[j] = (p.so && j < p.N) ? p.so[(size_t)b * p.N + j] : 1.f;
+        bs[j] = (p.bias && j < p.N) ? p.bias[j] : 0.f;
+    }
+    float* yb = p.y + (size_t)b * p.N * a.plane;
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j)
+        if (j < p.N)
+            st4<VEC>(yb + (size_t)j * a.plane, i, a.plane,
+                make_float4(conv_epilogue(ec, acc[j].x, so[j], bs[j], nz.x), conv_epilogue(ec, acc[j].y, so[j], bs[j], nz.y),
+                            conv_epilogue(ec, acc[j].z, so[j], bs[j], nz.z), conv_epilogue(ec, acc[j].w, so[j], bs[j], nz.w)));
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void pw_widen_kernel(PwArgs a) {
+    const ConvArgs& p = a.c;
+    const int b = blockIdx.y;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= a.plane) return;
+    const float* xb = p.x + (size_t)b * p.K * a.plane;
+    float4 xs[MAXS];
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j) {
+        xs[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (j < p.K) {
+            const float4 v = ld4<VEC>(xb + (size_t)j * a.plane, i, a.plane);
+            const float s = p.si ? p.si[(size_t)b * p.K + j] : 1.f;
+            xs[j] = make_float4(v.x * s, v.y * s, v.z * s, v.w * s);
+        }
+    }
+    const EpilogueConsts ec = epilogue_consts(p);
+    const float4 nz = p.noise ? ld4<VEC>(p.noise + (size_t)b * a.plane, i, a.plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+    float* yb = p.y + (size_t)b * p.N * a.plane;
+    // per-channel factors are uniform (scalar loads): they do not sit between the stores as vector loads would
+    for (int n = 0; n < p.N; ++n) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < MAXS; ++j)
+            if (j < p.K) acc = fma4(p.w[(size_t)j * p.N + n], xs[j], acc);
+        const float so = p.so ? p.so[(size_t)b * p.N + n] : 1.f, bs = p.bias ? p.bias[n] : 0.f;
+        st4<VEC>(yb + (size_t)n * a.plane, i, a.plane,
+            make_float4(conv_epilogue(ec, acc.x, so, bs, nz.x), conv_epilogue(ec, acc.y, so, bs, nz.y),
+                        conv_epilogue(ec, acc.z, so, bs, nz.z), conv_epilogue(ec, acc.w, so, bs, nz.w)));
+    }
+}
+
+// Weight gradient: thin side S (<= 4 planes of `thin`), wide side L planes of `wide`; part[block][l][s] partial sums.
+struct PwWgArgs {
+    const float* thin; const float* wide; const float* st; const float* sw;     // tensors and their per-sample scales ([B, S] / [B, L])
+    float* part;
+    int B, S, L;
+    long long plane; int vec; int groups_per_block; int thin_is_x;
+};
+
+template <bool VEC>
+__global__ __launch_bounds__(256) void pw_wgrad_kernel(PwWgArgs a) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long groups = (a.plane + 3) / 4;                       // 4-pixel groups per plane
+    const long long g_begin = (long long)blockIdx.x * a.groups_per_block, g_end = min(groups, g_begin + a.groups_per_block);
+    float* out = a.part + (size_t)(blockIdx.y * gridDim.x + blockIdx.x) * a.L * a.S;
+    const int b = blockIdx.y;
+    float ts[MAXS];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) ts[s] = (a.st && s < a.S) ? a.st[(size_t)b * a.S + s] : 1.f;
+    for (int l0 = 0; l0 < a.L; l0 += CHUNK) {
+        float acc[CHUNK][MAXS];
+#pragma unroll
+        for (int q = 0; q < CHUNK; ++q)
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) acc[q][s] = 0.f;
+        for (long long g = g_begin + threadIdx.x; g < g_end; g += 256) {
+            const long long i = g * 4;
+            float4 t[MAXS];
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) t[s] = ld4<VEC>(a.thin + ((size_t)b * a.S + min(s, a.S - 1)) * a.plane, i, a.plane);   // clamped duplicates are never written
+            float4 v[CHUNK];
+#pragma unroll
+            for (int q = 0; q < CHUNK; ++q) v[q] = ld4<VEC>(a.wide + ((size_t)b * a.L + min(l0 + q, a.L - 1)) * a.plane, i, a.plane);
+#pragma unroll
+            for (int q = 0; q < CHUNK; ++q)
+#pragma unroll
+                for (int s = 0; s < MAXS; ++s)
+                    acc[q][s] += v[q].x * t[s].x + v[q].y * t[s].y + v[q].z * t[s].z + v[q].w * t[s].w;
+        }
+        // fixed-order block reduction: lanes (shuffles), then the four waves through LDS
+#pragma unroll
+        for (int q = 0; q < CHUNK; ++q)
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {
+                float r = acc[q][s];
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) r += __shfl_down(r, o, 64);
+                if (lane == 0) red[wave][q * MAXS + s] = r;
+            }
+        __syncthreads();
+        if (threadIdx.x < CHUNK * MAXS) {
+            const int q = threadIdx.x / MAXS, s = threadIdx.x % MAXS;
+            if (l0 + q < a.L && s < a.S) {
+                const float sum = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+                const float sw = a.sw ? a.sw[(size_t)b * a.L + l0 + q] : 1.f;
+                // dw order [k][n]: the thin side is k when it is x, n when it is dy
+                out[a.thin_is_x ? (size_t)s * a.L + l0 + q : (size_t)(l0 + q) * a.S + s] = sum * ts[s] * sw;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// dw[e] = sum over parts (fixed order: lane i adds parts i, i + 64, ...; then a shuffle tree).  One wave per output element:
+// a serial loop over ~10^2..10^3 parts in a single lane would be a chain of dependent loads.
+__global__ __launch_bounds__(64) void pw_wgrad_finish_kernel(const float* __restrict__ part, float* __restrict__ dw, int parts, int count) {
+    const int e = blockIdx.x;
+    float s = 0.f;
+    for (int pt = threadIdx.x; pt < parts; pt += 64) s += part[(size_t)pt * count + e];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+    if (threadIdx.x == 0) dw[e] = s;
+}
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+int wgrad_blocks(long long plane) {
+    const long long groups = (plane + 3) / 4;
+    return (int)std::min<long long>(std::max<long long>(groups / 2048, 1), 128);      // >= 8 groups per lane, <= 128 blocks per sample
+}
+
+}  // namespace
+
+bool gcconv::pointwise_thin(const gc_conv_desc* d) {
+    // only where the launch is a bandwidth problem: one lane per 4 pixels must still fill the chip (>= 256 workgroups);
+    // the low-resolution ToRGB layers (512 channels, <= 128 x 128) stay on the matrix kernels with their split over K
+    return d && d->kh == 1 && d->kw == 1 && d->up == 1 && d->down == 1 && d->pad_x == 0 && d->pad_y == 0 &&
+           (d->in_ch <= MAXS || d->out_ch <= MAXS) && d->batch <= 65535 &&
+           (long long)d->out_h * d->out_w * d->batch >= (1LL << 18);
+}
+
+int gcconv::pointwise_conv(const gc_conv_desc* d, const float* x, const float* w, const float* in_scale, const float* out_scale,
+                           const gc_conv_epilogue* ep, float* y, gc_stream_t stream) {
+    PwArgs a;
+    a.c = ConvArgs{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w, 0, 0, 0, 0};
+    set_epilogue(a.c, ep);
+    a.c.k_per_split = 0; a.c.part = nullptr;
+    a.plane = (long long)d->out_h * d->out_w;
+    a.vec = a.plane % 4 == 0 && aligned16(x) && aligned16(y) && (!a.c.noise || aligned16(a.c.noise));
+    const long long groups = (a.plane + 3) / 4;
+    dim3 grid((unsigned)((groups + 255) / 256), d->batch);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->out_ch <= MAXS) {
+        if (a.vec) hipLaunchKernelGGL(pw_narrow_kernel<true>, grid, dim3(256), 0, s, a);
+        else       hipLaunchKernelGGL(pw_narrow_kernel<false>, grid, dim3(256), 0, s, a);
+    } else {
+        if (a.vec) hipLaunchKernelGGL(pw_widen_kernel<true>, grid, dim3(256), 0, s, a);
+        else       hipLaunchKernelGGL(pw_widen_kernel<false>, grid, dim3(256), 0, s, a);
+    }
+    return gc::check_launch("gc_conv2d_f32(pointwise)");
+}
+
+size_t gcconv::pointwise_wgrad_workspace(const gc_conv_desc* d) {
+    return (size_t)wgrad_blocks((long long)d->out_h * d->out_w) * d->batch * d->in_ch * d->out_ch * sizeof(float);
+}
+
+int gcconv::pointwise_wgrad(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale,
+                            float* dw, void* workspace, gc_stream_t stream) {
+    PwWgArgs a;
+    const bool thin_is_x = d->in_ch <= MAXS;
+    a.thin = thin_is_x ? x : dy; a.wide = thin_is_x ? dy : x;
+    a.st = thin_is_x ? in_scale : out_scale; a.sw = thin_is_x ? out_scale : in_scale;
+    a.S = thin_is_x ? d->in_ch : d->out_ch; a.L = thin_is_x ? d->out_ch : d->in_ch;
+    a.B = d->batch; a.thin_is_x = thin_is_x ? 1 : 0;
+    a.plane = (long long)d->out_h * d->out_w;
+    a.vec = a.plane % 4 == 0 && aligned16(x) && aligned16(dy);
+    a.part = static_cast<float*>(workspace);
+    const int blocks = wgrad_blocks(a.plane);
+    a.groups_per_block = (int)(((a.plane + 3) / 4 + blocks - 1) / blocks);
+    hipStream_t s = (hipStream_t)stream;
+    if (a.vec) hipLaunchKernelGGL(pw_wgrad_kernel<true>, dim3(blocks, d->batch), dim3(256), 0, s, a);
+    else       hipLaunchKernelGGL(pw_wgrad_kernel<false>, dim3(blocks, d->batch), dim3(256), 0, s, a);
+    int rc = gc::check_launch("gc_conv2d_wgrad_f32(pointwise)");
+    if (rc) return rc;
+    const int kn = d->in_ch * d->out_ch;
+    hipLaunchKernelGGL(pw_wgrad_finish_kernel, dim3(kn), dim3(64), 0, s, a.part, dw, blocks * d->batch, kn);
+    return gc::check_launch("gc_conv2d_wgrad_f32(pointwise finish)");
+}

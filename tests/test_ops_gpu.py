@@ -349,6 +349,9 @@ BF16_CASES = CONV_CASES + [
     (1, 32, 32, 30, 30, 3, 2, 1, 0), (1, 24, 40, 40, 33, 3, 2, 1, 1), (2, 64, 64, 64, 64, 3, 2, 1, 2), (1, 128, 32, 33, 70, 3, 2, 1, 2),
     (1, 64, 64, 63, 63, 1, 1, 2, 0), (2, 64, 96, 41, 77, 3, 1, 2, 0), (1, 128, 64, 129, 65, 3, 1, 2, 0), (1, 32, 32, 64, 96, 3, 1, 1, 1),
     (1, 32, 64, 65, 97, 3, 1, 2, 0), (2, 48, 70, 41, 77, 3, 1, 2, 0), (1, 40, 64, 63, 63, 1, 1, 2, 0), (1, 32, 64, 257, 259, 3, 1, 2, 0),
+    (2, 3, 40, 67, 129, 1, 1, 1, 0), (2, 40, 3, 67, 129, 1, 1, 1, 0), (3, 64, 4, 128, 128, 1, 1, 1, 0), (1, 1, 70, 33, 35, 1, 1, 1, 0), (2, 4, 2, 20, 20, 1, 1, 1, 0),
+    # planes large enough for the vector-ALU pointwise kernels (csrc/pointwise.hip): aligned and ragged
+    (4, 32, 3, 256, 256, 1, 1, 1, 0), (4, 3, 32, 256, 256, 1, 1, 1, 0), (1, 3, 33, 515, 511, 1, 1, 1, 0), (2, 20, 2, 363, 365, 1, 1, 1, 0),
 ]
 
 
