@@ -62,7 +62,17 @@ struct BCfg {
     static constexpr int TPH = WG_PX * WPX;                 // tile rows (each 32-pixel MFMA column block is one row segment)
     static constexpr int NT1 = UP == 1 ? KS : (KS + UP - 1) / UP;
     static constexpr int PH = (TPH - 1) * DOWN + NT1, PWD = 31 * DOWN + NT1;
-    static constexpr int PLANE = PH * PWD;                  // units per channel group
+    // Column order of a patch row in LDS.  Stride 2: de-interleaved (even columns, then odd), so that lane l's fragment
+    // read of column 2 l + tap is a run of consecutive 16-byte units -- row-major order spent 41 % of the LDS cycles in
+    // bank conflicts there (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE), de-interleaved 15 %, kernel -3 %.  Stride 1 stays
+    // row-major: its reads are conflict-free, and none of the de-interleaved variants measured (by 2 / by 4, pitches
+    // 17..20 / 9..12) moved the kernel time by more than the noise although they change the conflict count by 2.4x:
+    // the LDS is not what bounds that kernel.  Column c sits at unit (c % DI) * Q + c / DI.
+    static constexpr int DI = DOWN == 1 ? 1 : 2;
+    static constexpr int Q = DOWN == 1 ? PWD : (PWD + 1) / 2;
+    static constexpr int RP = DI * Q;                       // row pitch in units
+    static constexpr int PLANE = PH * RP;                   // units per channel group
+    __device__ static __forceinline__ int ucol(int c) { return (c % DI) * Q + c / DI; }
     static constexpr int WUNITS = NT1 * NT1 * KG * OCT;     // weight units per chunk (per hi / lo)
     static constexpr int PUNITS = KG * PLANE;
     static constexpr int SMEM_UNITS = 2 * (WUNITS + PUNITS);
@@ -144,7 +154,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
 
     int boff[WPX];
 #pragma unroll
-    for (int j = 0; j < WPX; ++j) boff[j] = hi * PLANE + (wave_px * WPX + j) * DOWN * PWD + l31 * DOWN;
+    for (int j = 0; j < WPX; ++j) boff[j] = hi * PLANE + (wave_px * WPX + j) * DOWN * C::RP;      // row of this lane's pixels (tap row 0)
+
     const int aoff = hi * OCT + wave_oc * WOC * 32 + l31;
 
     const float* xb = p.x + (size_t)b * p.K * p.in_h * p.in_w;
@@ -207,8 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
         for (int j = 0; j < C::NT; ++j) {
             const typename C::Task tk = C::task_of(tb + 128 * j, lead);
             const int inrow = p.in_w - (ix0 + tk.col);               // pixels of this group that are still inside the image row
-            uint4* dh = &p_h[kgl * PLANE + tk.row * PWD + tk.col];
-            uint4* dl = &p_l[kgl * PLANE + tk.row * PWD + tk.col];
+            const int rbase = kgl * PLANE + tk.row * C::RP;
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 bf16x8 h, l;
@@ -221,8 +231,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
                     l[q] = (__bf16)(v - (float)hh);
                 }
                 if (i < tk.used) {
-                    dh[i] = *reinterpret_cast<uint4*>(&h);
-                    dl[i] = *reinterpret_cast<uint4*>(&l);
+                    const int u = rbase + C::ucol(tk.col + i);
+                    p_h[u] = *reinterpret_cast<uint4*>(&h);
+                    p_l[u] = *reinterpret_cast<uint4*>(&l);
                 }
             }
         }
@@ -232,7 +243,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
         for (int jy = 0; jy < nty; ++jy) {
             for (int jx = 0; jx < ntx; ++jx) {
                 const int wbase = (jy * ntx + jx) * KG * OCT + aoff;
-                const int pbase = jy * PWD + jx;
+                const int pbase = jy * C::RP + C::ucol(l31 * DOWN + jx);      // LDS column of this lane's pixel under tap jx
                 bf16x8 ah[WOC], al[WOC], bh[WPX], bl[WPX];
 #pragma unroll
                 for (int i = 0; i < WOC; ++i) {
