@@ -250,13 +250,26 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvArgs p) {
         if (qy >= qh || qx >= qw) continue;
         const int oy = qy * UP + phy, ox = qx * UP + phx;
         const float nz = p.noise ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
+        float res[WOC][16];
+        if (p.residual) {           // fetched before the first store of this pixel row
+#pragma unroll
+            for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int oc = min(n0 + (wave_oc * WOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, p.N - 1);
+                    res[i][r] = p.residual[(((size_t)b * p.N + oc) * p.out_h + oy) * p.out_w + ox];
+                }
+        }
 #pragma unroll
         for (int i = 0; i < WOC; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ocl = (wave_oc * WOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (n0 + ocl < p.N)
-                    yb[((size_t)(n0 + ocl) * p.out_h + oy) * p.out_w + ox] = conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz);
+                if (n0 + ocl < p.N) {
+                    float v = conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz);
+                    if (p.residual) v += res[i][r];
+                    yb[((size_t)(n0 + ocl) * p.out_h + oy) * p.out_w + ox] = v;
+                }
             }
         }
     }
@@ -532,7 +545,7 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p, int slic
         const int n = (int)(bn % p.N), b = (int)(bn / p.N);
         const float so = p.so ? p.so[(size_t)b * p.N + n] : 1.f, bias = p.bias ? p.bias[n] : 0.f;
         const float nz = p.noise ? p.noise[(size_t)b * plane + o] : 0.f;
-        p.y[i] = conv_epilogue(ec, acc, so, bias, nz);
+        p.y[i] = conv_epilogue(ec, acc, so, bias, nz) + (p.residual ? p.residual[i] : 0.f);
     }
 }
 

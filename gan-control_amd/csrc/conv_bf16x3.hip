@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + (size_t)b * p.N * p.out_h * p.out_w, (unsigned)p.N * oplane);
     // store one finished tile (demodulation + fused epilogue) and clear the accumulators for the next
     const EpilogueConsts ec = epilogue_consts(p);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + (size_t)b * p.N * p.out_h * p.out_w : p.y, p.residual ? (unsigned)p.N * oplane : 0u);
     auto finish_tile = [&](int tile) {
         const int qy0 = (tile / p.tiles_x) * TPH, qx0 = (tile % p.tiles_x) * 32;
         const int n0 = opaque_s(n0_blk);          // recompute the channel offsets here rather than carry 64 of them across the loop
@@ -285,6 +286,14 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
             const bool inside = qy < qh && qx < qw;
             const unsigned voff = inside ? (unsigned)(oy * p.out_w + ox) * 4u + (unsigned)(4 * hi) * oplane : OOB;
             const float nz = (p.noise && inside) ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
+            float res[WOC][16];
+            if (p.residual) {       // all residual values of this pixel row are fetched before its first store (a load between stores waits for them)
+#pragma unroll
+                for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        res[i][r] = buf_load_f32(rres, voff, (unsigned)(n0 + (wave_oc_u * WOC + i) * 32 + (r & 3) + 8 * (r >> 2)) * oplane);
+            }
 #pragma unroll
             for (int i = 0; i < WOC; ++i) {
 #pragma unroll
@@ -292,7 +301,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
                     // a register row holds channel ocs in lanes 0..31 and ocs + 4 in lanes 32..63
                     const int ocl = (wave_oc * WOC + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const int ocs = n0 + (wave_oc_u * WOC + i) * 32 + (r & 3) + 8 * (r >> 2);
-                    const float v = conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz);
+                    float v = conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz);
+                    if (p.residual) v += res[i][r];
                     __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff, (int)((unsigned)ocs * oplane), 0);
                     acc[i][j][r] = 0.f;
                 }
@@ -1007,6 +1017,14 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
             const int oy = 2 * qy + (ph >> 1), ox = 2 * qx + (ph & 1);
             if (oy >= p.out_h || ox >= p.out_w) continue;
             const float nz = p.noise ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
+            float res[16];
+            if (EPI == 2 && p.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int oc = min(n0 + wave_oc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, p.N - 1);
+                    res[r] = p.residual[(((size_t)b * p.N + oc) * p.out_h + oy) * p.out_w + ox];
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ocl = wave_oc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
@@ -1014,6 +1032,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
                     float v = acc[ph][j][r];
                     if (EPI == 1) v *= s_so[ocl];
                     if (EPI == 2) v = conv_epilogue(ec, v, s_so[ocl], s_bias[ocl], nz);
+                    if (EPI == 2 && p.residual) v += res[r];
                     yb[((size_t)(n0 + ocl) * p.out_h + oy) * p.out_w + ox] = v;
                 }
             }
@@ -1030,7 +1049,7 @@ int launch_t(Bf16Args a, hipStream_t s) {
     const long long gx = (long long)a.c.tiles_x * a.c.tiles_y * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
     dim3 grid((unsigned)gx, gc::ceil_div(a.c.N, C::OCT));
-    const int epi = (a.c.bias || a.c.noise || a.c.act) ? 2 : (a.c.so ? 1 : 0);
+    const int epi = (a.c.bias || a.c.noise || a.c.act || a.c.residual) ? 2 : (a.c.so ? 1 : 0);
     if (epi == 2)      hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 2>), grid, dim3(256), 0, s, a);
     else if (epi == 1) hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 1>), grid, dim3(256), 0, s, a);
     else               hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 0>), grid, dim3(256), 0, s, a);

@@ -13,6 +13,7 @@ struct ConvArgs {
     // fused epilogue (gc_conv_epilogue): y = act(so * acc + noise_w * noise[b, pixel] + bias[n])
     const float* bias; const float* noise; const float* noise_w;
     float slope, gain; int act;
+    const float* residual;    // added after the activation (gc_conv_epilogue)
     // grid-level split over the input channels (conv_mfma_kernel, small planes): slice z handles channels
     // [z * k_per_split, min(K, (z + 1) * k_per_split)) and writes its raw partial sums to part + z * B*N*out_h*out_w
     int k_per_split; float* part;
@@ -25,6 +26,7 @@ inline void set_epilogue(ConvArgs& a, const gc_conv_epilogue* ep) {
     a.slope = ep ? ep->slope : 1.f;
     a.gain = ep ? ep->gain : 1.f;
     a.act = ep ? ep->activate : 0;
+    a.residual = ep ? ep->residual : nullptr;
 }
 
 inline int validate_epilogue(const gc_conv_epilogue* ep, const char* who) {
@@ -47,6 +49,7 @@ __device__ __forceinline__ EpilogueConsts epilogue_consts(const ConvArgs& p) {
     return e;
 }
 __device__ __forceinline__ float conv_epilogue(const EpilogueConsts& e, float acc, float so, float bias, float nz) {
+#pragma clang fp contract(off)      // the products below are rounded on their own (as in bias_act.hip); a residual the caller adds must not fuse into them
     float v = acc * so;
     v = fmaf(e.nw, nz, v);
     v += bias;

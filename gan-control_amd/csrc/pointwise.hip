@@ -73,12 +73,16 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(PwArgs a) {
         bs[j] = (p.bias && j < p.N) ? p.bias[j] : 0.f;
     }
     float* yb = p.y + (size_t)b * p.N * a.plane;
+    float4 res[MAXS];
+#pragma unroll
+    for (int j = 0; j < MAXS; ++j)
+        res[j] = (p.residual && j < p.N) ? ld4<VEC>(p.residual + ((size_t)b * p.N + j) * a.plane, i, a.plane) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
     for (int j = 0; j < MAXS; ++j)
         if (j < p.N)
             st4<VEC>(yb + (size_t)j * a.plane, i, a.plane,
-                make_float4(conv_epilogue(ec, acc[j].x, so[j], bs[j], nz.x), conv_epilogue(ec, acc[j].y, so[j], bs[j], nz.y),
-                            conv_epilogue(ec, acc[j].z, so[j], bs[j], nz.z), conv_epilogue(ec, acc[j].w, so[j], bs[j], nz.w)));
+                make_float4(conv_epilogue(ec, acc[j].x, so[j], bs[j], nz.x) + res[j].x, conv_epilogue(ec, acc[j].y, so[j], bs[j], nz.y) + res[j].y,
+                            conv_epilogue(ec, acc[j].z, so[j], bs[j], nz.z) + res[j].z, conv_epilogue(ec, acc[j].w, so[j], bs[j], nz.w) + res[j].w));
 }
 
 template <bool VEC>
@@ -102,15 +106,25 @@ __global__ __launch_bounds__(256) void pw_widen_kernel(PwArgs a) {
     const float4 nz = p.noise ? ld4<VEC>(p.noise + (size_t)b * a.plane, i, a.plane) : make_float4(0.f, 0.f, 0.f, 0.f);
     float* yb = p.y + (size_t)b * p.N * a.plane;
     // per-channel factors are uniform (scalar loads): they do not sit between the stores as vector loads would
-    for (int n = 0; n < p.N; ++n) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    constexpr int RB = 8;             // residual rows fetched together, ahead of their stores
+    for (int n0 = 0; n0 < p.N; n0 += RB) {
+        float4 res[RB];
 #pragma unroll
-        for (int j = 0; j < MAXS; ++j)
-            if (j < p.K) acc = fma4(p.w[(size_t)j * p.N + n], xs[j], acc);
-        const float so = p.so ? p.so[(size_t)b * p.N + n] : 1.f, bs = p.bias ? p.bias[n] : 0.f;
-        st4<VEC>(yb + (size_t)n * a.plane, i, a.plane,
-            make_float4(conv_epilogue(ec, acc.x, so, bs, nz.x), conv_epilogue(ec, acc.y, so, bs, nz.y),
-                        conv_epilogue(ec, acc.z, so, bs, nz.z), conv_epilogue(ec, acc.w, so, bs, nz.w)));
+        for (int q = 0; q < RB; ++q)
+            res[q] = p.residual ? ld4<VEC>(p.residual + ((size_t)b * p.N + min(n0 + q, p.N - 1)) * a.plane, i, a.plane) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < RB; ++q) {
+            const int n = n0 + q;
+            if (n >= p.N) break;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < MAXS; ++j)
+                if (j < p.K) acc = fma4(p.w[(size_t)j * p.N + n], xs[j], acc);
+            const float so = p.so ? p.so[(size_t)b * p.N + n] : 1.f, bs = p.bias ? p.bias[n] : 0.f;
+            st4<VEC>(yb + (size_t)n * a.plane, i, a.plane,
+                make_float4(conv_epilogue(ec, acc.x, so, bs, nz.x) + res[q].x, conv_epilogue(ec, acc.y, so, bs, nz.y) + res[q].y,
+                            conv_epilogue(ec, acc.z, so, bs, nz.z) + res[q].z, conv_epilogue(ec, acc.w, so, bs, nz.w) + res[q].w));
+        }
     }
 }
 
@@ -212,7 +226,7 @@ int gcconv::pointwise_conv(const gc_conv_desc* d, const float* x, const float* w
     set_epilogue(a.c, ep);
     a.c.k_per_split = 0; a.c.part = nullptr;
     a.plane = (long long)d->out_h * d->out_w;
-    a.vec = a.plane % 4 == 0 && aligned16(x) && aligned16(y) && (!a.c.noise || aligned16(a.c.noise));
+    a.vec = a.plane % 4 == 0 && aligned16(x) && aligned16(y) && (!a.c.noise || aligned16(a.c.noise)) && (!a.c.residual || aligned16(a.c.residual));
     const long long groups = (a.plane + 3) / 4;
     dim3 grid((unsigned)((groups + 255) / 256), d->batch);
     hipStream_t s = (hipStream_t)stream;

@@ -26,7 +26,7 @@ class ConvDesc(ctypes.Structure):
 
 class ConvEpilogue(ctypes.Structure):
     """Mirror of ``gc_conv_epilogue``."""
-    _fields_ = [('bias', _vp), ('noise', _vp), ('noise_w', _vp), ('slope', _f32), ('gain', _f32), ('activate', _i32)]
+    _fields_ = [('bias', _vp), ('noise', _vp), ('noise_w', _vp), ('slope', _f32), ('gain', _f32), ('activate', _i32), ('residual', _vp)]
 
 
 # name -> (restype, argtypes); kept in one table so tests can check every exported symbol

@@ -408,26 +408,35 @@ class ConvLayer(nn.Sequential):
         self._decimating_fir = downsample and kernel_size == 1
         self._has_blur, self._activate = downsample, activate
 
-    def forward(self, input, out_gain=1.0):
-        """out_gain multiplies the layer's output; it is folded into the activation gain / the weight scale (no extra pass)."""
+    def forward(self, input, out_gain=1.0, residual=None, fork=False):
+        """out_gain multiplies the layer's output; it is folded into the activation gain / the weight scale (no extra pass).
+        residual (activation-free layers) is added in the convolution's epilogue.  fork=True returns (out, input') where
+        input' is the input for its second consumer: that consumer's gradient is then added inside this layer's
+        input-gradient convolution instead of by a separate elementwise pass."""
         out, idx = input, 0
         if self._has_blur:
             blur, idx = self[0], 1
             out = upfirdn2d(out, blur.kernel, down=2, pad=blur.pad) if self._decimating_fir else blur(out)
         conv = self[idx]
         stride = 1 if self._decimating_fir else conv.stride
+        if fork and not (self._activate and _FUSE_EPILOGUE and not self._has_blur):
+            raise NotImplementedError('ConvLayer: fork is built for the fused conv + activation layer without Blur only')
         if self._activate and _FUSE_EPILOGUE:
+            if residual is not None:
+                raise NotImplementedError('ConvLayer: residual after an activation is not built')
             # EqualConv2d -> FusedLeakyReLU in one launch: bias + leaky-ReLU run in the convolution's epilogue
             act = self[idx + 1]
             return conv2d_gradfix.conv2d_bias_act(out, conv.weight, act.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale,
-                                                  negative_slope=act.negative_slope, scale=act.scale * out_gain)
+                                                  negative_slope=act.negative_slope, scale=act.scale * out_gain, fork=fork)
         if self._activate:
             out = conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale)
             act = self[idx + 1]
-            return fused_leaky_relu(out, act.bias, act.negative_slope, act.scale * out_gain)
-        if conv.bias is not None and out_gain != 1.0:
-            raise NotImplementedError('ConvLayer: out_gain with a plain bias is not built')
-        return conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale * out_gain)
+            out = fused_leaky_relu(out, act.bias, act.negative_slope, act.scale * out_gain)
+            return out if residual is None else out + residual
+        if conv.bias is not None and (out_gain != 1.0 or residual is not None):
+            raise NotImplementedError('ConvLayer: out_gain / residual with a plain bias is not built')
+        return conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale * out_gain,
+                                     residual=residual)
 
 
 class ResBlock(nn.Module):
@@ -445,7 +454,13 @@ class ResBlock(nn.Module):
         # (conv2(conv1(x)) + skip(x)) / sqrt(2) with the 1/sqrt(2) folded into conv2's activation gain and the skip conv's
         # weight scale: one elementwise pass (the add) instead of two
         rs = 1.0 / math.sqrt(2)
-        return self.conv2(self.conv1(input), out_gain=rs) + self.skip(input, out_gain=rs)
+        if not _FUSE_EPILOGUE:
+            return self.conv2(self.conv1(input), out_gain=rs) + self.skip(input, out_gain=rs)
+        # Neither sum of this block is a pass of its own: `out + skip` is the residual epilogue of the skip convolution, and
+        # the two gradients of `input` (conv1 path, skip path) meet in the epilogue of conv1's input-gradient convolution
+        # (conv1 hands `input` on to the skip branch: fork).
+        out, forked = self.conv1(input, fork=True)
+        return self.skip(forked, out_gain=rs, residual=self.conv2(out, out_gain=rs))
 
 
 def minibatch_stddev(x, group_size=4, feat=1):

@@ -214,7 +214,7 @@ class HipBackend:
     def conv2d(self, x, w_t, in_scale, out_scale, geom, epilogue=None):
         """x [B,K,H,W], w_t [kh,kw,K,N] -> [B,N,out_h,out_w]; see gc_conv2d_fused_f32.
 
-        epilogue = (bias [N] | None, noise [B,1,oh,ow] | None, noise_w [1] | None, slope, gain, activate) or None.
+        epilogue = (bias [N] | None, noise [B,1,oh,ow] | None, noise_w [1] | None, slope, gain, activate[, residual [B,N,oh,ow] | None]) or None.
         """
         dev = _lib.require_cuda_f32(x, w_t, in_scale, out_scale)
         n_out = w_t.shape[3]
@@ -225,13 +225,16 @@ class HipBackend:
         lib = _lib.load()
         ep = None
         if epilogue is not None:
-            bias, noise, noise_w, slope, gain, activate = epilogue
-            _lib.require_cuda_f32(x, bias, noise, noise_w)
+            bias, noise, noise_w, slope, gain, activate = epilogue[:6]
+            residual = epilogue[6] if len(epilogue) > 6 else None
+            _lib.require_cuda_f32(x, bias, noise, noise_w, residual)
+            if residual is not None and tuple(residual.shape) != tuple(y.shape):
+                raise RuntimeError('conv2d epilogue: residual shape %s, output shape %s' % (tuple(residual.shape), tuple(y.shape)))
             if bias is not None and bias.numel() != n_out:
                 raise RuntimeError('conv2d epilogue: bias has %d elements, expected %d' % (bias.numel(), n_out))
             if noise is not None and noise.numel() != x.shape[0] * geom.out_h * geom.out_w:
                 raise RuntimeError('conv2d epilogue: noise has %d elements, expected %d' % (noise.numel(), x.shape[0] * geom.out_h * geom.out_w))
-            ep = ctypes.byref(_lib.ConvEpilogue(_lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), float(slope), float(gain), int(bool(activate))))
+            ep = ctypes.byref(_lib.ConvEpilogue(_lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), float(slope), float(gain), int(bool(activate)), _lib.ptr(residual)))
         ws = None
         if self.conv_mode == 'bf16x3':
             nbytes = lib.gc_conv2d_bf16x3_workspace(desc)

@@ -32,12 +32,16 @@ def _adjoint_weight(w_t):
 
 
 class _GConv(Function):
+    """y = gconv(x, w_t) [+ residual].  The residual rides in the convolution's epilogue (gc_conv_epilogue.residual): the
+    `out + skip` of a ResBlock, and on the backward side the gradient coming from the other consumer of a forked tensor."""
+
     @staticmethod
-    def forward(ctx, x, w_t, geom):
+    def forward(ctx, x, w_t, geom, residual=None):
         ctx.geom = geom
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.save_for_backward(x, w_t)
-        return _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None, None, geom)
+        ep = None if residual is None else (None, None, None, 1.0, 1.0, False, residual.contiguous())
+        return _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None, None, geom, epilogue=ep)
 
     @staticmethod
     def backward(ctx, gy):
@@ -48,7 +52,8 @@ class _GConv(Function):
             gx = _GConv.apply(gy, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw))
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(x, gy, g)
-        return gx, gw, None
+        want_res = len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3]
+        return (gx, gw, None, gy if want_res else None)[:len(ctx.needs_input_grad)]
 
 
 def _weight_grad(x, gy, g):
@@ -82,35 +87,42 @@ class _WGrad(Function):
 class _GConvAct(Function):
     """out = gain * lrelu(gconv(x, w_t) + bias): the activation runs in the convolution's epilogue (gc_conv_epilogue), so
     the pre-activation tensor is never written.  Backward = FusedLeakyReLU's (mask from the sign of the OUTPUT, bias
-    gradient reduced in the same pass) followed by _GConv's; every piece is a differentiable Function, so R1 closes."""
+    gradient reduced in the same pass) followed by _GConv's; every piece is a differentiable Function, so R1 closes.
+
+    fork=True additionally returns x itself as a second output for the OTHER consumer of x (the skip branch of a ResBlock).
+    That consumer's gradient then arrives here as the second output-gradient and is added inside the input-gradient
+    convolution (residual epilogue) instead of by autograd's separate elementwise add over the largest tensors of D.
+    """
 
     @staticmethod
-    def forward(ctx, x, w_t, bias, geom, slope, gain):
+    def forward(ctx, x, w_t, bias, geom, slope, gain, fork=False):
         out = _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None, None, geom, epilogue=(bias, None, None, slope, gain, True))
         ctx.geom, ctx.cfg = geom, (slope, gain)
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.save_for_backward(x, w_t, out)
-        return out
+        return (out, x.view_as(x)) if fork else out
 
     @staticmethod
-    def backward(ctx, gy):
+    def backward(ctx, gy, gfork=None):
         from .fused_act import _BiasActGrad, _BiasActGradReduce
         x, w_t, out = ctx.saved_tensors
         g = ctx.geom
         slope, gain = ctx.cfg
         gx = gw = gb = None
         if not any(ctx.needs_input_grad[:3]):
-            return None, None, None, None, None, None
+            return None, None, None, None, None, None, None
+        if gy is None:                      # only the forked copy was used downstream
+            return (gfork if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
         if ctx.needs_input_grad[2]:
             g_pre, psum = _BiasActGradReduce.apply(gy, out, None, slope, gain)[:2]
             gb = psum.sum((0, 2))
         else:
             g_pre = _BiasActGrad.apply(gy, out, slope, gain)
         if ctx.needs_input_grad[0]:
-            gx = _GConv.apply(g_pre, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw))
+            gx = _GConv.apply(g_pre, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw), gfork)
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(x, g_pre, g)
-        return gx, gw, gb, None, None, None
+        return gx, gw, gb, None, None, None, None
 
 
 def _pair(v):
@@ -128,12 +140,12 @@ def _check(input, weight, stride, padding, dilation, groups):
     return s[0], p[0]
 
 
-def conv2d_t(x, w_t, stride=1, padding=0):
-    """conv2d with the weight already in [kh, kw, IC, OC] layout."""
+def conv2d_t(x, w_t, stride=1, padding=0, residual=None):
+    """conv2d with the weight already in [kh, kw, IC, OC] layout (+ residual, added in the kernel's epilogue)."""
     kh, kw = w_t.shape[0], w_t.shape[1]
     oh = (x.shape[2] + 2 * padding - kh) // stride + 1
     ow = (x.shape[3] + 2 * padding - kw) // stride + 1
-    return _GConv.apply(x, w_t, ConvGeom(kh, kw, 1, stride, padding, padding, oh, ow))
+    return _GConv.apply(x, w_t, ConvGeom(kh, kw, 1, stride, padding, padding, oh, ow), residual)
 
 
 def conv_transpose2d_t(x, w_t, stride=1, padding=0):
@@ -144,17 +156,19 @@ def conv_transpose2d_t(x, w_t, stride=1, padding=0):
     return _GConv.apply(x, w_t, ConvGeom(kh, kw, stride, 1, kh - 1 - padding, kw - 1 - padding, oh, ow))
 
 
-def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_scale=1.0):
+def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_scale=1.0, residual=None):
     """Same call signature as torch.nn.functional.conv2d (weight [OC, IC, kh, kw]); weight_scale (an extension) folds
     the equalised-learning-rate factor into the layout pass instead of a separate ``weight * scale``."""
     s, p = _check(input, weight, stride, padding, dilation, groups)
     if weight.shape[1] != input.shape[1]:
         raise ValueError(f'conv2d: weight expects {weight.shape[1]} input channels, got {input.shape[1]}')
-    y = conv2d_t(input, kernel_layout(weight, weight_scale), s, p)
+    if residual is not None and bias is not None:
+        raise NotImplementedError('conv2d: residual together with a plain bias is not built')
+    y = conv2d_t(input, kernel_layout(weight, weight_scale), s, p, residual)
     return y if bias is None else y + bias.reshape(1, -1, 1, 1)
 
 
-def conv2d_bias_act(input, weight, bias, stride=1, padding=0, weight_scale=1.0, negative_slope=0.2, scale=2 ** 0.5):
+def conv2d_bias_act(input, weight, bias, stride=1, padding=0, weight_scale=1.0, negative_slope=0.2, scale=2 ** 0.5, fork=False):
     """scale * leaky_relu(conv2d(input, weight * weight_scale) + bias): EqualConv2d -> FusedLeakyReLU (ConvLayer,
     gan_model.py:844-890) as ONE kernel launch."""
     s, p = _check(input, weight, stride, padding, 1, 1)
@@ -166,7 +180,7 @@ def conv2d_bias_act(input, weight, bias, stride=1, padding=0, weight_scale=1.0, 
     oh = (input.shape[2] + 2 * p - kh) // s + 1
     ow = (input.shape[3] + 2 * p - kw) // s + 1
     return _GConvAct.apply(input, kernel_layout(weight, weight_scale), bias.reshape(-1).contiguous(),
-                           ConvGeom(kh, kw, 1, s, p, p, oh, ow), float(negative_slope), float(scale))
+                           ConvGeom(kh, kw, 1, s, p, p, oh, ow), float(negative_slope), float(scale), bool(fork))
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, weight_scale=1.0):

@@ -161,7 +161,12 @@ int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,
  * FusedLeakyReLU in ConvLayer gan_model.py:844-890; ModulatedConv2d -> NoiseInjection -> FusedLeakyReLU in StyledConv
  * gan_model.py:402-408; `+ self.bias` in ToRGB gan_model.py:430) applied to the accumulators before they are stored:
  *
- *   y[b,n,o] = A( out_scale[b,n] * sum(...) + noise_w[0] * noise[b,o] + bias[n] ),  A(v) = activate ? gain * lrelu(v, slope) : v
+ *   y[b,n,o] = A( out_scale[b,n] * sum(...) + noise_w[0] * noise[b,o] + bias[n] ) + residual[b,n,o],
+ *   A(v) = activate ? gain * lrelu(v, slope) : v
+ *
+ * `residual` (same shape as y, may be NULL) is the second operand of an add that follows the convolution: the
+ * `out + skip` of ResBlock.forward (gan_model.py:919-921) and -- on the backward side -- the gradient arriving from the
+ * other consumer of a tensor that feeds two layers (what autograd would sum with a separate elementwise pass).
  *
  * with the arithmetic of gc_bias_act_f32 in the same order, so conv + epilogue equals gc_conv2d_f32 followed by
  * gc_bias_act_f32 bit for bit while saving one write and one read of the activation tensor.  ep == NULL: plain convolution.
@@ -172,6 +177,7 @@ typedef struct gc_conv_epilogue {
     const float* noise_w;  /* DEVICE scalar; set exactly when noise is */
     float slope, gain;     /* used when activate != 0 */
     int32_t activate;
+    const float* residual; /* [batch, out_ch, out_h, out_w] or NULL; must not alias y */
 } gc_conv_epilogue;
 
 int gc_conv2d_fused_f32(const gc_conv_desc* d, const float* x, const float* w,

@@ -136,13 +136,15 @@ class EmulatedBackend:
         if out_scale is not None:
             y = y * out_scale[:, :, None, None]
         if epilogue is not None:
-            bias, noise, noise_w, slope, gain, activate = epilogue
+            bias, noise, noise_w, slope, gain, activate = epilogue[:6]
             if noise is not None:
                 y = y + noise_w * noise.reshape(y.shape[0], 1, *y.shape[2:])
             if bias is not None:
                 y = y + bias.reshape(1, -1, 1, 1)
             if activate:
                 y = F.leaky_relu(y, slope) * gain
+            if len(epilogue) > 6 and epilogue[6] is not None:
+                y = y + epilogue[6]
         return y
 
     def conv2d_wgrad(self, x, dy, in_scale, out_scale, geom):

@@ -235,6 +235,38 @@ def test_upfirdn2d_fused_activation(shape, pad):
         assert rel_err(a, c) < 1e-5
 
 
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
+def test_resblock_fused_sums_match_elementwise(mode):
+    """ResBlock with both of its sums inside convolution epilogues (residual / fork) vs the plain elementwise version:
+    values, first-order gradients and the R1-style second-order gradients."""
+    from gan_control_amd.models import gan_model
+    hip, _ = _be()
+    prev, hip.conv_mode = hip.conv_mode, mode
+    torch.manual_seed(5)
+    blk = gan_model.ResBlock(24, 40).to(DEV)
+    for prm in blk.parameters():
+        prm.data.normal_()
+    x0 = torch.randn(2, 24, 66, 70, device=DEV)
+    res = []
+    try:
+        for fused in (True, False):
+            gan_model._FUSE_EPILOGUE = fused
+            x = x0.clone().requires_grad_(True)
+            y = blk(x)
+            params = list(blk.parameters())
+            g1 = torch.autograd.grad(y.square().mean(), [x] + params, retain_graph=True)
+            gx, = torch.autograd.grad(y.sum(), x, create_graph=True)
+            g2 = torch.autograd.grad(gx.square().sum(), params, allow_unused=True)
+            res.append([y.detach(), *g1, gx.detach()] + [t for t in g2 if t is not None])
+    finally:
+        gan_model._FUSE_EPILOGUE = True
+        hip.conv_mode = prev
+    assert len(res[0]) == len(res[1])
+    tol = 2e-5 if mode == 'f32' else 3e-4
+    for i, (a, c) in enumerate(zip(*res)):
+        assert rel_err(a, c) < tol, i
+
+
 CONV_CASES = [
     # b, K, N, h, w, k, up, down, pad
     (2, 8, 8, 4, 4, 3, 1, 1, 1), (2, 16, 130, 8, 8, 3, 1, 1, 1), (1, 40, 64, 16, 16, 3, 1, 1, 1),
@@ -412,6 +444,11 @@ def test_conv2d_fused_epilogue(case, mode):
             assert torch.equal(fused, plain + bias.reshape(1, -1, 1, 1))
             fused = hip.conv2d(x, wt, *scales, geom, epilogue=(None, None, None, 0.2, 2 ** 0.5, True))
             assert torch.equal(fused, hip.bias_act(plain, None, None, None, 0.2, 2 ** 0.5))
+            res = torch.randn(plain.shape, generator=gen).to(DEV)
+            fused = hip.conv2d(x, wt, *scales, geom, epilogue=(None, None, None, 1.0, 1.0, False, res))
+            assert torch.equal(fused, plain + res)
+            fused = hip.conv2d(x, wt, *scales, geom, epilogue=(bias, nz, nw, 0.2, 2 ** 0.5, True, res))
+            assert torch.equal(fused, hip.bias_act(plain, bias, nz, nw, 0.2, 2 ** 0.5) + res)
         # against the independent emulation in fp64
         ref = emu.conv2d(x.cpu().double(), wt.cpu().double(), si.cpu().double(), so.cpu().double(), geom,
                          epilogue=(bias.cpu().double(), nz.cpu().double(), nw.cpu().double(), 0.2, 2 ** 0.5, True))
