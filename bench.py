@@ -126,12 +126,27 @@ def main():
         torch.cuda.synchronize()
 
     it = 0
+    # Discovery during the (untimed) warm-up: every convolution launch is bracketed to find the variant that takes the most
+    # GPU time; in the timed region only that variant (and the FIR tile kernel, for the HBM line) gets HIP events, so the
+    # measurement costs < 1 % instead of ~3 % of the step.
+    discover = None
+    if rank == 0 and not args.no_kernel_timer and args.timer == 'roofline':
+        discover = KernelTimer(only=('conv',))
+        _backend.get().timer = discover
     for _ in range(args.warmup):
         trainer.train_iteration(it, real)
         it += 1
     timer = None
     if rank == 0 and not args.no_kernel_timer:
-        timer = KernelTimer(only=None if args.timer == 'all' else ('conv', 'fir44'))
+        if discover is not None:
+            torch.cuda.synchronize()
+            found = discover.summary()
+            names = {'fir44_tile_kernel'}
+            if found:
+                names.add(max(found.items(), key=lambda kv: kv[1]['total_ms'])[0])
+            timer = KernelTimer(only=('conv', 'fir44'), names=names)
+        else:
+            timer = KernelTimer(only=None)
         _backend.get().timer = timer
     barrier()
     t0 = time.perf_counter()

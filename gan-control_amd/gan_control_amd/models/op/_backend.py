@@ -37,15 +37,8 @@ class HipBackend:
             return y
         lib = _lib.load()
         g = self._guard(dev)
-        t0 = self.timer.start('fir44') if self.timer else None
-        if g: g.__enter__()
-        try:
-            rc = lib.gc_upfirdn2d_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n * c, h, w, out_h, out_w,
-                                      taps.shape[0], taps.shape[1], up, up, down, down, pad_x0, pad_y0, int(flip), _lib.stream_of(x))
-        finally:
-            if g: g.__exit__(None, None, None)
-        _lib.check(rc, 'gc_upfirdn2d_f32')
-        if t0 is not None:
+        t0 = None
+        if self.timer:
             name = 'upfirdn2d_generic_kernel'          # mirrors the dispatch of gc_upfirdn2d_f32
             if tuple(taps.shape) == (4, 4) and n * c <= 65535:
                 if up == 1 and down == 1 and out_w >= 64 and out_h >= 16:
@@ -54,6 +47,15 @@ class HipBackend:
                     name = 'fir44_down2_kernel'
                 elif (up, down) == (2, 1) and out_w >= 32 and out_h >= 8:
                     name = 'fir44_up2_kernel'
+            t0 = self.timer.start('fir44', name)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_upfirdn2d_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n * c, h, w, out_h, out_w,
+                                      taps.shape[0], taps.shape[1], up, up, down, down, pad_x0, pad_y0, int(flip), _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_upfirdn2d_f32')
+        if t0 is not None:
             self.timer.stop(name, t0, 4.0 * (x.numel() + y.numel()))
         return y
 
@@ -71,7 +73,7 @@ class HipBackend:
             return y
         lib = _lib.load()
         g = self._guard(dev)
-        t0 = self.timer.start('fir44') if self.timer else None
+        t0 = self.timer.start('fir44', 'fir44_tile_kernel') if self.timer else None
         if g: g.__enter__()
         try:
             rc = lib.gc_upfirdn2d_act_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n, c, h, w, out_h, out_w, taps.shape[0], taps.shape[1],
@@ -242,7 +244,11 @@ class HipBackend:
         elif self.conv_mode != 'f32':
             raise RuntimeError('GANCONTROL_CONV_PRECISION must be f32 or bf16x3, got %r' % self.conv_mode)
         g = self._guard(dev)
-        t0 = self.timer.start('conv') if self.timer else None
+        t0 = None
+        if self.timer:
+            from ...utils.profiling import conv_variant, conv_flops
+            tname = conv_variant(geom, n_out, x.shape[0], x.shape[1], self.conv_mode)
+            t0 = self.timer.start('conv', tname)
         if g: g.__enter__()
         try:
             if ws is None:
@@ -254,8 +260,7 @@ class HipBackend:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_conv2d_fused_f32')
         if t0 is not None:
-            from ...utils.profiling import conv_variant, conv_flops
-            self.timer.stop(conv_variant(geom, n_out, x.shape[0], x.shape[1], self.conv_mode), t0, conv_flops(x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom))
+            self.timer.stop(tname, t0, conv_flops(x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom))
         return y
 
     def conv2d_wgrad(self, x, dy, in_scale, out_scale, geom):

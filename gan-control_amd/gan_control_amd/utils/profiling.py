@@ -60,13 +60,16 @@ def conv_flops(batch, k_in, n_out, in_h, in_w, geom):
 
 
 class KernelTimer:
-    def __init__(self, only=None):
+    def __init__(self, only=None, names=None):
         self.records = []          # (name, start_event, end_event, work)
         self.enabled = True
         self.only = only           # None: every launch; else a tuple of kinds ('conv', 'wgrad', 'fir44', 'bias_act')
+        self.names = names         # None: every kernel of those kinds; else the set of kernel names to bracket
 
-    def start(self, kind=None):
+    def start(self, kind=None, name=None):
         if not self.enabled or (self.only is not None and kind not in self.only):
+            return None
+        if self.names is not None and name is not None and name not in self.names:
             return None
         e = torch.cuda.Event(enable_timing=True)
         e.record()
