@@ -18,6 +18,7 @@ from torch.nn import functional as F
 
 import os
 _FUSE_EPILOGUE = os.environ.get('GANCONTROL_FUSE_EPILOGUE', '1') != '0'   # debugging knob: 0 = convolution and activation as two launches
+from .op import _backend
 from .op import (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, upfirdn2d_bias_act, conv2d_gradfix, modulated_conv2d,
                  modulated_conv2d_act)
 
@@ -382,7 +383,8 @@ class Generator(nn.Module):
         if pl_noise is None:
             pl_noise = torch.randn_like(fake_img)
         pl_noise = pl_noise / math.sqrt(fake_img.shape[2] * fake_img.shape[3] * dim_1_shape)
-        grad, = autograd.grad(outputs=(fake_img * pl_noise).sum(), inputs=latents, create_graph=True)
+        with _backend.activation_grads_only():          # only d/d(latents) is wanted: no weight / bias gradients in this backward
+            grad, = autograd.grad(outputs=(fake_img * pl_noise).sum(), inputs=latents, create_graph=True)
         return grad
 
 

@@ -13,6 +13,27 @@ import torch
 
 from ... import _lib
 
+# ctx.needs_input_grad of a custom Function is fixed at forward time: inside `autograd.grad(outputs, inputs=[...])` a backward
+# cannot see that only the listed inputs are wanted.  R1 (gradient w.r.t. the real images) and the path-length regulariser
+# (gradient w.r.t. the latents) would therefore compute -- and throw away -- every weight / bias / noise-strength gradient of
+# the network in their first (create_graph) backward.  The two call sites wrap that call in `activation_grads_only()` and
+# the Functions of this package skip the parameter gradients while it is active.
+_ACT_GRADS_ONLY = [False]
+
+
+class activation_grads_only:
+    def __enter__(self):
+        self.prev = _ACT_GRADS_ONLY[0]
+        _ACT_GRADS_ONLY[0] = True
+
+    def __exit__(self, *exc):
+        _ACT_GRADS_ONLY[0] = self.prev
+
+
+def want_param_grads():
+    return not _ACT_GRADS_ONLY[0]
+
+
 # Geometry of the generalised convolution (gc_conv_desc minus batch/channels/in-size, which come from tensors)
 ConvGeom = namedtuple('ConvGeom', 'kh kw up down pad_y pad_x out_h out_w')
 

@@ -50,7 +50,7 @@ class _GConv(Function):
         gx = gw = None
         if ctx.needs_input_grad[0]:
             gx = _GConv.apply(gy, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw))
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _backend.want_param_grads():
             gw = _weight_grad(x, gy, g)
         want_res = len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3]
         return (gx, gw, None, gy if want_res else None)[:len(ctx.needs_input_grad)]
@@ -113,14 +113,15 @@ class _GConvAct(Function):
             return None, None, None, None, None, None, None
         if gy is None:                      # only the forked copy was used downstream
             return (gfork if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
-        if ctx.needs_input_grad[2]:
+        params = _backend.want_param_grads()
+        if ctx.needs_input_grad[2] and params:
             g_pre, psum = _BiasActGradReduce.apply(gy, out, None, slope, gain)[:2]
             gb = psum.sum((0, 2))
         else:
             g_pre = _BiasActGrad.apply(gy, out, slope, gain)
         if ctx.needs_input_grad[0]:
             gx = _GConv.apply(g_pre, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw), gfork)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and params:
             gw = _weight_grad(x, g_pre, g)
         return gx, gw, gb, None, None, None, None
 

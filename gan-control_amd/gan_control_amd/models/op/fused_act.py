@@ -46,9 +46,10 @@ class _BiasAct(Function):
         gx = gb = gn = gnw = None
         if not any(ctx.needs_input_grad[:4]):
             return None, None, None, None, None, None
-        want_b = ctx.has_bias and ctx.needs_input_grad[1]
+        params = _backend.want_param_grads()
+        want_b = ctx.has_bias and ctx.needs_input_grad[1] and params
         want_n = ctx.has_noise and ctx.needs_input_grad[2]
-        want_nw = ctx.has_noise and ctx.needs_input_grad[3]
+        want_nw = ctx.has_noise and ctx.needs_input_grad[3] and params
         if (want_b or want_nw) and not want_n:
             # one pass: activation gradient + per-plane partial sums for the bias / noise-strength gradients
             gx, psum, pdot = _BiasActGradReduce.apply(gy, y, noise if want_nw else None, slope, gain)[:3]

@@ -79,7 +79,7 @@ class _ModConv(Function):
         need_si = ctx.has_si and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[0] or need_si:
             gx = _ModConv.apply(gy, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw))
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and _backend.want_param_grads():
             gw = _mod_weight_grad(x, gy, si, so, g)
         if need_si:
             gsi = _PlaneDot.apply(x, gx) / _safe(si)
@@ -121,6 +121,9 @@ class _ModConvAct(Function):
         if not any(need[:7]):
             return (None,) * 10
         want_so = has_so and need[3]
+        if not _backend.want_param_grads():
+            need = list(need)
+            need[1] = need[4] = need[6] = False          # weight, bias, noise strength
         if (has_bias and need[4]) or (has_noise and need[6]) or want_so:
             g_pre, psum, pdot, pself = _BiasActGradReduce.apply(gy, out, noise, slope, gain, bias, noise_w, want_so)
             if has_bias and need[4]:

@@ -79,7 +79,8 @@ class _UpFirDn2dAct(Function):
         slope, gain = ctx.act
         need = ctx.needs_input_grad
         gx = gb = gnw = None
-        want_b, want_nw = ctx.has_bias and need[4], ctx.has_noise and need[6]
+        params = _backend.want_param_grads()
+        want_b, want_nw = ctx.has_bias and need[4] and params, ctx.has_noise and need[6] and params
         if not (need[0] or want_b or want_nw):
             return (None,) * 9
         if want_b or want_nw:

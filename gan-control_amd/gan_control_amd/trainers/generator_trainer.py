@@ -22,6 +22,7 @@ from torch import autograd, optim
 from torch.nn import functional as F
 
 from ..models.gan_model import Generator, Discriminator
+from ..models.op import _backend
 from ..utils.fc_config import fc_config_from_sub_groups
 from . import ddp
 from .utils import accumulate, requires_grad, mixing_noise, make_mini_batch_from_noise, set_grad_none
@@ -138,7 +139,8 @@ class GeneratorTrainer:
 
     @staticmethod
     def d_r1_loss(real_pred, real_img):
-        grad_real, = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+        with _backend.activation_grads_only():          # only d/d(image) is wanted: no parameter gradients in this backward
+            grad_real, = autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
         return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
 
     @staticmethod

@@ -1,14 +1,4 @@
 cd $GRAFT_REPO_ROOT
-export TMPDIR=/tmp
-timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/bench_f_bf16x3.json
-timeout 900 python bench.py --no-cpu-baseline --no-kernel-timer 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-160
-timeout 900 python bench.py --precision f32 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/bench_f_f32.json
-timeout 900 python bench.py --size 512 --batch-per-gpu 16 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/bench_f_config1.json
-for m in bf16x3 f32; do
-  rm -rf gpurun_out/prof_$m && mkdir -p gpurun_out/prof_$m
-  timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$m -o $m --output-format csv -- python3 bench.py --precision $m --no-cpu-baseline > gpurun_out/prof_bench_$m.log 2>&1
-  cp $(find gpurun_out/prof_$m -name "*kernel_stats.csv" | head -1) gpurun_out/kernel_stats_$m.csv
-  find gpurun_out/prof_$m -name "*kernel_trace.csv" -delete
-done
-cut -c1-200 gpurun_out/bench_f_bf16x3.json; echo; cut -c1-200 gpurun_out/bench_f_f32.json; echo; cut -c1-200 gpurun_out/bench_f_config1.json
-timeout 600 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "bench or ddp" 2>&1 | tail -2
+timeout 600 python tools/phase_times.py --reps 8 2>&1 | grep -v amdgpu.ids | tail -6
+timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3
+for f in 1 1; do timeout 600 python bench.py --no-cpu-baseline --no-kernel-timer 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-140; done

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Device time of the path-length regularisation step by kernel / op (dev tool, GPU only)."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'gan-control_amd'))
+import torch
+from torch.profiler import profile, ProfilerActivity
+from gan_control_amd.models.op import _backend
+from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
+_backend.get().conv_mode = 'bf16x3'
+tr = GeneratorTrainer(default_config(1024, 4), device='cuda', seed=0)
+real = torch.randn(4, 3, 1024, 1024, device='cuda').clamp(-1, 1)
+tr.train_iteration(0, real)
+for _ in range(2):
+    tr.generator_regularize_step()
+torch.cuda.synchronize()
+with profile(activities=[ProfilerActivity.CUDA]) as prof:
+    tr.generator_regularize_step()
+    torch.cuda.synchronize()
+rows = []
+for e in prof.key_averages():
+    dt = getattr(e, 'self_device_time_total', None)
+    if dt is None: dt = e.self_cuda_time_total
+    if dt > 0: rows.append((dt, e.count, e.key))
+rows.sort(reverse=True)
+tot = sum(r[0] for r in rows)
+print(f'total {tot/1e3:.1f} ms, {sum(r[1] for r in rows)} launches')
+for dt, n, k in rows[:40]:
+    print(f'{dt/1e3:8.2f} ms {dt/tot*100:5.1f}% {n:5d}x  {k[:110]}')
