@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             xreg[j][0] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 0));
             xreg[j][1] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 16));
             xsc[j] = p.si ? p.si[(size_t)b * p.K + min(k, p.K - 1)] : 1.f;
-            xcol[j] = ok ? ixb : -100000;
+            xcol[j] = ok ? ixb : 0;                 // invalid units were loaded as zeros: nothing to mask
             xneg = neg ? (xneg | (1u << j)) : (xneg & ~(1u << j));
         }
 #pragma unroll
@@ -463,7 +463,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             yreg[j][0] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 0));
             yreg[j][1] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 16));
             ysc[j] = p.so ? p.so[(size_t)b * p.N + min(n, p.N - 1)] : 1.f;
-            ycol[j] = ok ? oxb : -100000;
+            ycol[j] = ok ? oxb : 0;
         }
     };
     auto unit8 = [&](const float4 (&r)[2], int col0, int width, float scale, bool shifted, uint4* h, uint4* l) {
@@ -473,8 +473,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             for (int q = 7; q > 0; --q) v[q] = v[q - 1];
             v[0] = 0.f;
         }
+        if (col0 < 0 || col0 + 8 > width) {      // only lanes whose unit straddles an image border pay for the masks (a third of the commit VALU work)
 #pragma unroll
-        for (int q = 0; q < 8; ++q) v[q] = (col0 + q >= 0 && col0 + q < width) ? v[q] : 0.f;   // row borders
+            for (int q = 0; q < 8; ++q) v[q] = (col0 + q >= 0 && col0 + q < width) ? v[q] : 0.f;
+        }
         split8(v, scale, h, l);
     };
     auto commit = [&]() {

@@ -118,6 +118,11 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
         float* dst = yp + (size_t)oy * out_w + ox;
         if (VEC) {
             if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        } else if (ox + 3 < out_w) {
+            // odd widths (1025, 513, ...): rows are only 4-byte aligned, which a 16-byte store accepts on gfx9 (as the
+            // 16-byte loads of the weight-gradient kernels do): one store instruction instead of four
+            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+            *reinterpret_cast<f4u*>(dst) = f4u{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)

@@ -1,4 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python tools/phase_times.py --reps 8 2>&1 | grep -v amdgpu.ids | tail -6
-timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -3
-for f in 1 1; do timeout 600 python bench.py --no-cpu-baseline --no-kernel-timer 2>&1 | grep -v amdgpu.ids | tail -1 | cut -c1-140; done
+for v in new old new old; do
+  if [ $v = new ]; then unset GANCONTROL_HIP_LIB; else export GANCONTROL_HIP_LIB=$GRAFT_REPO_ROOT/gan-control_amd/csrc/build/exp/lib_old.so; fi
+  echo == $v; python tools/fir_odd_bench.py 2>&1 | grep blur
+done
