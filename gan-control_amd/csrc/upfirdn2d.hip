@@ -43,24 +43,38 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
 #pragma unroll
         for (int b = 0; b < 4; ++b) T[a][b] = flip ? taps[(3 - a) * 4 + (3 - b)] : taps[a * 4 + b];
 
-    // stage the patch: consecutive lanes -> consecutive floats of one input row.  All loads are issued
-    // before the first LDS write so their latencies overlap (19 independent dword loads per lane).
+    // stage the patch: a lane fetches 4 consecutive floats of one input row with one 16-byte load (rows are only 4-byte
+    // aligned for 1025-wide planes: fine for gfx9) -- 5 loads per lane instead of 19 dword loads; groups that touch an
+    // image border fall back to guarded scalar loads.  All loads are issued before the first LDS write.
     const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
-    constexpr int NLD = (PH * PITCH + 255) / 256;
-    float stage[NLD];
+    constexpr int GPR = PITCH / 4;                           // 16-byte groups per patch row
+    constexpr int NLD = (PH * GPR + 255) / 256;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    float4 stage[NLD];
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int idx = tid + 256 * j;
-        const int r = idx / PITCH, c = idx - r * PITCH;
+        const int r = idx / GPR, c = (idx - r * GPR) * 4;
         const int iy = iy0 + r, ix = ix0 + c;
-        float v = 0.f;
-        if (idx < PH * PITCH && c < PW && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(size_t)iy * in_w + ix];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < PH * GPR && iy >= 0 && iy < in_h) {
+            const float* src = xp + (size_t)iy * in_w + ix;
+            if (ix >= 0 && ix + 3 < in_w) {
+                const f4u t = *reinterpret_cast<const f4u*>(src);
+                v = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                if (ix >= 0 && ix < in_w) v.x = src[0];
+                if (ix + 1 >= 0 && ix + 1 < in_w) v.y = src[1];
+                if (ix + 2 >= 0 && ix + 2 < in_w) v.z = src[2];
+                if (ix + 3 >= 0 && ix + 3 < in_w) v.w = src[3];
+            }
+        }
         stage[j] = v;
     }
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int idx = tid + 256 * j;
-        if (idx < PH * PITCH) patch[idx] = stage[j];
+        if (idx < PH * GPR) *reinterpret_cast<float4*>(&patch[idx * 4]) = stage[j];
     }
     __syncthreads();
 
@@ -157,21 +171,34 @@ __global__ __launch_bounds__(256) void fir44_down2_kernel(
         for (int b = 0; b < 4; ++b) T[a][b] = flip ? taps[(3 - a) * 4 + (3 - b)] : taps[a * 4 + b];
 
     const int iy0 = 2 * oy0 - pad_y0, ix0 = 2 * ox0 - pad_x0;
-    constexpr int NLD = (D_PH * D_PITCH + 255) / 256;
-    float stage[NLD];
+    constexpr int GPR = D_PITCH / 4;                         // 16-byte groups per patch row (see fir44_tile_kernel)
+    constexpr int NLD = (D_PH * GPR + 255) / 256;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    float4 stage[NLD];
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int idx = tid + 256 * j;
-        const int r = idx / D_PITCH, c = idx - r * D_PITCH;
+        const int r = idx / GPR, c = (idx - r * GPR) * 4;
         const int iy = iy0 + r, ix = ix0 + c;
-        float v = 0.f;
-        if (idx < D_PH * D_PITCH && c < D_PW && iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) v = xp[(size_t)iy * in_w + ix];
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (idx < D_PH * GPR && iy >= 0 && iy < in_h) {
+            const float* src = xp + (size_t)iy * in_w + ix;
+            if (ix >= 0 && ix + 3 < in_w) {
+                const f4u t = *reinterpret_cast<const f4u*>(src);
+                v = make_float4(t.x, t.y, t.z, t.w);
+            } else {
+                if (ix >= 0 && ix < in_w) v.x = src[0];
+                if (ix + 1 >= 0 && ix + 1 < in_w) v.y = src[1];
+                if (ix + 2 >= 0 && ix + 2 < in_w) v.z = src[2];
+                if (ix + 3 >= 0 && ix + 3 < in_w) v.w = src[3];
+            }
+        }
         stage[j] = v;
     }
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
         const int idx = tid + 256 * j;
-        if (idx < D_PH * D_PITCH) patch[idx] = stage[j];
+        if (idx < D_PH * GPR) *reinterpret_cast<float4*>(&patch[idx * 4]) = stage[j];
     }
     __syncthreads();
 
@@ -205,6 +232,9 @@ __global__ __launch_bounds__(256) void fir44_down2_kernel(
         float* dst = yp + (size_t)oy * out_w + ox;
         if (VEC) {
             if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+        } else if (ox + 3 < out_w) {
+            typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
+            *reinterpret_cast<f4s*>(dst) = f4s{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -284,6 +314,9 @@ __global__ __launch_bounds__(256) void fir44_up2_kernel(
             float* dst = yp + (size_t)oy * out_w + ox;
             if (VEC) {
                 if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+            } else if (ox + 3 < out_w) {
+                typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
+                *reinterpret_cast<f4s*>(dst) = f4s{o[0], o[1], o[2], o[3]};
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
