@@ -117,15 +117,26 @@ __global__ __launch_bounds__(256) void bias_act_bwd_reduce_kernel(
     const float ipos = 1.f / pos, ineg = 1.f / neg;
     const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
     float s = 0.f, d = 0.f, q = 0.f;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-        const float y = yref[base + i];
-        const float g = dy[base + i] * (y > 0.f ? pos : neg);
-        dx[base + i] = g;
+    auto one = [&](float yv, float dyv, float nz) {
+        const float g = dyv * (yv > 0.f ? pos : neg);
         s += g;
-        const float nz = NOISE ? np[i] : 0.f;
         if (NOISE) d = fmaf(g, nz, d);
-        if (SELF) q = fmaf(g, y * (y > 0.f ? ipos : ineg) - bv - nw * nz, q);
+        if (SELF) q = fmaf(g, yv * (yv > 0.f ? ipos : ineg) - bv - nw * nz, q);
+        return g;
+    };
+    // 16-byte accesses (4-byte alignment is enough on gfx9: planes of odd size start anywhere), then the <= 3 leftovers
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int64_t n4 = (hi - lo) >> 2;
+    for (int64_t v = threadIdx.x; v < n4; v += 256) {
+        const int64_t i = lo + 4 * v;
+        const f4u y4 = *reinterpret_cast<const f4u*>(yref + base + i), g4 = *reinterpret_cast<const f4u*>(dy + base + i);
+        f4u z4 = {0.f, 0.f, 0.f, 0.f};
+        if (NOISE) z4 = *reinterpret_cast<const f4u*>(np + i);
+        const f4u o4 = {one(y4.x, g4.x, z4.x), one(y4.y, g4.y, z4.y), one(y4.z, g4.z, z4.z), one(y4.w, g4.w, z4.w)};
+        *reinterpret_cast<f4u*>(dx + base + i) = o4;
     }
+    for (int64_t i = lo + 4 * n4 + threadIdx.x; i < hi; i += 256)
+        dx[base + i] = one(yref[base + i], dy[base + i], NOISE ? np[i] : 0.f);
     const float rs = block_sum(s, lds);
     if (threadIdx.x == 0) psum[(size_t)plane * chunks + j] = rs;
     if (NOISE) {
@@ -146,7 +157,14 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
     const size_t base = (size_t)plane * inner;
     const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
     float acc = 0.f;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc = fmaf(a[base + i], b[base + i], acc);
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int64_t n4 = (hi - lo) >> 2;
+    for (int64_t v = threadIdx.x; v < n4; v += 256) {
+        const int64_t i = lo + 4 * v;
+        const f4u a4 = *reinterpret_cast<const f4u*>(a + base + i), b4 = *reinterpret_cast<const f4u*>(b + base + i);
+        acc = fmaf(a4.x, b4.x, acc); acc = fmaf(a4.y, b4.y, acc); acc = fmaf(a4.z, b4.z, acc); acc = fmaf(a4.w, b4.w, acc);
+    }
+    for (int64_t i = lo + 4 * n4 + threadIdx.x; i < hi; i += 256) acc = fmaf(a[base + i], b[base + i], acc);
     const float r = block_sum(acc, lds);
     if (threadIdx.x == 0) partial[(size_t)plane * chunks + j] = r;
 }
