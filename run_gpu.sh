@@ -1,7 +1,13 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_ops_gpu.py -x -q -m gpu -k "conv2d or network" 2>&1 | tail -3
-for v in db nodb db nodb; do
-  if [ $v = db ]; then unset GC_NO_DB; else export GC_NO_DB=1; fi
-  echo == $v
-  python tools/kbench.py --mode bf16x3 --reps 20 --only "conv3x3 s1" 2>&1 | grep -v "wgrad" | grep "@32 \|@64 \|@128\|@256"
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests/ -x -q -m gpu 2>&1 | tail -2
+timeout 900 python bench.py 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/bench_g_bf16x3.json
+timeout 900 python bench.py --precision f32 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/bench_g_f32.json
+timeout 900 python bench.py --size 512 --batch-per-gpu 16 2>&1 | grep -v amdgpu.ids | tail -1 > gpurun_out/bench_g_config1.json
+for m in bf16x3 f32; do
+  rm -rf gpurun_out/prof_$m && mkdir -p gpurun_out/prof_$m
+  timeout 900 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_$m -o $m --output-format csv -- python3 bench.py --precision $m --no-cpu-baseline > gpurun_out/prof_bench_$m.log 2>&1
+  cp $(find gpurun_out/prof_$m -name "*kernel_stats.csv" | head -1) gpurun_out/kernel_stats_$m.csv
+  find gpurun_out/prof_$m -name "*kernel_trace.csv" -delete
 done
+cut -c1-200 gpurun_out/bench_g_bf16x3.json; echo; cut -c1-200 gpurun_out/bench_g_f32.json; echo; cut -c1-200 gpurun_out/bench_g_config1.json

@@ -15,6 +15,7 @@ from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default
 ap = argparse.ArgumentParser()
 ap.add_argument('--size', type=int, default=1024); ap.add_argument('--batch', type=int, default=4)
 ap.add_argument('--precision', default='bf16x3'); ap.add_argument('--top', type=int, default=60)
+ap.add_argument('--iter', type=int, default=16, help='iteration index to profile (16: with R1 + path-length, 17: plain D + G step)')
 ap.add_argument('--all', action='store_true', help='include the HIP-library kernels and autograd Function rows')
 a = ap.parse_args()
 _backend.get().conv_mode = a.precision
@@ -25,7 +26,7 @@ for i in range(3):
     tr.train_iteration(i, real)          # includes the every-16 regularisers at i = 0
 torch.cuda.synchronize()
 with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
-    tr.train_iteration(16, real)         # i % 16 == 0 -> R1 and path-length passes included
+    tr.train_iteration(a.iter, real)     # 16: R1 and path-length passes included; 17: plain
     torch.cuda.synchronize()
 rows = []
 for e in prof.key_averages(group_by_input_shape=True):

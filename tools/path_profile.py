@@ -14,14 +14,14 @@ tr.train_iteration(0, real)
 for _ in range(2):
     tr.generator_regularize_step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CUDA]) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     tr.generator_regularize_step()
     torch.cuda.synchronize()
 rows = []
-for e in prof.key_averages():
+for e in prof.key_averages(group_by_input_shape=True):
     dt = getattr(e, 'self_device_time_total', None)
     if dt is None: dt = e.self_cuda_time_total
-    if dt > 0: rows.append((dt, e.count, e.key))
+    if dt > 0 and e.key.startswith('aten::'): rows.append((dt, e.count, e.key + ' ' + str(e.input_shapes)[:90]))
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f'total {tot/1e3:.1f} ms, {sum(r[1] for r in rows)} launches')
