@@ -489,6 +489,36 @@ def golden_augment():
     print('augment ok')
 
 
+def golden_fid():
+    """Frechet distance fixtures from the reference's calc_fid (fid_utils/fid.py:43-66) and its batch plan (:22-27)."""
+    stubs = {n: mock.MagicMock() for n in ['gan_control.fid_utils.calc_inception', 'tqdm'] if n not in sys.modules}
+    with mock.patch.dict(sys.modules, stubs):
+        import importlib
+        ref_fid = importlib.import_module('gan_control.fid_utils.fid')
+    from oracle import fid as ofid
+    rng = np.random.default_rng(7)
+    out = {}
+    for i, (dim, n1, n2, shift) in enumerate([(16, 200, 300, 0.0), (48, 500, 400, 0.3), (64, 90, 2000, 1.0), (32, 1000, 1000, 0.05)]):
+        mix1, mix2 = rng.normal(size=(dim, dim)), rng.normal(size=(dim, dim))
+        f1 = rng.normal(size=(n1, dim)) @ mix1
+        f2 = rng.normal(size=(n2, dim)) @ mix2 + shift
+        m1, c1, m2, c2 = f1.mean(0), np.cov(f1, rowvar=False), f2.mean(0), np.cov(f2, rowvar=False)
+        ref = float(ref_fid.calc_fid(m1, c1, m2, c2))
+        ora = ofid.frechet_distance(m1, c1, m2, c2)
+        assert abs(ref - ora) <= 1e-6 * max(1.0, abs(ref)), (i, ref, ora)
+        out.update({f'case{i}/m1': m1, f'case{i}/c1': c1, f'case{i}/m2': m2, f'case{i}/c2': c2, f'case{i}/fid': np.float64(ref)})
+    # identical statistics: distance 0 up to the square-root round-off of the reference implementation
+    out['same/fid'] = np.float64(ref_fid.calc_fid(m1, c1, m1, c1))
+    for n, b in [(50000, 20), (101, 20), (7, 8), (40, 20)]:
+        n_batch = n // b
+        resid = n - n_batch * b
+        plan = [b] * n_batch + ([resid] if resid else [])
+        assert plan == ofid.batch_plan(n, b)
+        out[f'plan/{n}_{b}'] = np.asarray(plan, dtype=np.int64)
+    np.savez_compressed(os.path.join(GOLD, 'fid.npz'), **out)
+    print('fid ok')
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -499,6 +529,7 @@ def main():
     golden_networks()
     golden_step()
     golden_augment()
+    golden_fid()
     total = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print('fixtures written to %s (%.1f KiB)' % (GOLD, total / 1024))
 
