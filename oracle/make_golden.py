@@ -519,6 +519,49 @@ def golden_fid():
     print('fid ok')
 
 
+def golden_controller():
+    """FcStack forward / gradients and three optimisation steps from the reference's own classes."""
+    import gan_control.models.controller_model as ref_cm
+    from oracle import controller as octl
+    torch.manual_seed(11)
+    lr_mlp, n_mlp, in_dim, mid, out_dim, chunk = 0.01, 4, 3, 32, 24, (40, 64)
+    ref = ref_cm.FcStack(lr_mlp, n_mlp, in_dim, mid, out_dim).double()
+    for prm in ref.parameters():
+        prm.data.add_(torch.randn_like(prm) * 0.3)
+    controls = torch.randn(6, in_dim, dtype=torch.float64)
+    w_latent = torch.randn(6, 96, dtype=torch.float64)
+    out = {'controls': controls, 'w_latent': w_latent, 'chunk': np.asarray(chunk), 'hyper': np.asarray([lr_mlp, n_mlp, in_dim, mid, out_dim])}
+    for k, v in ref.state_dict().items():
+        out['init/' + k] = v.clone()
+    y = ref(controls)
+    ws = [ref.fc_stack[i].weight.detach().clone() for i in range(n_mlp)]
+    bs = [ref.fc_stack[i].bias.detach().clone() for i in range(n_mlp)]
+    close(octl.fc_stack_forward(controls, ws, bs, lr_mlp), y, 1e-12, 'controller forward')
+    out['forward'] = y.detach()
+    # the reference's step: L1 on the group slice, Adam(lr * ratio, betas = (0 ** ratio, 0.99 ** ratio)), ratio = 4 / 5
+    ratio = 4 / 5
+    opt = torch.optim.Adam(ref.parameters(), lr=0.002 * ratio, betas=(0 ** ratio, 0.99 ** ratio))
+    rec = torch.nn.L1Loss()
+    losses = []
+    for _ in range(3):
+        ref.zero_grad()
+        loss = rec(ref(controls), w_latent[:, chunk[0]:chunk[1]])
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    leaf_w = [w.requires_grad_(True) for w in ws]
+    leaf_b = [b.requires_grad_(True) for b in bs]
+    ora = octl.controller_step(leaf_w, leaf_b, lr_mlp, controls, w_latent, chunk, steps=3)
+    assert np.allclose(ora, losses, rtol=1e-12), (ora, losses)
+    for i in range(n_mlp):
+        close(leaf_w[i], ref.fc_stack[i].weight, 1e-10, 'controller weight %d after 3 steps' % i)
+    out['losses'] = np.asarray(losses)
+    for k, v in ref.state_dict().items():
+        out['after3/' + k] = v.clone()
+    np.savez_compressed(os.path.join(GOLD, 'controller.npz'), **to_np(out))
+    print('controller ok')
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
@@ -530,6 +573,7 @@ def main():
     golden_step()
     golden_augment()
     golden_fid()
+    golden_controller()
     total = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print('fixtures written to %s (%.1f KiB)' % (GOLD, total / 1024))
 

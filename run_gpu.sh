@@ -1,3 +1,6 @@
+#!/bin/bash
 cd $GRAFT_REPO_ROOT
-timeout 600 python tools/train_sanity.py --size 64 --batch 8 --iters 150 2>&1 | grep -v amdgpu.ids | tail -4
-timeout 600 python tools/train_sanity.py --size 128 --batch 4 --iters 40 --ada 2>&1 | grep -v amdgpu.ids | tail -3
+export TMPDIR=/tmp
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -8
+timeout 300 python bench.py --steps 32 --warmup 16 2>&1 | tail -1 > gpurun_out/bench_latest.json
+cat gpurun_out/bench_latest.json | cut -c1-700
