@@ -351,6 +351,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
 // tiles sit in LDS pixel-contiguous as 16-byte units of 8 pixels (hi and lo parts).  A horizontal tap shift of
 // tx pixels is a funnel shift over two neighbouring units (4 v_perm for tx = 1, register moves for tx = 2) --
 // every ds_read_b128 stays 16-byte aligned.  Each wave owns a 32k x 32n block for all taps (144 accumulators).
+#if defined(GC_ABL) && GC_ABL == 3      // dev ablation: no global loads in the weight-gradient staging
+#define WG_LOAD(r, off, imm) make_uint4((off), (off) + 1u, (off) + 2u, (off) + 3u)
+#else
+#define WG_LOAD(r, off, imm) buf_load_u128(r, off, imm)
+#endif
 struct WgArgs {
     const float* x; const float* dy; const float* si; const float* so; float* ws;
     int B, K, N, in_h, in_w, out_h, out_w, pad_y, pad_x;
@@ -365,6 +370,11 @@ __device__ __forceinline__ uint4 shift_px(const uint4 a, const uint4 b, int tx) 
 }
 
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4* h, uint4* l) {
+#if defined(GC_ABL) && GC_ABL == 2      // dev ablation: staging without the conversions
+    *h = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
+    *l = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
+    return;
+#endif
     bf16x8 hh, ll;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -419,16 +429,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
     const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
     const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
 
+    // Between prefetch and commit only the loaded data lives in registers: the per-sample scales sit in an LDS table
+    // (refilled when a split crosses into the next sample), border columns are recomputed from the tile index.
+    __shared__ float s_scale[KT + NTL];
+    int b_tab = -1;
     float4 xreg[C::NPX][2], yreg[C::NPY][2];
-    float xsc[C::NPX], ysc[C::NPY];
-    int xcol[C::NPX], ycol[C::NPY];          // first column of each unit (for the border masks applied at commit)
-    unsigned xneg = 0;                       // units loaded from offset 0 instead of -pad (see prefetch)
     const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
     auto prefetch = [&](int tile) {
         const int t_ = opaque(tid);
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
-        const int oy0 = (rem / p.tiles_x) * TR, ox0 = (rem % p.tiles_x) * 32;
+        const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows (L2 hits)
         const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
@@ -444,13 +455,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             // The very first unit of a sample (k = 0, iy = 0, left halo) would start at a NEGATIVE offset, which the
             // range check rejects as a whole: load it from offset 0 and shift it into place at commit time.
             const int lin = k * xchan + iy * p.in_w + ixb;
-            const bool neg = ok && lin < 0;
-            const unsigned off = ok ? (unsigned)(neg ? 0 : lin) * 4u : OOB;
-            xreg[j][0] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 0));
-            xreg[j][1] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 16));
-            xsc[j] = p.si ? p.si[(size_t)b * p.K + min(k, p.K - 1)] : 1.f;
-            xcol[j] = ok ? ixb : 0;                 // invalid units were loaded as zeros: nothing to mask
-            xneg = neg ? (xneg | (1u << j)) : (xneg & ~(1u << j));
+            const unsigned off = ok ? (unsigned)max(lin, 0) * 4u : OOB;
+            xreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 0));
+            xreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 16));
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
@@ -460,10 +467,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             const int n = n0 + nn, oy = oy0 + r, oxb = ox0 + 8 * yu;
             const bool ok = u < C::NYU && n < p.N && oy < p.out_h;
             const unsigned off = ok ? (unsigned)(n * ychan + oy * p.out_w + oxb) * 4u : OOB;
-            yreg[j][0] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 0));
-            yreg[j][1] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 16));
-            ysc[j] = p.so ? p.so[(size_t)b * p.N + min(n, p.N - 1)] : 1.f;
-            ycol[j] = ok ? oxb : 0;
+            yreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 0));
+            yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 16));
         }
     };
     auto unit8 = [&](const float4 (&r)[2], int col0, int width, float scale, bool shifted, uint4* h, uint4* l) {
@@ -479,17 +484,37 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
         }
         split8(v, scale, h, l);
     };
-    auto commit = [&]() {
+    auto commit = [&](int tile) {
+        const int b = tile / tiles_per_sample;
+        const int rem = tile - b * tiles_per_sample;
+        const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows (L2 hits)
+        const bool scaled = p.si != nullptr || p.so != nullptr;
+        if (scaled && b != b_tab) {          // uniform: every lane of the workgroup sees the same tile
+            __syncthreads();
+            if (tid < KT) s_scale[tid] = p.si ? p.si[(size_t)b * p.K + min(k0 + tid, p.K - 1)] : 1.f;
+            else if (tid < KT + NTL) s_scale[tid] = p.so ? p.so[(size_t)b * p.N + min(n0 + tid - KT, p.N - 1)] : 1.f;
+            __syncthreads();
+            b_tab = b;
+        }
         wait_staged_loads();
+#pragma unroll
+        for (int j = 0; j < C::NPX; ++j) { pin_staged(xreg[j][0]); pin_staged(xreg[j][1]); }
+#pragma unroll
+        for (int j = 0; j < C::NPY; ++j) { pin_staged(yreg[j][0]); pin_staged(yreg[j][1]); }
         const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
             const int u = t_ + 256 * j;
             const int row = u / XU;
+            const int kk = row / PH, r = row % PH;
+            const int col0 = ox0 - p.pad_x + 8 * (u % XU);
+            // the unit that was fetched from offset 0 instead of -pad (see prefetch): first channel, first row, left halo
+            const bool shifted = col0 < 0 && k0 + kk == 0 && oy0 - p.pad_y + r == 0;
+            const float sc = scaled ? s_scale[min(kk, KT - 1)] : 1.f;
             uint4 h, l;
-            unit8(xreg[j], xcol[j], p.in_w, xsc[j], (xneg >> j) & 1u, &h, &l);
+            unit8(xreg[j], col0, p.in_w, sc, shifted, &h, &l);       // rows / channels outside the image were loaded as zeros
             if (u < C::NXU) {
-                const int o = (row / PH) * C::CSX + (row % PH) * XU + u % XU;
+                const int o = kk * C::CSX + r * XU + u % XU;
                 xh[o] = h; xl[o] = l;
             }
         }
@@ -497,8 +522,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
         for (int j = 0; j < C::NPY; ++j) {
             const int u = t_ + 256 * j;
             const int row = u / YU;
+            const float sc = scaled ? s_scale[KT + min(row / TR, NTL - 1)] : 1.f;
             uint4 h, l;
-            unit8(yreg[j], ycol[j], p.out_w, ysc[j], false, &h, &l);
+            unit8(yreg[j], ox0 + 8 * (u % YU), p.out_w, sc, false, &h, &l);
             if (u < C::NYU) {
                 const int o = (row / TR) * C::CSY + (row % TR) * YU + u % YU;
                 yh[o] = h; yl[o] = l;
@@ -508,13 +534,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
 
     if (t_begin < t_end) {
         prefetch(t_begin);
-        commit();
+        commit(t_begin);
         __syncthreads();
         const int xa = (wk * 32 + l31) * C::CSX + hi, yb_ = (wn * 32 + l31) * C::CSY + hi;
         for (int tile = t_begin; tile < t_end; ++tile) {
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
-            if (more) prefetch(tile + 1);
+            prefetch(more ? tile + 1 : tile);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
 #pragma unroll 1
             for (int step = 0; step < 2 * TR / WP; ++step) {
                 {
@@ -533,18 +559,23 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
                             const uint4 uh = shift_px(a0h, a1h, tx), ul = shift_px(a0l, a1l, tx);
                             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh), al = *reinterpret_cast<const bf16x8*>(&ul);
                             f32x16 c = acc[ty * KS + tx];
+#if defined(GC_ABL) && GC_ABL == 1      // dev ablation: one MFMA instead of three
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+#else
                             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+#endif
                             acc[ty * KS + tx] = c;
                         }
+                        if (KS == 3) __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
             __syncthreads();
             if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
             {
-                commit();
+                commit(tile + 1);
                 __syncthreads();
             }
         }
@@ -648,14 +679,17 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
     const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
     const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
 
+    // Only the loaded data lives in registers between prefetch and commit: the per-sample scales sit in an LDS table
+    // (refilled when a split crosses into the next sample) and the border columns are recomputed from the tile index --
+    // with 144 accumulators the kernel otherwise spills inside the tile loop.
+    __shared__ float s_scale[KT + NTL];
+    int b_tab = -1;
     float4 xreg[C::NPX][4], yreg[C::NPY][2];
-    float xsc[C::NPX], ysc[C::NPY];
-    int xcol[C::NPX], ycol[C::NPY];
     auto prefetch = [&](int tile) {
         const int t_ = opaque(tid);
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
-        const int oy0 = (rem / p.tiles_x) * TR, ox0 = (rem % p.tiles_x) * 32;
+        const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows (L2 hits)
         const int iy0 = oy0 * 2, ix0 = ox0 * 2;                      // pad = 0 (checked on the host)
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
@@ -668,9 +702,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             const bool ok = u < C::NXI && k < p.K && iy < p.in_h;
             const unsigned off = ok ? (unsigned)(k * xchan + iy * p.in_w + ixb) * 4u : OOB;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) xreg[j][v] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 16 * v));
-            xsc[j] = p.si ? p.si[(size_t)b * p.K + min(k, p.K - 1)] : 1.f;
-            xcol[j] = ok ? ixb : -100000;
+            for (int v = 0; v < 4; ++v) xreg[j][v] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 16 * v));
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
@@ -680,48 +712,67 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             const int n = n0 + nn, oy = oy0 + r, oxb = ox0 + 8 * yu;
             const bool ok = u < C::NYU && n < p.N && oy < p.out_h;
             const unsigned off = ok ? (unsigned)(n * ychan + oy * p.out_w + oxb) * 4u : OOB;
-            yreg[j][0] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 0));
-            yreg[j][1] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 16));
-            ysc[j] = p.so ? p.so[(size_t)b * p.N + min(n, p.N - 1)] : 1.f;
-            ycol[j] = ok ? oxb : -100000;
+            yreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 0));
+            yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 16));
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](int tile) {
+        const int b = tile / tiles_per_sample;
+        const int rem = tile - b * tiles_per_sample;
+        const int ox0 = (rem / p.tiles_y) * 32;
+        const bool scaled = p.si != nullptr || p.so != nullptr;
+        if (scaled && b != b_tab) {          // uniform: every lane of the workgroup sees the same tile
+            __syncthreads();
+            if (tid < KT) s_scale[tid] = p.si ? p.si[(size_t)b * p.K + min(k0 + tid, p.K - 1)] : 1.f;
+            else if (tid < KT + NTL) s_scale[tid] = p.so ? p.so[(size_t)b * p.N + min(n0 + tid - KT, p.N - 1)] : 1.f;
+            __syncthreads();
+            b_tab = b;
+        }
         wait_staged_loads();
+#pragma unroll
+        for (int j = 0; j < C::NPX; ++j)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) pin_staged(xreg[j][v]);
+#pragma unroll
+        for (int j = 0; j < C::NPY; ++j) { pin_staged(yreg[j][0]); pin_staged(yreg[j][1]); }
         const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
             const int u = t_ + 256 * j;
             const int it = u % NI, row = u / NI;
+            const int col0 = 2 * ox0 + 16 * it;          // rows / channels outside the image were loaded as zeros already
+            const float sc = scaled ? s_scale[min(row / PH, KT - 1)] : 1.f;
             const float4* q4 = xreg[j];
             const float v[16] = {q4[0].x, q4[0].y, q4[0].z, q4[0].w, q4[1].x, q4[1].y, q4[1].z, q4[1].w,
                                  q4[2].x, q4[2].y, q4[2].z, q4[2].w, q4[3].x, q4[3].y, q4[3].z, q4[3].w};
+            const int room = p.in_w - col0;             // columns of this item inside the image (pad = 0: only the right border cuts)
             float ev[8], od[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                ev[q] = (xcol[j] + 2 * q >= 0 && xcol[j] + 2 * q < p.in_w) ? v[2 * q] : 0.f;
-                od[q] = (xcol[j] + 2 * q + 1 >= 0 && xcol[j] + 2 * q + 1 < p.in_w) ? v[2 * q + 1] : 0.f;
-            }
+            for (int q = 0; q < 8; ++q) { ev[q] = 2 * q < room ? v[2 * q] : 0.f; od[q] = 2 * q + 1 < room ? v[2 * q + 1] : 0.f; }
             uint4 eh, el, oh, ol;
-            split8(ev, xsc[j], &eh, &el);
+            split8(ev, sc, &eh, &el);
             if (u < C::NXI) {
                 const int o = (row / PH) * C::CSX + (row % PH) * RU;
                 xh[o + it] = eh; xl[o + it] = el;
                 if (KS == 3 && it < C::XO) {
-                    split8(od, xsc[j], &oh, &ol);
+                    split8(od, sc, &oh, &ol);
                     xh[o + XE + it] = oh; xl[o + XE + it] = ol;
                 }
             }
+            __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaving the conversions of several items costs more registers than there are
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
             const int u = t_ + 256 * j;
             const int row = u / YU;
+            const int col0 = ox0 + 8 * (u % YU);
+            const float sc = scaled ? s_scale[KT + min(row / TR, NTL - 1)] : 1.f;
             float v[8] = {yreg[j][0].x, yreg[j][0].y, yreg[j][0].z, yreg[j][0].w, yreg[j][1].x, yreg[j][1].y, yreg[j][1].z, yreg[j][1].w};
+            const int room = p.out_w - col0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (ycol[j] + q >= 0 && ycol[j] + q < p.out_w) ? v[q] : 0.f;
+            for (int q = 0; q < 8; ++q) v[q] = q < room ? v[q] : 0.f;
             uint4 h, l;
-            split8(v, ysc[j], &h, &l);
+            split8(v, sc, &h, &l);
             if (u < C::NYU) {
                 const int o = (row / TR) * C::CSY + (row % TR) * YU + u % YU;
                 yh[o] = h; yl[o] = l;
@@ -731,13 +782,13 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
 
     if (t_begin < t_end) {
         prefetch(t_begin);
-        commit();
+        commit(t_begin);
         __syncthreads();
         const int xa = (wk * 32 + l31) * C::CSX + hi, yb_ = (wn * 32 + l31) * C::CSY + hi;
         for (int tile = t_begin; tile < t_end; ++tile) {
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
-            if (more) prefetch(tile + 1);
+            prefetch(more ? tile + 1 : tile);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
 #pragma unroll ((TR == 1 || WK == 1) ? 1 : 2)
             for (int r = 0; r < TR; ++r) {
 #pragma unroll ((TR == 1 || WK == 1) ? 1 : 2)
@@ -748,19 +799,33 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
 #pragma unroll
                     for (int ty = 0; ty < KS; ++ty) {
                         const int o = xa + (2 * r + ty) * RU + 2 * st;
-                        const uint4 e0h = xh[o], e0l = xl[o];
-                        uint4 e1h = e0h, e1l = e0l, o0h = e0h, o0l = e0l;
-                        if (KS == 3) { e1h = xh[o + 1]; e1l = xl[o + 1]; o0h = xh[o + XE]; o0l = xl[o + XE]; }
-#pragma unroll
-                        for (int tx = 0; tx < KS; ++tx) {
-                            const uint4 uh = tx == 0 ? e0h : (tx == 1 ? o0h : shift_px(e0h, e1h, 1));
-                            const uint4 ul = tx == 0 ? e0l : (tx == 1 ? o0l : shift_px(e0l, e1l, 1));
+                        auto tap = [&](int tx, const uint4 uh, const uint4 ul) {
                             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh), al = *reinterpret_cast<const bf16x8*>(&ul);
                             f32x16 c = acc[ty * KS + tx];
+#if defined(GC_ABL) && GC_ABL == 1      // dev ablation: one MFMA instead of three
+                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+#else
                             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
                             c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
+#endif
                             acc[ty * KS + tx] = c;
+                        };
+                        // tap order 0, 2, 1: the even units (and their one-pixel shift) retire before the odd unit is live --
+                        // with 144 accumulators and the staged tile in registers there is no room for all three fragments at once
+                        const uint4 e0h = xh[o], e0l = xl[o];
+                        if (KS == 3) {
+                            const uint4 e1h = xh[o + 1], e1l = xl[o + 1];
+                            const uint4 sh = shift_px(e0h, e1h, 1), sl = shift_px(e0l, e1l, 1);
+                            tap(0, e0h, e0l);
+                            __builtin_amdgcn_sched_barrier(0);
+                            const uint4 o0h = xh[o + XE], o0l = xl[o + XE];
+                            tap(2, sh, sl);
+                            __builtin_amdgcn_sched_barrier(0);
+                            tap(1, o0h, o0l);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else {
+                            tap(0, e0h, e0l);
                         }
                     }
                 }
@@ -768,7 +833,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             __syncthreads();
             if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
             {
-                commit();
+                commit(tile + 1);
                 __syncthreads();
             }
         }
