@@ -429,56 +429,67 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
     const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
     const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
 
-    // Between prefetch and commit only the loaded data lives in registers: the per-sample scales sit in an LDS table
-    // (refilled when a split crosses into the next sample), border columns are recomputed from the tile index.
+    // Staging is kept LEAN: with two workgroups per CU the vector ALUs (index arithmetic, masks, conversions), not the
+    // matrix pipes, bound this kernel.  Everything that depends only on the lane is computed once -- the byte offset of each
+    // staged unit inside a sample and a packed descriptor (LDS unit offset, patch row, unit column, channel) -- so a tile costs
+    // ~6 vector instructions per unit to address and ~40 to convert.  The per-sample scales sit in an LDS table (refilled
+    // when a split crosses into the next sample).
     __shared__ float s_scale[KT + NTL];
     int b_tab = -1;
     float4 xreg[C::NPX][2], yreg[C::NPY][2];
+    unsigned xdesc[C::NPX], ydesc[C::NPY];       // LDS unit offset | unit column << 16 | patch row << 20 | channel << 24 | idle lane << 31
+    constexpr unsigned OUTSIDE = 0x80000000u;    // beyond every buffer
+#pragma unroll
+    for (int j = 0; j < C::NPX; ++j) {
+        const int u = tid + 256 * j;
+        const int xu = u % XU, row = u / XU;
+        const int r = row % PH, kk = min(row / PH, KT - 1);
+        const bool live = u < C::NXU && k0 + kk < p.K;
+        xdesc[j] = (unsigned)(kk * C::CSX + r * XU + xu) | (unsigned)xu << 16 | (unsigned)r << 20 | (unsigned)kk << 24 | (live ? 0u : OUTSIDE);
+    }
+#pragma unroll
+    for (int j = 0; j < C::NPY; ++j) {
+        const int u = tid + 256 * j;
+        const int yu = u % YU, row = u / YU;
+        const int r = row % TR, nn = min(row / TR, NTL - 1);
+        const bool live = u < C::NYU && n0 + nn < p.N;
+        ydesc[j] = (unsigned)(nn * C::CSY + r * YU + yu) | (unsigned)yu << 16 | (unsigned)r << 20 | (unsigned)nn << 24 | (live ? 0u : OUTSIDE);
+    }
     const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
     auto prefetch = [&](int tile) {
-        const int t_ = opaque(tid);
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
         const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows (L2 hits)
         const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+        const int xoff = (k0 * xchan + iy0 * p.in_w + ix0) * 4, yoff = (n0 * ychan + oy0 * p.out_w + ox0) * 4;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
 #pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
-            const int u = t_ + 256 * j;
-            const int xu = u % XU, row = u / XU;
-            const int r = row % PH, kk = row / PH;
-            const int k = k0 + kk, iy = iy0 + r, ixb = ix0 + 8 * xu;
-            const bool ok = u < C::NXU && k < p.K && iy >= 0 && iy < p.in_h;
-            // rows start at odd offsets (pad - 1, 1025-wide planes): the 16-byte loads are only 4-byte aligned,
-            // which buffer_load_dwordx4 accepts; each dword is range-checked separately
-            // The very first unit of a sample (k = 0, iy = 0, left halo) would start at a NEGATIVE offset, which the
-            // range check rejects as a whole: load it from offset 0 and shift it into place at commit time.
-            const int lin = k * xchan + iy * p.in_w + ixb;
-            const unsigned off = ok ? (unsigned)max(lin, 0) * 4u : OOB;
+            // rows start at odd offsets (pad - 1, 1025-wide planes): the 16-byte loads are only 4-byte aligned, which
+            // buffer_load_dwordx4 accepts; each dword is range-checked separately.  The very first unit of a sample
+            // (channel 0, row 0, left halo) would start at a NEGATIVE offset, which the range check rejects as a whole:
+            // it is loaded from offset 0 and patched after the commit (fix_first_unit).
+            const unsigned d = (unsigned)opaque((int)xdesc[j]);       // opaque: nothing derived from the descriptor may be hoisted out of the tile loop (registers)
+            const int r = (int)((d >> 20) & 15u);
+            const int lin = (int)((d >> 24) & 63u) * (xchan * 4) + r * (p.in_w * 4) + (int)((d >> 16) & 15u) * 32 + xoff;
+            const unsigned off = ((int)d >= 0 && (unsigned)(iy0 + r) < (unsigned)p.in_h) ? (unsigned)max(lin, 0) : OUTSIDE;
             xreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 0));
             xreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 16));
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
-            const int u = t_ + 256 * j;
-            const int yu = u % YU, row = u / YU;
-            const int r = row % TR, nn = row / TR;
-            const int n = n0 + nn, oy = oy0 + r, oxb = ox0 + 8 * yu;
-            const bool ok = u < C::NYU && n < p.N && oy < p.out_h;
-            const unsigned off = ok ? (unsigned)(n * ychan + oy * p.out_w + oxb) * 4u : OOB;
+            const unsigned d = (unsigned)opaque((int)ydesc[j]);
+            const int r = (int)((d >> 20) & 15u);
+            const int lin = (int)((d >> 24) & 63u) * (ychan * 4) + r * (p.out_w * 4) + (int)((d >> 16) & 15u) * 32 + yoff;
+            const unsigned off = ((int)d >= 0 && oy0 + r < p.out_h) ? (unsigned)lin : OUTSIDE;
             yreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 0));
             yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 16));
         }
     };
-    auto unit8 = [&](const float4 (&r)[2], int col0, int width, float scale, bool shifted, uint4* h, uint4* l) {
+    auto unit8 = [&](const float4 (&r)[2], int col0, int width, float scale, uint4* h, uint4* l) {
         float v[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
-        if (shifted) {      // data starts at column 0 but the unit starts at column -1 (pad_x = 1, checked on the host)
-#pragma unroll
-            for (int q = 7; q > 0; --q) v[q] = v[q - 1];
-            v[0] = 0.f;
-        }
-        if (col0 < 0 || col0 + 8 > width) {      // only lanes whose unit straddles an image border pay for the masks (a third of the commit VALU work)
+        if (col0 < 0 || col0 + 8 > width) {      // only lanes whose unit straddles an image border pay for the masks
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (col0 + q >= 0 && col0 + q < width) ? v[q] : 0.f;
         }
@@ -487,7 +498,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
     auto commit = [&](int tile) {
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
-        const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows (L2 hits)
+        const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;
         const bool scaled = p.si != nullptr || p.so != nullptr;
         if (scaled && b != b_tab) {          // uniform: every lane of the workgroup sees the same tile
             __syncthreads();
@@ -498,36 +509,33 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
         }
         wait_staged_loads();
 #pragma unroll
-        for (int j = 0; j < C::NPX; ++j) { pin_staged(xreg[j][0]); pin_staged(xreg[j][1]); }
-#pragma unroll
-        for (int j = 0; j < C::NPY; ++j) { pin_staged(yreg[j][0]); pin_staged(yreg[j][1]); }
-        const int t_ = opaque(tid);
-#pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
-            const int u = t_ + 256 * j;
-            const int row = u / XU;
-            const int kk = row / PH, r = row % PH;
-            const int col0 = ox0 - p.pad_x + 8 * (u % XU);
-            // the unit that was fetched from offset 0 instead of -pad (see prefetch): first channel, first row, left halo
-            const bool shifted = col0 < 0 && k0 + kk == 0 && oy0 - p.pad_y + r == 0;
-            const float sc = scaled ? s_scale[min(kk, KT - 1)] : 1.f;
+            const unsigned d = (unsigned)opaque((int)xdesc[j]);       // opaque: nothing derived from the descriptor may be hoisted out of the tile loop (registers)
+            const float sc = scaled ? s_scale[(d >> 24) & 63u] : 1.f;
             uint4 h, l;
-            unit8(xreg[j], col0, p.in_w, sc, shifted, &h, &l);       // rows / channels outside the image were loaded as zeros
-            if (u < C::NXU) {
-                const int o = kk * C::CSX + r * XU + u % XU;
-                xh[o] = h; xl[o] = l;
-            }
+            unit8(xreg[j], ox0 - p.pad_x + 8 * (int)((d >> 16) & 15u), p.in_w, sc, &h, &l);      // rows / channels outside the image were loaded as zeros
+            if (256 * (j + 1) <= C::NXU || tid + 256 * j < C::NXU) { xh[d & 0xffffu] = h; xl[d & 0xffffu] = l; }
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
-            const int u = t_ + 256 * j;
-            const int row = u / YU;
-            const float sc = scaled ? s_scale[KT + min(row / TR, NTL - 1)] : 1.f;
+            const unsigned d = (unsigned)opaque((int)ydesc[j]);
+            const float sc = scaled ? s_scale[KT + ((d >> 24) & 63u)] : 1.f;
             uint4 h, l;
-            unit8(yreg[j], ox0 + 8 * (u % YU), p.out_w, sc, false, &h, &l);
-            if (u < C::NYU) {
-                const int o = (row / TR) * C::CSY + (row % TR) * YU + u % YU;
-                yh[o] = h; yl[o] = l;
+            unit8(yreg[j], ox0 + 8 * (int)((d >> 16) & 15u), p.out_w, sc, &h, &l);
+            if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; yl[d & 0xffffu] = l; }
+        }
+        // the one unit per sample that was fetched from offset 0 instead of -pad (see prefetch): channel 0, image row 0, left halo
+        if (k0 == 0 && ox0 == 0 && p.pad_x > 0 && oy0 < PH && oy0 - p.pad_y <= 0) {          // uniform and rare
+            __syncthreads();
+            if (tid == 0) {
+                const int r = p.pad_y - oy0;                 // patch row that holds image row 0
+                const float* row0 = p.x + (size_t)b * p.K * xchan;
+                float v[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) { const int c = q - p.pad_x; v[q] = (c >= 0 && c < p.in_w) ? row0[c] : 0.f; }
+                uint4 h, l;
+                split8(v, scaled ? s_scale[0] : 1.f, &h, &l);
+                xh[r * XU] = h; xl[r * XU] = l;
             }
         }
     };
@@ -648,8 +656,10 @@ struct WgS2Cfg {
     static constexpr int NT = KS * KS;
 };
 
-// TR = 2: 110 KB of LDS, one workgroup per CU with the whole register file; TR = 1: 64 KB, two per CU (the second hides the
-// staging phases of the first, but every input row is fetched 3 instead of 2.5 times): better on planes <= 128 wide.
+// Dispatched with two workgroups per CU (64 KB of LDS each): 64k x 64n tiles of ONE output row (the second workgroup hides the
+// staging phases of the first; every input row is fetched 3 instead of 2.5 times, from L2 since tiles run down a column strip),
+// or 32k x 64n tiles of two rows for 32..63 input channels.  A two-row 64k x 64n tile needs 110 KB -- one workgroup per CU --
+// and measured 130 against 171 TFLOP/s on 64 -> 128 channels at 513^2.
 template <int TR, int KS, int WK>
 __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
     using C = WgS2Cfg<TR, KS, WK>;
@@ -880,7 +890,7 @@ WgPlan plan_wg(const gc_conv_desc* d) {
     pl.ct = pl.small ? 32 : 64;
     pl.kt = (d->down == 2 && d->in_ch < 64) ? 32 : pl.ct;      // stride 2 with 32..63 input channels: 32k x 64n tiles
     pl.tr = pl.small ? 4 : 2;
-    if (d->down == 2 && d->out_w <= 128 && pl.kt == 64) pl.tr = 1;     // stride 2, small planes: one output row per tile, two workgroups per CU
+    if (d->down == 2 && pl.kt == 64) pl.tr = 1;     // stride 2, 64k x 64n: one output row per tile keeps two workgroups per CU (two-row tiles need 110 KB of LDS: 130 vs 171 TFLOP/s)     // stride 2, small planes: one output row per tile, two workgroups per CU
     pl.tiles_x = gc::ceil_div(d->out_w, 32);
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
@@ -1265,13 +1275,19 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
             if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 3, 2>), grid, dim3(256), 0, s, a);
             else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 1, 2>), grid, dim3(256), 0, s, a);
         } else {
-            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 3, 2>), grid, dim3(256), 0, s, a);
-            else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 1, 2>), grid, dim3(256), 0, s, a);
+            return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_bf16x3_f32: no stride-2 kernel for this tile plan");
         }
     } else if (pl.small) {
         if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 4, 3>), grid, dim3(256), 0, s, a);
         else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 4, 1>), grid, dim3(256), 0, s, a);
     } else {
+#if defined(GC_ABL)      // dev ablation: GC_ABL_DYNLDS=<bytes> of dynamic LDS forces one workgroup per CU
+        static const int dyn = getenv("GC_ABL_DYNLDS") ? atoi(getenv("GC_ABL_DYNLDS")) : 0;
+        if (dyn > 0 && d->kh == 3) {
+            hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_bf16x3_kernel<2, 2, 1, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, dyn);
+            hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 3>), grid, dim3(256), dyn, s, a);
+        } else
+#endif
         if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 3>), grid, dim3(256), 0, s, a);
         else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 1>), grid, dim3(256), 0, s, a);
     }
