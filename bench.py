@@ -193,10 +193,17 @@ def main():
                                    'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
                                    'launches': dom['launches'], 'avg_launch_us': dom['avg_us'],
                                    'gpu_time_share': dom['total_ms'] / (1e3 * elapsed)}
+                traffic_file = os.path.join(REPO, 'profiles', 'pmc_r01_traffic.json')
+                if os.path.exists(traffic_file):      # separate rocprofv3 --pmc passes (tools/pmc_mix.py), launch-weighted over this kernel's shape mix
+                    pmc = json.load(open(traffic_file))
+                    if pmc.get('kernel') == name:
+                        out['roofline']['traffic'] = pmc['traffic_bytes_per_launch']
+                        out['roofline']['traffic_unit'] = 'bytes/launch'
+                        out['roofline']['traffic_source'] = pmc['source']
                 if split:
                     out['roofline']['note'] = ('achieved = ALGORITHMIC flops/s; the split-bf16 kernel issues 3 bf16 MFMAs per product, '
                                                'so the matrix pipes do 3x this (frac of bf16 peak spent = %.3f) and frac <= 1/3 by construction; '
-                                               'HBM traffic per launch from separate PMC passes: profiles/pmc_r01.md' % (3 * ach / peak))
+                                               'per-shape PMC traffic: profiles/pmc_r01_traffic.json, profiles/pmc_r01.md' % (3 * ach / peak))
             fir = summ.get('fir44_tile_kernel')
             if fir:
                 ach = fir['work'] / (fir['total_ms'] * 1e-3) / 1e9
