@@ -1084,33 +1084,50 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
         }
     }
 
+    // The phases px = 0 / 1 of one input column are NEIGHBOURS in the output row: they leave as one 8-byte store (4-byte aligned:
+    // rows of a 1025-wide plane start anywhere), half the store instructions and whole 128-byte segments per 16 lanes.
+    typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
     float* yb = p.y + (size_t)b * p.N * p.out_h * p.out_w;
     const EpilogueConsts ec = epilogue_consts(p);
+    float nz[WPX][2][2];         // fetched before the first store: a load between stores waits for every store before it
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         const int qy = qy0 + (wave_px * WPX + j) * RPB + l31 / TPW, qx = qx0 + l31 % TPW;
 #pragma unroll
         for (int ph = 0; ph < 4; ++ph) {
-            const int oy = 2 * qy + (ph >> 1), ox = 2 * qx + (ph & 1);
+            const int oy = min(2 * qy + (ph >> 1), p.out_h - 1), ox = min(2 * qx + (ph & 1), p.out_w - 1);
+            nz[j][ph >> 1][ph & 1] = (EPI == 2 && p.noise) ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) {
+        const int qy = qy0 + (wave_px * WPX + j) * RPB + l31 / TPW, qx = qx0 + l31 % TPW;
+#pragma unroll
+        for (int py = 0; py < 2; ++py) {
+            const int oy = 2 * qy + py, ox = 2 * qx;
             if (oy >= p.out_h || ox >= p.out_w) continue;
-            const float nz = p.noise ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
-            float res[16];
+            const bool pair = ox + 1 < p.out_w;
+            float res[2][16];
             if (EPI == 2 && p.residual) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int oc = min(n0 + wave_oc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi, p.N - 1);
-                    res[r] = p.residual[(((size_t)b * p.N + oc) * p.out_h + oy) * p.out_w + ox];
+                    const float* rp = p.residual + (((size_t)b * p.N + oc) * p.out_h + oy) * p.out_w + ox;
+                    res[0][r] = rp[0];
+                    res[1][r] = pair ? rp[1] : 0.f;
                 }
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int ocl = wave_oc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (n0 + ocl < p.N) {
-                    float v = acc[ph][j][r];
-                    if (EPI == 1) v *= s_so[ocl];
-                    if (EPI == 2) v = conv_epilogue(ec, v, s_so[ocl], s_bias[ocl], nz);
-                    if (EPI == 2 && p.residual) v += res[r];
-                    yb[((size_t)(n0 + ocl) * p.out_h + oy) * p.out_w + ox] = v;
+                    float v0 = acc[py * 2][j][r], v1 = acc[py * 2 + 1][j][r];
+                    if (EPI == 1) { v0 *= s_so[ocl]; v1 *= s_so[ocl]; }
+                    if (EPI == 2) { v0 = conv_epilogue(ec, v0, s_so[ocl], s_bias[ocl], nz[j][py][0]); v1 = conv_epilogue(ec, v1, s_so[ocl], s_bias[ocl], nz[j][py][1]); }
+                    if (EPI == 2 && p.residual) { v0 += res[0][r]; v1 += res[1][r]; }
+                    float* yp = yb + ((size_t)(n0 + ocl) * p.out_h + oy) * p.out_w + ox;
+                    if (pair) { f2u v = {v0, v1}; *reinterpret_cast<f2u*>(yp) = v; }
+                    else yp[0] = v0;
                 }
             }
         }
