@@ -576,7 +576,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
 #endif
                             acc[ty * KS + tx] = c;
                         }
-                        if (KS == 3) __builtin_amdgcn_sched_barrier(0);
+                        if (KS == 3) __builtin_amdgcn_sched_barrier(0x100);
                     }
                 }
             }
@@ -828,12 +828,12 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
                             const uint4 e1h = xh[o + 1], e1l = xl[o + 1];
                             const uint4 sh = shift_px(e0h, e1h, 1), sl = shift_px(e0l, e1l, 1);
                             tap(0, e0h, e0l);
-                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_sched_barrier(0x100);
                             const uint4 o0h = xh[o + XE], o0l = xl[o + XE];
                             tap(2, sh, sl);
-                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_sched_barrier(0x100);
                             tap(1, o0h, o0l);
-                            __builtin_amdgcn_sched_barrier(0);
+                            __builtin_amdgcn_sched_barrier(0x100);
                         } else {
                             tap(0, e0h, e0l);
                         }
