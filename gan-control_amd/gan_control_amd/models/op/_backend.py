@@ -64,6 +64,8 @@ class HipBackend:
             if tuple(taps.shape) == (4, 4) and n * c <= 65535:
                 if up == 1 and down == 1 and out_w >= 64 and out_h >= 16:
                     name = 'fir44_tile_kernel'
+                elif up == 1 and down == 1 and (out_h + 3) * (out_w + 3) <= 1296:
+                    name = 'fir44_small_kernel'
                 elif (up, down) == (1, 2) and out_w >= 32 and out_h >= 8:
                     name = 'fir44_down2_kernel'
                 elif (up, down) == (2, 1) and out_w >= 32 and out_h >= 8:
