@@ -149,6 +149,62 @@ __global__ __launch_bounds__(256) void bias_act_bwd_reduce_kernel(
     }
 }
 
+// Adjoint of the pass above (see gc_bias_act_bwd_reduce_adjoint_f32): every cotangent of a chunk reduction is one scalar per
+// (plane, chunk), so the whole second-order formula is a single elementwise pass with two small reductions.
+__global__ __launch_bounds__(256) void bias_act_bwd_reduce_adjoint_kernel(
+    const float* __restrict__ ggx, const float* __restrict__ cs, const float* __restrict__ cd, const float* __restrict__ cw,
+    const float* __restrict__ yref, const float* __restrict__ dx, const float* __restrict__ noise, const float* __restrict__ bias,
+    const float* __restrict__ noise_w, float* __restrict__ g_dy, float* __restrict__ g_yref, float* __restrict__ pgb, float* __restrict__ pgn,
+    int channels, int64_t inner, int chunks, int64_t chunk_len, float pos, float neg) {
+    __shared__ float lds[4];
+    const int plane = blockIdx.y, j = blockIdx.x;
+    const int b = plane / channels, c = plane % channels;
+    const size_t base = (size_t)plane * inner, pj = (size_t)plane * chunks + j;
+    const float* np = noise ? noise + (size_t)b * inner : nullptr;
+    const float bv = bias ? bias[c] : 0.f, nw = (noise && noise_w) ? noise_w[0] : 0.f;
+    const float ipos = 1.f / pos, ineg = 1.f / neg;
+    const float vs = cs ? cs[pj] : 0.f, vd = (cd && noise) ? cd[pj] : 0.f, vw = cw ? cw[pj] : 0.f;
+    const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
+    float sb = 0.f, sn = 0.f;
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    auto one = [&](float yv, float gg, float gxv, float nz, float* gyref) {
+        const bool up = yv > 0.f;
+        const float xpre = yv * (up ? ipos : ineg) - bv - nw * nz;
+        const float total = gg + vs + vd * nz + vw * xpre;
+        const float wg = vw * gxv;
+        sb += wg;
+        sn = fmaf(wg, nz, sn);
+        *gyref = wg * (up ? ipos : ineg);
+        return total * (up ? pos : neg);
+    };
+    const int64_t n4 = (hi - lo) >> 2;
+    for (int64_t v = threadIdx.x; v < n4; v += 256) {
+        const int64_t i = lo + 4 * v;
+        const f4u y4 = *reinterpret_cast<const f4u*>(yref + base + i);
+        f4u g4 = {0.f, 0.f, 0.f, 0.f}, x4 = g4, z4 = g4, r4;
+        if (ggx) g4 = *reinterpret_cast<const f4u*>(ggx + base + i);
+        if (cw) x4 = *reinterpret_cast<const f4u*>(dx + base + i);
+        if (np) z4 = *reinterpret_cast<const f4u*>(np + i);
+        float r0, r1, r2, r3;
+        const f4u o4 = {one(y4.x, g4.x, x4.x, z4.x, &r0), one(y4.y, g4.y, x4.y, z4.y, &r1), one(y4.z, g4.z, x4.z, z4.z, &r2), one(y4.w, g4.w, x4.w, z4.w, &r3)};
+        *reinterpret_cast<f4u*>(g_dy + base + i) = o4;
+        if (g_yref) { r4 = {r0, r1, r2, r3}; *reinterpret_cast<f4u*>(g_yref + base + i) = r4; }
+    }
+    for (int64_t i = lo + 4 * n4 + threadIdx.x; i < hi; i += 256) {
+        float r;
+        g_dy[base + i] = one(yref[base + i], ggx ? ggx[base + i] : 0.f, cw ? dx[base + i] : 0.f, np ? np[i] : 0.f, &r);
+        if (g_yref) g_yref[base + i] = r;
+    }
+    if (pgb) {
+        const float rb = block_sum(sb, lds);
+        if (threadIdx.x == 0) pgb[pj] = rb;
+    }
+    if (pgn) {
+        const float rn = block_sum(sn, lds);
+        if (threadIdx.x == 0) pgn[pj] = rn;
+    }
+}
+
 // partial[plane][chunk] = sum over the chunk of a * b  (per-sample modulation / demodulation gradients)
 __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial,
                                                         int64_t inner, int chunks, int64_t chunk_len) {
@@ -301,6 +357,23 @@ extern "C" int gc_bias_act_bwd_reduce_self_f32(const float* dy, const float* y_r
     else       { if (pself) GC_LAUNCH(false, true); else GC_LAUNCH(false, false); }
 #undef GC_LAUNCH
     return gc::check_launch("gc_bias_act_bwd_reduce_f32");
+}
+
+extern "C" int gc_bias_act_bwd_reduce_adjoint_f32(const float* ggx, const float* cs, const float* cd, const float* cw, const float* y_ref, const float* dx,
+                                                  const float* noise, const float* bias, const float* noise_w, float* g_dy, float* g_yref, float* pgb, float* pgn,
+                                                  int batch, int channels, int64_t inner, float slope, float gain, gc_stream_t stream) {
+    if (!y_ref || !g_dy) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_adjoint_f32: null pointer");
+    if (cw && !dx) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_adjoint_f32: cw needs dx");
+    if (cw && noise && !noise_w) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_adjoint_f32: cw with noise needs noise_w");
+    if (cd && !noise) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_adjoint_f32: cd needs noise");
+    if (slope == 0.f || gain == 0.f) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_adjoint_f32: needs an invertible activation (slope, gain != 0)");
+    if (batch <= 0 || channels <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_adjoint_f32: bad extents");
+    if ((int64_t)batch * channels > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_adjoint_f32: more than 65535 planes");
+    int chunks; int64_t len;
+    channel_sum_plan(inner, &chunks, &len);
+    hipLaunchKernelGGL(bias_act_bwd_reduce_adjoint_kernel, dim3(chunks, batch * channels), dim3(256), 0, (hipStream_t)stream, ggx, cs, cd, cw, y_ref, dx,
+                       noise, bias, noise_w, g_dy, g_yref, pgb, pgn, channels, inner, chunks, len, gain, gain * slope);
+    return gc::check_launch("gc_bias_act_bwd_reduce_adjoint_f32");
 }
 
 extern "C" int gc_bias_act_bwd_reduce_f32(const float* dy, const float* y_ref, const float* noise, float* dx,

@@ -176,6 +176,31 @@ class HipBackend:
         _lib.check(rc, 'gc_bias_act_bwd_reduce_self_f32')
         return dx, psum, pdot, pself
 
+    def bias_act_bwd_reduce_adjoint(self, ggx, cs, cd, cw, y_ref, dx, noise, bias, noise_w, slope, gain, want_gyref):
+        """Second-order pass through bias_act_bwd_reduce -> (g_dy, g_yref | None, pgb | None, pgn | None); see gc_bias_act_bwd_reduce_adjoint_f32."""
+        dev = _lib.require_cuda_f32(y_ref, ggx, cs, cd, cw, dx, noise, bias, noise_w)
+        batch, ch = y_ref.shape[0], y_ref.shape[1]
+        inner = y_ref.numel() // (batch * ch)
+        lib = _lib.load()
+        chunks = lib.gc_bias_act_bwd_chunks(inner)
+        for t in (cs, cd, cw):
+            if t is not None and tuple(t.shape) != (batch, ch, chunks):
+                raise RuntimeError('bias_act_bwd_reduce_adjoint: cotangent shape %s, expected %s' % (tuple(t.shape), (batch, ch, chunks)))
+        g_dy = torch.empty_like(y_ref)
+        g_yref = torch.empty_like(y_ref) if (want_gyref and cw is not None) else None
+        pgb = torch.empty((batch, ch, chunks), dtype=y_ref.dtype, device=dev) if cw is not None else None
+        pgn = torch.empty((batch, ch, chunks), dtype=y_ref.dtype, device=dev) if (cw is not None and noise is not None) else None
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_bias_act_bwd_reduce_adjoint_f32(_lib.ptr(ggx), _lib.ptr(cs), _lib.ptr(cd), _lib.ptr(cw), _lib.ptr(y_ref), _lib.ptr(dx), _lib.ptr(noise),
+                                                        _lib.ptr(bias), _lib.ptr(noise_w), _lib.ptr(g_dy), _lib.ptr(g_yref), _lib.ptr(pgb), _lib.ptr(pgn),
+                                                        batch, ch, inner, slope, gain, _lib.stream_of(y_ref))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_bias_act_bwd_reduce_adjoint_f32')
+        return g_dy, g_yref, pgb, pgn
+
     def plane_dot(self, a, b):
         """[B, C, *] x [B, C, *] -> [B, C]: sum over the trailing dims of a * b."""
         dev = _lib.require_cuda_f32(a, b)

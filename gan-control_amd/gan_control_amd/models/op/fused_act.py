@@ -116,6 +116,21 @@ class _BiasActGradReduce(Function):
         y, noise, bias, noise_w, gx = ctx.saved_tensors
         slope, gain = ctx.cfg
         b = y.shape[0]
+        if not torch.is_grad_enabled() and slope != 0 and gain != 0:
+            # the usual case (the regulariser's own backward): one fused pass; the ATen formulas below stay for higher orders
+            def chunked(t):
+                return None if (t is None or t.numel() == 0) else t.contiguous()
+            cw = chunked(gpself) if ctx.self_dot else None
+            g_gy, g_y, pgb, pgn = _backend.get().bias_act_bwd_reduce_adjoint(
+                None if ggx is None else ggx.contiguous(), chunked(gpsum), chunked(gpdot) if ctx.has_noise else None, cw, y,
+                gx if cw is not None else None, noise.contiguous() if ctx.has_noise else None, bias if (cw is not None and ctx.has_bias) else None,
+                noise_w if (cw is not None and ctx.has_noise) else None, slope, gain, want_gyref=ctx.needs_input_grad[1])
+            g_bias = g_nw = None
+            if cw is not None and ctx.has_bias and ctx.needs_input_grad[5]:
+                g_bias = -pgb.sum((0, 2))
+            if cw is not None and ctx.has_noise and ctx.needs_input_grad[6]:
+                g_nw = -pgn.sum().reshape(noise_w.shape)
+            return (g_gy if ctx.needs_input_grad[0] else None), g_y, None, None, None, g_bias, g_nw, None
         noise4 = noise.reshape(b, 1, *y.shape[2:]) if ctx.has_noise else None
         total = torch.zeros_like(y) if ggx is None else ggx
         if gpsum is not None:

@@ -118,6 +118,20 @@ int gc_bias_act_bwd_reduce_self_f32(const float* dy, const float* y_ref, const f
                                     float* dx, float* psum, float* pdot, float* pself, int batch, int channels, int64_t inner,
                                     float slope, float gain, gc_stream_t stream);
 
+/* ADJOINT of gc_bias_act_bwd_reduce_self_f32 with respect to dy (and to y_ref through pself): the second-order pass of the R1 and
+ * path-length regularisers (d_r1_loss / g_path_regularize, generator_trainer.py / gan_model.py) through an activation backward.
+ * Cotangents: ggx [B,C,inner] of dx (may be NULL), cs / cd / cw [B,C,chunks] of psum / pdot / pself (each may be NULL).  With
+ *   total = ggx + cs + cd * noise + cw * x_pre      (x_pre as above)
+ *   g_dy   = total * (y_ref > 0 ? gain : gain * slope)
+ *   g_yref = cw * dx * (y_ref > 0 ? 1 / gain : 1 / (gain * slope))            (only with cw; dx = the first pass's output)
+ *   pgb[(b*C + c)*chunks + j] = sum over chunk j of cw * dx          (bias gradient   = -sum over b, j)
+ *   pgn[(b*C + c)*chunks + j] = sum over chunk j of cw * dx * noise  (noise_w gradient = -sum over everything)
+ * one read of each input and one write of each output instead of ~14 elementwise passes.  g_yref / pgb / pgn may be NULL;
+ * dx is required when cw is given. */
+int gc_bias_act_bwd_reduce_adjoint_f32(const float* ggx, const float* cs, const float* cd, const float* cw, const float* y_ref, const float* dx,
+                                       const float* noise, const float* bias, const float* noise_w, float* g_dy, float* g_yref, float* pgb, float* pgn,
+                                       int batch, int channels, int64_t inner, float slope, float gain, gc_stream_t stream);
+
 /* partial[p*chunks + j] = sum over chunk j of a[p,:] * b[p,:], chunks = gc_bias_act_bwd_chunks(inner); planes = B*C.
  * Gradients of the per-sample modulation / demodulation factors of K3 (sum_hw x * dx and sum_hw dy * y). */
 int gc_plane_dot_f32(const float* a, const float* b, float* partial, int planes, int64_t inner, gc_stream_t stream);

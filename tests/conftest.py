@@ -112,6 +112,43 @@ class EmulatedBackend:
             pself = (flat * chunked(pre)).sum(3)
         return dx, psum, pdot, pself
 
+    def bias_act_bwd_reduce_adjoint(self, ggx, cs, cd, cw, y_ref, dx, noise, bias, noise_w, slope, gain, want_gyref):
+        b, c = y_ref.shape[0], y_ref.shape[1]
+        inner = y_ref.numel() // (b * c)
+        chunk = 16384
+
+        def spread(t):
+            return t.repeat_interleave(chunk, dim=2)[:, :, :inner].reshape(y_ref.shape)
+
+        nz = None if noise is None else noise.reshape(b, 1, *y_ref.shape[2:])
+        total = torch.zeros_like(y_ref) if ggx is None else ggx.clone()
+        if cs is not None:
+            total = total + spread(cs)
+        if cd is not None:
+            total = total + spread(cd) * nz
+        g_yref = pgb = pgn = None
+        if cw is not None:
+            w = spread(cw)
+            pre = torch.where(y_ref > 0, y_ref / gain, y_ref / (gain * slope))
+            if bias is not None:
+                pre = pre - bias.reshape([1, -1] + [1] * (y_ref.ndim - 2))
+            if nz is not None:
+                pre = pre - noise_w * nz
+            total = total + w * pre
+            wg = w * dx
+            if want_gyref:
+                g_yref = torch.where(y_ref > 0, wg / gain, wg / (gain * slope))
+
+            def chunk_sums(t):
+                flat = F.pad(t.reshape(b, c, inner), [0, -(-inner // chunk) * chunk - inner])
+                return flat.reshape(b, c, -1, chunk).sum(3)
+
+            pgb = chunk_sums(wg)
+            if nz is not None:
+                pgn = chunk_sums(wg * nz)
+        g_dy = total * torch.where(y_ref > 0, torch.full_like(y_ref, gain), torch.full_like(y_ref, gain * slope))
+        return g_dy, g_yref, pgb, pgn
+
     def plane_dot(self, a, b):
         return (a * b).reshape(a.shape[0], a.shape[1], -1).sum(2)
 

@@ -556,3 +556,29 @@ def test_transposed_conv_grads_bf16x3(bf16x3_mode):
         gp = autograd.grad(out, [xp, wp], go.float().to(DEV))
         for a, c in zip(gp, gr):
             assert rel_err(a, c) < 5e-5
+
+
+@pytest.mark.parametrize('shape,noise,self_dot', [((2, 5, 33, 40), True, True), ((2, 5, 33, 40), False, True), ((3, 4, 150, 130), True, True),
+                                                  ((2, 6, 20, 17), True, False), ((1, 3, 7), False, False), ((2, 4, 129, 129), False, True)])
+def test_bias_act_bwd_reduce_adjoint(shape, noise, self_dot):
+    """The fused second-order pass (gc_bias_act_bwd_reduce_adjoint_f32) against the ATen formulas it replaces, through autograd:
+    the same double-backward computed with grad mode on (ATen branch) and off (HIP kernel)."""
+    from gan_control_amd.models.op import fused_act
+    gen = torch.Generator().manual_seed(sum(shape) + noise + 2 * self_dot)
+    slope, gain = 0.2, 2 ** 0.5
+    y = torch.randn(*shape, generator=gen).to(DEV)
+    y = torch.where(y.abs() < 0.05, torch.full_like(y, 0.3), y).requires_grad_(True)
+    gy = torch.randn(*shape, generator=gen).to(DEV).requires_grad_(True)
+    nz = torch.randn(shape[0], 1, *shape[2:], generator=gen).to(DEV) if noise else None
+    bias = torch.randn(shape[1], generator=gen).to(DEV).requires_grad_(True) if self_dot else None
+    nw = torch.randn(1, generator=gen).to(DEV).requires_grad_(True) if (self_dot and noise) else None
+    outs = fused_act._BiasActGradReduce.apply(gy, y, nz, slope, gain, bias, nw, self_dot)
+    live = [o for o in outs if o.numel() > 0 and o.requires_grad]
+    cots = [torch.randn(o.shape, generator=gen).to(DEV) for o in live]
+    wrt = [t for t in (gy, y, bias, nw) if t is not None]
+    ref = torch.autograd.grad(live, wrt, cots, retain_graph=True, create_graph=True, allow_unused=True)      # grad mode on: ATen formulas
+    out = torch.autograd.grad(live, wrt, cots, retain_graph=True, allow_unused=True)                          # grad mode off: the HIP pass
+    for r, o, name in zip(ref, out, ('gy', 'y', 'bias', 'noise_w')):
+        assert (r is None) == (o is None), name
+        if r is not None:
+            assert rel_err(o, r.detach()) < 1e-5, name
