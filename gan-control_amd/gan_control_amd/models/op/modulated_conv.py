@@ -38,7 +38,7 @@ def demod_coefficients(weight, s, scale, eps=1e-8):
 
 def _safe(scale):
     """Divisor for the scale gradients; an exactly-zero factor (measure zero) would otherwise give 0/0."""
-    return torch.where(scale == 0, torch.ones_like(scale), scale)
+    return torch.where(scale == 0, 1.0, scale)
 
 
 class _PlaneDot(Function):

@@ -1,7 +1,5 @@
 #!/bin/bash
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
-timeout -k 10 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-timeout -k 10 300 python bench.py --steps 32 --warmup 16 --no-cpu-baseline 2>&1 | tail -1 > gpurun_out/bench_latest.json
-cut -c1-200 gpurun_out/bench_latest.json
-timeout -k 10 300 python tools/train_sanity.py 2>&1 | tail -3
+echo "=== iter 20 (path)"; timeout -k 10 300 python tools/aten_profile.py --iter 20 --top 40 2>&1 | grep -v "amdgpu.ids\|Warn\|warn"
+echo "=== iter 16 (r1 + path)"; timeout -k 10 300 python tools/aten_profile.py --iter 16 --top 25 2>&1 | grep -v "amdgpu.ids\|Warn\|warn"
