@@ -889,7 +889,7 @@ WgPlan plan_wg(const gc_conv_desc* d) {
     pl.small = d->down == 1 && !(d->in_ch >= 64 && d->out_ch >= 64);
     pl.ct = pl.small ? 32 : 64;
     pl.kt = (d->down == 2 && d->in_ch < 64) ? 32 : pl.ct;      // stride 2 with 32..63 input channels: 32k x 64n tiles
-    pl.tr = pl.small ? 4 : 2;
+    pl.tr = pl.small ? 6 : 2;          // 32 x 32 channel tiles: six rows (81 MFMAs per wave between barriers, 65 KB of LDS; four rows: 923 vs 880 us at 32 -> 32 @1024^2)
     if (d->down == 2 && pl.kt == 64) pl.tr = 1;     // stride 2, 64k x 64n: one output row per tile keeps two workgroups per CU (two-row tiles need 110 KB of LDS: 130 vs 171 TFLOP/s)     // stride 2, small planes: one output row per tile, two workgroups per CU
     pl.tiles_x = gc::ceil_div(d->out_w, 32);
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
@@ -1295,8 +1295,8 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
             return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_bf16x3_f32: no stride-2 kernel for this tile plan");
         }
     } else if (pl.small) {
-        if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 4, 3>), grid, dim3(256), 0, s, a);
-        else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 4, 1>), grid, dim3(256), 0, s, a);
+        if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 6, 3>), grid, dim3(256), 0, s, a);
+        else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 6, 1>), grid, dim3(256), 0, s, a);
     } else {
 #if defined(GC_ABL)      // dev ablation: GC_ABL_DYNLDS=<bytes> of dynamic LDS forces one workgroup per CU
         static const int dyn = getenv("GC_ABL_DYNLDS") ? atoi(getenv("GC_ABL_DYNLDS")) : 0;
