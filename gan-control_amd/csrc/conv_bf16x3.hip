@@ -16,6 +16,7 @@
 // ds_read_b128 at a shifted unit index -- plus the [tap][2][OCT] weight units (A fragments).
 // Register-prefetch pipeline over chunks, compile-time geometry, phase decomposition for up = 2.
 #include "conv_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     const unsigned wbytes = (unsigned)(KS * KS) * a.kgroups * p.N * 16u;
     const __amdgpu_buffer_rsrc_t rwh = make_rsrc(a.wh, wbytes), rwl = make_rsrc(a.wl, wbytes);
     auto prefetch = [&](int tile, int k0) {
-        const int t_ = opaque(tid);
+        const int t_ = tid;
         const int iy0 = (tile / p.tiles_x) * TPH * DOWN + ay.d0, ix0 = (tile % p.tiles_x) * 32 * DOWN + ax.d0;
         // weights: unit u -> (tap, kg, oc); plain 16-byte copies of the pre-split slab
 #pragma unroll
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
         }
     };
     auto commit = [&](int tile, int k0) {
-        const int t_ = opaque(tid);
+        const int t_ = tid;
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
             const int u = t_ + 256 * j;
@@ -214,29 +215,36 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
         // per-sample input scales of this chunk (zero beyond K: a ragged last chunk contributes nothing)
         const float4 sa = *reinterpret_cast<const float4*>(&s_si[k0 + kgl * 8]), sb = *reinterpret_cast<const float4*>(&s_si[k0 + kgl * 8 + 4]);
         const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+        // 16-byte groups start at multiples of four pixels (ix0 + lead is a multiple of 32), so in a row whose width is a multiple of
+        // four a group lies entirely inside the image or entirely outside (and was then fetched as zeros): the per-pixel row-end mask --
+        // 32 selects per chunk -- is only needed for the odd widths (the 1025-wide planes of the stride-2 convolutions).
+        const bool ragged_rows = (p.in_w & 3) != 0;
+        auto convert = [&](auto masked) {
 #pragma unroll
-        for (int j = 0; j < C::NT; ++j) {
-            const typename C::Task tk = C::task_of(tb + 128 * j, lead);
-            const int inrow = p.in_w - (ix0 + tk.col);               // pixels of this group that are still inside the image row
-            const int rbase = kgl * PLANE + tk.row * C::RP;
+            for (int j = 0; j < C::NT; ++j) {
+                const typename C::Task tk = C::task_of(tb + 128 * j, lead);
+                const int inrow = p.in_w - (ix0 + tk.col);               // pixels of this group that are still inside the image row
+                const int rbase = kgl * PLANE + tk.row * C::RP;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                bf16x8 h, l;
+                for (int i = 0; i < 4; ++i) {
+                    bf16x8 h, l;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    const unsigned raw = i == 0 ? preg[j][q].x : (i == 1 ? preg[j][q].y : (i == 2 ? preg[j][q].z : preg[j][q].w));
-                    const float v = i < inrow ? __uint_as_float(raw) * sc[q] : 0.f;
-                    const __bf16 hh = (__bf16)v;
-                    h[q] = hh;
-                    l[q] = (__bf16)(v - (float)hh);
-                }
-                if (i < tk.used) {
-                    const int u = rbase + C::ucol(tk.col + i);
-                    p_h[u] = *reinterpret_cast<uint4*>(&h);
-                    p_l[u] = *reinterpret_cast<uint4*>(&l);
+                    for (int q = 0; q < 8; ++q) {
+                        const unsigned raw = i == 0 ? preg[j][q].x : (i == 1 ? preg[j][q].y : (i == 2 ? preg[j][q].z : preg[j][q].w));
+                        const float v = (!decltype(masked)::value || i < inrow) ? __uint_as_float(raw) * sc[q] : 0.f;
+                        const __bf16 hh = (__bf16)v;
+                        h[q] = hh;
+                        l[q] = (__bf16)(v - (float)hh);
+                    }
+                    if (i < tk.used) {
+                        const int u = rbase + C::ucol(tk.col + i);
+                        p_h[u] = *reinterpret_cast<uint4*>(&h);
+                        p_l[u] = *reinterpret_cast<uint4*>(&l);
+                    }
                 }
             }
-        }
+        };
+        if (ragged_rows) convert(std::true_type{}); else convert(std::false_type{});
     };
     auto mfma_phase = [&]() {
         const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
