@@ -991,7 +991,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     const unsigned wbytes = 9u * a.kgroups * p.N * 16u;
     const __amdgpu_buffer_rsrc_t rwh = make_rsrc(a.wh, wbytes), rwl = make_rsrc(a.wl, wbytes);
     auto prefetch = [&](int k0) {
-        const int t_ = opaque(tid);
+        const int t_ = tid;
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
             const int u = t_ + 256 * j;
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     };
     auto commit = [&](int k0) {
         wait_staged_loads();
-        const int t_ = opaque(tid);
+        const int t_ = tid;
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
             const int u = t_ + 256 * j;
