@@ -364,13 +364,15 @@ class Generator(nn.Module):
                                 styles[1].unsqueeze(1).repeat(1, self.n_latent - inject_index, 1)], 1)
 
         out = self.input(latent)
-        out = self.conv1(out, latent[:, 0], noise=noise[0])
-        skip = self.to_rgb1(out, latent[:, 1])
+        # one unbind instead of 26 slices: its backward is a single stack, a slice's backward is a zero-fill + add of the whole latent
+        lat = latent.unbind(1)
+        out = self.conv1(out, lat[0], noise=noise[0])
+        skip = self.to_rgb1(out, lat[1])
         i = 1
         for up_conv, conv, n1, n2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2], self.to_rgbs):
-            out = up_conv(out, latent[:, i], noise=n1)
-            out = conv(out, latent[:, i + 1], noise=n2)
-            skip = to_rgb(out, latent[:, i + 2], skip)
+            out = up_conv(out, lat[i], noise=n1)
+            out = conv(out, lat[i + 1], noise=n2)
+            skip = to_rgb(out, lat[i + 2], skip)
             i += 2
         image = skip
         if return_grad:

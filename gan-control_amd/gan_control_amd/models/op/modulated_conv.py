@@ -33,7 +33,19 @@ from .upfirdn2d import upfirdn2d
 def demod_coefficients(weight, s, scale, eps=1e-8):
     """d[b,oc] = rsqrt(sum_{ic,k} (scale * W[oc,ic,k] * s[b,ic])^2 + eps); weight is [1,OC,IC,k,k], s is [B,IC]."""
     wsq = weight.view(weight.shape[1:]).pow(2).sum([2, 3])     # [OC, IC]  (view, not weight[0]: its backward is free)
-    return torch.rsqrt((s.pow(2) @ wsq.t()) * (scale * scale) + eps)
+    # scale^2 * (s^2 @ wsq^T) + eps as ONE GEMM call (alpha, bias epilogue) instead of GEMM + two elementwise launches
+    return torch.rsqrt(torch.addmm(_eps_vector(s, wsq.shape[0], eps), s.pow(2), wsq.t(), alpha=scale * scale))
+
+
+_EPS_VECTORS = {}
+
+
+def _eps_vector(like, n, eps):
+    key = (like.device, like.dtype, n, eps)
+    t = _EPS_VECTORS.get(key)
+    if t is None:
+        t = _EPS_VECTORS[key] = torch.full((n,), eps, device=like.device, dtype=like.dtype)
+    return t
 
 
 def _safe(scale):
