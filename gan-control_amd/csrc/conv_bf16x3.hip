@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
         // 16-byte groups start at multiples of four pixels (ix0 + lead is a multiple of 32), so in a row whose width is a multiple of
         // four a group lies entirely inside the image or entirely outside (and was then fetched as zeros): the per-pixel row-end mask --
         // 32 selects per chunk -- is only needed for the odd widths (the 1025-wide planes of the stride-2 convolutions).
-        const bool ragged_rows = (p.in_w & 3) != 0;
+        const bool ragged_rows = (p.in_w & 3) != 0 && ix0 + lead + 32 * C::SEG_M + 4 > p.in_w;      // ... and there only in the tiles that reach the row end
         auto convert = [&](auto masked) {
 #pragma unroll
             for (int j = 0; j < C::NT; ++j) {
