@@ -16,6 +16,12 @@
 // ds_read_b128 at a shifted unit index -- plus the [tap][2][OCT] weight units (A fragments).
 // Register-prefetch pipeline over chunks, compile-time geometry, phase decomposition for up = 2.
 #include "conv_common.h"
+
+// Wave priority during the MFMA phases: the co-resident workgroup is staging (vector ALU, LDS, loads) meanwhile; letting the
+// multiplying wave issue first keeps the matrix pipe fed (same-box A/B: -2 % forward, -1..3 % weight gradients).
+#ifndef GC_MFMA_PRIO
+#define GC_MFMA_PRIO 2
+#endif
 #include <type_traits>
 
 namespace {
@@ -341,7 +347,11 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     // in flight and the compiler plants no wait inside the next prefetch; the last item is peeled below.
     for (int it = 1; it < items; ++it) {
         prefetch(tile_n, k0_n);
-        mfma_phase();
+        __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
+        __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
+    mfma_phase();
+    __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         commit(tile_n, k0_n);                               // retires the loads first: no store is outstanding yet
         k0_n += KCB; if (k0_n >= p.K) { k0_n = 0; ++tile_n; }
@@ -557,6 +567,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
             prefetch(more ? tile + 1 : tile);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
+            __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
 #pragma unroll 1
             for (int step = 0; step < 2 * TR / WP; ++step) {
                 {
@@ -588,6 +599,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
             {
@@ -807,6 +819,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
             const bool more = tile + 1 < t_end;
             prefetch(more ? tile + 1 : tile);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
+            __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
 #pragma unroll ((TR == 1 || WK == 1) ? 1 : 2)
             for (int r = 0; r < TR; ++r) {
 #pragma unroll ((TR == 1 || WK == 1) ? 1 : 2)
@@ -848,6 +861,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
                     }
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             __syncthreads();
             if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
             {
@@ -1051,6 +1065,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
         wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
         const bool more = k0 + KCB < p.K;
         if (more) prefetch(k0 + KCB);
+        __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
 #pragma unroll
         for (int dyi = 0; dyi < 2; ++dyi) {
 #pragma unroll
@@ -1084,6 +1099,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
         {
