@@ -710,38 +710,60 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
     const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
 
     // Only the loaded data lives in registers between prefetch and commit: the per-sample scales sit in an LDS table
-    // (refilled when a split crosses into the next sample) and the border columns are recomputed from the tile index --
-    // with 144 accumulators the kernel otherwise spills inside the tile loop.
+    // (refilled when a split crosses into the next sample), and every staged item has ONE packed per-lane descriptor
+    // (LDS unit offset | item column << 16 | patch row << 20 | channel << 24 | idle lane << 31), made opaque per use so that
+    // nothing derived from it is hoisted into registers -- with 144 accumulators the kernel otherwise spills inside the tile loop.
     __shared__ float s_scale[KT + NTL];
     int b_tab = -1;
     float4 xreg[C::NPX][4], yreg[C::NPY][2];
+    constexpr unsigned OUTSIDE = 0x80000000u;    // beyond every buffer
+    auto xdesc_of = [&](int u) -> unsigned {
+        const int it = u % NI, row = u / NI;
+        const int r = row % PH, kk = min(row / PH, KT - 1);
+        const bool live = u < C::NXI && k0 + kk < p.K;
+        return (unsigned)(kk * C::CSX + r * RU + it) | (unsigned)it << 16 | (unsigned)r << 20 | (unsigned)kk << 24 | (live ? 0u : OUTSIDE);
+    };
+    auto ydesc_of = [&](int u) -> unsigned {
+        const int yu = u % YU, row = u / YU;
+        const int r = row % TR, nn = min(row / TR, NTL - 1);
+        const bool live = u < C::NYU && n0 + nn < p.N;
+        return (unsigned)(nn * C::CSY + r * YU + yu) | (unsigned)yu << 16 | (unsigned)r << 20 | (unsigned)nn << 24 | (live ? 0u : OUTSIDE);
+    };
+    // 64k x 64n: the descriptors stay in registers (6 of them); 32k x 64n has two more staged items per lane and no register to
+    // spare -- it rebuilds them from the lane index per use (measured: keeping them there costs scratch reloads in front of the loads)
+    constexpr bool KEEP = WK == 2;
+    unsigned xdesc[KEEP ? C::NPX : 1], ydesc[KEEP ? C::NPY : 1];
+    if (KEEP) {
+#pragma unroll
+        for (int j = 0; j < C::NPX; ++j) xdesc[j] = xdesc_of(tid + 256 * j);
+#pragma unroll
+        for (int j = 0; j < C::NPY; ++j) ydesc[j] = ydesc_of(tid + 256 * j);
+    }
+    auto xd = [&](int j) -> unsigned { return KEEP ? (unsigned)opaque((int)xdesc[KEEP ? j : 0]) : xdesc_of(opaque(tid) + 256 * j); };
+    auto yd = [&](int j) -> unsigned { return KEEP ? (unsigned)opaque((int)ydesc[KEEP ? j : 0]) : ydesc_of(opaque(tid) + 256 * j); };
     auto prefetch = [&](int tile) {
-        const int t_ = opaque(tid);
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
         const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows (L2 hits)
         const int iy0 = oy0 * 2, ix0 = ox0 * 2;                      // pad = 0 (checked on the host)
+        const int xoff = (k0 * xchan + iy0 * p.in_w + ix0) * 4, yoff = (n0 * ychan + oy0 * p.out_w + ox0) * 4;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
 #pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
-            const int u = t_ + 256 * j;
-            const int it = u % NI, row = u / NI;
-            const int r = row % PH, kk = row / PH;
-            const int k = k0 + kk, iy = iy0 + r, ixb = ix0 + 16 * it;
-            const bool ok = u < C::NXI && k < p.K && iy < p.in_h;
-            const unsigned off = ok ? (unsigned)(k * xchan + iy * p.in_w + ixb) * 4u : OOB;
+            const unsigned d = xd(j);
+            const int r = (int)((d >> 20) & 15u);
+            const int lin = (int)((d >> 24) & 63u) * (xchan * 4) + r * (p.in_w * 4) + (int)((d >> 16) & 15u) * 64 + xoff;
+            const unsigned off = ((int)d >= 0 && iy0 + r < p.in_h) ? (unsigned)lin : OUTSIDE;
 #pragma unroll
             for (int v = 0; v < 4; ++v) xreg[j][v] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 16 * v));
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
-            const int u = t_ + 256 * j;
-            const int yu = u % YU, row = u / YU;
-            const int r = row % TR, nn = row / TR;
-            const int n = n0 + nn, oy = oy0 + r, oxb = ox0 + 8 * yu;
-            const bool ok = u < C::NYU && n < p.N && oy < p.out_h;
-            const unsigned off = ok ? (unsigned)(n * ychan + oy * p.out_w + oxb) * 4u : OOB;
+            const unsigned d = yd(j);
+            const int r = (int)((d >> 20) & 15u);
+            const int lin = (int)((d >> 24) & 63u) * (ychan * 4) + r * (p.out_w * 4) + (int)((d >> 16) & 15u) * 32 + yoff;
+            const unsigned off = ((int)d >= 0 && oy0 + r < p.out_h) ? (unsigned)lin : OUTSIDE;
             yreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 0));
             yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 16));
         }
@@ -765,13 +787,12 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             for (int v = 0; v < 4; ++v) pin_staged(xreg[j][v]);
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) { pin_staged(yreg[j][0]); pin_staged(yreg[j][1]); }
-        const int t_ = opaque(tid);
 #pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
-            const int u = t_ + 256 * j;
-            const int it = u % NI, row = u / NI;
+            const unsigned d = xd(j);
+            const int it = (int)((d >> 16) & 15u), o = (int)(d & 0xffffu);
             const int col0 = 2 * ox0 + 16 * it;          // rows / channels outside the image were loaded as zeros already
-            const float sc = scaled ? s_scale[min(row / PH, KT - 1)] : 1.f;
+            const float sc = scaled ? s_scale[(d >> 24) & 63u] : 1.f;
             const float4* q4 = xreg[j];
             const float v[16] = {q4[0].x, q4[0].y, q4[0].z, q4[0].w, q4[1].x, q4[1].y, q4[1].z, q4[1].w,
                                  q4[2].x, q4[2].y, q4[2].z, q4[2].w, q4[3].x, q4[3].y, q4[3].z, q4[3].w};
@@ -781,32 +802,27 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             for (int q = 0; q < 8; ++q) { ev[q] = 2 * q < room ? v[2 * q] : 0.f; od[q] = 2 * q + 1 < room ? v[2 * q + 1] : 0.f; }
             uint4 eh, el, oh, ol;
             split8(ev, sc, &eh, &el);
-            if (u < C::NXI) {
-                const int o = (row / PH) * C::CSX + (row % PH) * RU;
-                xh[o + it] = eh; xl[o + it] = el;
+            if (256 * (j + 1) <= C::NXI || tid + 256 * j < C::NXI) {
+                xh[o] = eh; xl[o] = el;
                 if (KS == 3 && it < C::XO) {
                     split8(od, sc, &oh, &ol);
-                    xh[o + XE + it] = oh; xl[o + XE + it] = ol;
+                    xh[o + XE] = oh; xl[o + XE] = ol;
                 }
             }
             __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaving the conversions of several items costs more registers than there are
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
-            const int u = t_ + 256 * j;
-            const int row = u / YU;
-            const int col0 = ox0 + 8 * (u % YU);
-            const float sc = scaled ? s_scale[KT + min(row / TR, NTL - 1)] : 1.f;
+            const unsigned d = yd(j);
+            const int col0 = ox0 + 8 * (int)((d >> 16) & 15u);
+            const float sc = scaled ? s_scale[KT + ((d >> 24) & 63u)] : 1.f;
             float v[8] = {yreg[j][0].x, yreg[j][0].y, yreg[j][0].z, yreg[j][0].w, yreg[j][1].x, yreg[j][1].y, yreg[j][1].z, yreg[j][1].w};
             const int room = p.out_w - col0;
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = q < room ? v[q] : 0.f;
             uint4 h, l;
             split8(v, sc, &h, &l);
-            if (u < C::NYU) {
-                const int o = (row / TR) * C::CSY + (row % TR) * YU + u % YU;
-                yh[o] = h; yl[o] = l;
-            }
+            if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; yl[d & 0xffffu] = l; }
         }
     };
 
