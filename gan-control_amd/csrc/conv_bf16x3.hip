@@ -782,12 +782,6 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
         }
         wait_staged_loads();
 #pragma unroll
-        for (int j = 0; j < C::NPX; ++j)
-#pragma unroll
-            for (int v = 0; v < 4; ++v) pin_staged(xreg[j][v]);
-#pragma unroll
-        for (int j = 0; j < C::NPY; ++j) { pin_staged(yreg[j][0]); pin_staged(yreg[j][1]); }
-#pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
             const unsigned d = xd(j);
             const int it = (int)((d >> 16) & 15u), o = (int)(d & 0xffffu);
