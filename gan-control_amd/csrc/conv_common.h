@@ -138,9 +138,6 @@ __device__ __forceinline__ uint4 buf_load_u128(__amdgpu_buffer_rsrc_t r, unsigne
 // serialises the pipeline.  simm16 = vmcnt(0) with expcnt / lgkmcnt left at their maxima.
 __device__ __forceinline__ void wait_staged_loads() { __builtin_amdgcn_s_waitcnt(0x0F70); }
 
-// Pins a staged register to this program point: nothing computed from it can be scheduled above (the compiler otherwise
-// hoists the first moves of the commit phase over the MFMA loop and waits for the prefetch before the MFMAs start).
-__device__ __forceinline__ void pin_staged(float4& q) { asm volatile("" : "+v"(q.x), "+v"(q.y), "+v"(q.z), "+v"(q.w)); }
 
 // defined in pointwise.hip: 1x1 convolutions with <= 4 channels on one side (ToRGB / FromRGB) on the vector ALUs
 bool pointwise_thin(const gc_conv_desc* d);
