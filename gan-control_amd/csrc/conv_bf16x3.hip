@@ -387,6 +387,7 @@ __device__ __forceinline__ uint4 shift_px(const uint4 a, const uint4 b, int tx) 
                       __builtin_amdgcn_alignbit(a.w, a.z, 16), __builtin_amdgcn_alignbit(b.x, a.w, 16));
 }
 
+template <bool SCALED = true>
 __device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4* h, uint4* l) {
 #if defined(GC_ABL) && GC_ABL == 2      // dev ablation: staging without the conversions
     *h = make_uint4(__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3]));
@@ -396,7 +397,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4* 
     bf16x8 hh, ll;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-        const float f = v[q] * scale;
+        const float f = SCALED ? v[q] * scale : v[q];
         const __bf16 t = (__bf16)f;
         hh[q] = t;
         ll[q] = (__bf16)(f - (float)t);
@@ -505,13 +506,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 16));
         }
     };
-    auto unit8 = [&](const float4 (&r)[2], int col0, int width, float scale, uint4* h, uint4* l) {
+    auto unit8 = [&](auto scaled_t, const float4 (&r)[2], int col0, int width, float scale, uint4* h, uint4* l) {
         float v[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
         if (col0 < 0 || col0 + 8 > width) {      // only lanes whose unit straddles an image border pay for the masks
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (col0 + q >= 0 && col0 + q < width) ? v[q] : 0.f;
         }
-        split8(v, scale, h, l);
+        split8<decltype(scaled_t)::value>(v, scale, h, l);
     };
     auto commit = [&](int tile) {
         const int b = tile / tiles_per_sample;
@@ -526,22 +527,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             b_tab = b;
         }
         wait_staged_loads();
+        auto items = [&](auto scaled_t) {          // without modulation (every layer of D) the multiply by one is not issued: it is packed fp32, which stalls the matrix pipe
+            constexpr bool SC = decltype(scaled_t)::value;
 #pragma unroll
-        for (int j = 0; j < C::NPX; ++j) {
-            const unsigned d = (unsigned)opaque((int)xdesc[j]);       // opaque: nothing derived from the descriptor may be hoisted out of the tile loop (registers)
-            const float sc = scaled ? s_scale[(d >> 24) & 63u] : 1.f;
-            uint4 h, l;
-            unit8(xreg[j], ox0 - p.pad_x + 8 * (int)((d >> 16) & 15u), p.in_w, sc, &h, &l);      // rows / channels outside the image were loaded as zeros
-            if (256 * (j + 1) <= C::NXU || tid + 256 * j < C::NXU) { xh[d & 0xffffu] = h; xl[d & 0xffffu] = l; }
-        }
+            for (int j = 0; j < C::NPX; ++j) {
+                const unsigned d = (unsigned)opaque((int)xdesc[j]);       // opaque: nothing derived from the descriptor may be hoisted out of the tile loop (registers)
+                const float sc = SC ? s_scale[(d >> 24) & 63u] : 1.f;
+                uint4 h, l;
+                unit8(scaled_t, xreg[j], ox0 - p.pad_x + 8 * (int)((d >> 16) & 15u), p.in_w, sc, &h, &l);      // rows / channels outside the image were loaded as zeros
+                if (256 * (j + 1) <= C::NXU || tid + 256 * j < C::NXU) { xh[d & 0xffffu] = h; xl[d & 0xffffu] = l; }
+            }
 #pragma unroll
-        for (int j = 0; j < C::NPY; ++j) {
-            const unsigned d = (unsigned)opaque((int)ydesc[j]);
-            const float sc = scaled ? s_scale[KT + ((d >> 24) & 63u)] : 1.f;
-            uint4 h, l;
-            unit8(yreg[j], ox0 + 8 * (int)((d >> 16) & 15u), p.out_w, sc, &h, &l);
-            if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; yl[d & 0xffffu] = l; }
-        }
+            for (int j = 0; j < C::NPY; ++j) {
+                const unsigned d = (unsigned)opaque((int)ydesc[j]);
+                const float sc = SC ? s_scale[KT + ((d >> 24) & 63u)] : 1.f;
+                uint4 h, l;
+                unit8(scaled_t, yreg[j], ox0 + 8 * (int)((d >> 16) & 15u), p.out_w, sc, &h, &l);
+                if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; yl[d & 0xffffu] = l; }
+            }
+        };
+        if (scaled) items(std::true_type{}); else items(std::false_type{});
         // the one unit per sample that was fetched from offset 0 instead of -pad (see prefetch): channel 0, image row 0, left halo
         if (k0 == 0 && ox0 == 0 && p.pad_x > 0 && oy0 < PH && oy0 - p.pad_y <= 0) {          // uniform and rare
             __syncthreads();
@@ -781,43 +786,47 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             b_tab = b;
         }
         wait_staged_loads();
+        auto items = [&](auto scaled_t) {
+            constexpr bool SC = decltype(scaled_t)::value;
 #pragma unroll
-        for (int j = 0; j < C::NPX; ++j) {
-            const unsigned d = xd(j);
-            const int it = (int)((d >> 16) & 15u), o = (int)(d & 0xffffu);
-            const int col0 = 2 * ox0 + 16 * it;          // rows / channels outside the image were loaded as zeros already
-            const float sc = scaled ? s_scale[(d >> 24) & 63u] : 1.f;
-            const float4* q4 = xreg[j];
-            const float v[16] = {q4[0].x, q4[0].y, q4[0].z, q4[0].w, q4[1].x, q4[1].y, q4[1].z, q4[1].w,
-                                 q4[2].x, q4[2].y, q4[2].z, q4[2].w, q4[3].x, q4[3].y, q4[3].z, q4[3].w};
-            const int room = p.in_w - col0;             // columns of this item inside the image (pad = 0: only the right border cuts)
-            float ev[8], od[8];
+            for (int j = 0; j < C::NPX; ++j) {
+                const unsigned d = xd(j);
+                const int it = (int)((d >> 16) & 15u), o = (int)(d & 0xffffu);
+                const int col0 = 2 * ox0 + 16 * it;          // rows / channels outside the image were loaded as zeros already
+                const float sc = SC ? s_scale[(d >> 24) & 63u] : 1.f;
+                const float4* q4 = xreg[j];
+                const float v[16] = {q4[0].x, q4[0].y, q4[0].z, q4[0].w, q4[1].x, q4[1].y, q4[1].z, q4[1].w,
+                                     q4[2].x, q4[2].y, q4[2].z, q4[2].w, q4[3].x, q4[3].y, q4[3].z, q4[3].w};
+                const int room = p.in_w - col0;             // columns of this item inside the image (pad = 0: only the right border cuts)
+                float ev[8], od[8];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) { ev[q] = 2 * q < room ? v[2 * q] : 0.f; od[q] = 2 * q + 1 < room ? v[2 * q + 1] : 0.f; }
-            uint4 eh, el, oh, ol;
-            split8(ev, sc, &eh, &el);
-            if (256 * (j + 1) <= C::NXI || tid + 256 * j < C::NXI) {
-                xh[o] = eh; xl[o] = el;
-                if (KS == 3 && it < C::XO) {
-                    split8(od, sc, &oh, &ol);
-                    xh[o + XE] = oh; xl[o + XE] = ol;
+                for (int q = 0; q < 8; ++q) { ev[q] = 2 * q < room ? v[2 * q] : 0.f; od[q] = 2 * q + 1 < room ? v[2 * q + 1] : 0.f; }
+                uint4 eh, el, oh, ol;
+                split8<SC>(ev, sc, &eh, &el);
+                if (256 * (j + 1) <= C::NXI || tid + 256 * j < C::NXI) {
+                    xh[o] = eh; xl[o] = el;
+                    if (KS == 3 && it < C::XO) {
+                        split8<SC>(od, sc, &oh, &ol);
+                        xh[o + XE] = oh; xl[o + XE] = ol;
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaving the conversions of several items costs more registers than there are
             }
-            __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaving the conversions of several items costs more registers than there are
-        }
 #pragma unroll
-        for (int j = 0; j < C::NPY; ++j) {
-            const unsigned d = yd(j);
-            const int col0 = ox0 + 8 * (int)((d >> 16) & 15u);
-            const float sc = scaled ? s_scale[KT + ((d >> 24) & 63u)] : 1.f;
-            float v[8] = {yreg[j][0].x, yreg[j][0].y, yreg[j][0].z, yreg[j][0].w, yreg[j][1].x, yreg[j][1].y, yreg[j][1].z, yreg[j][1].w};
-            const int room = p.out_w - col0;
+            for (int j = 0; j < C::NPY; ++j) {
+                const unsigned d = yd(j);
+                const int col0 = ox0 + 8 * (int)((d >> 16) & 15u);
+                const float sc = SC ? s_scale[KT + ((d >> 24) & 63u)] : 1.f;
+                float v[8] = {yreg[j][0].x, yreg[j][0].y, yreg[j][0].z, yreg[j][0].w, yreg[j][1].x, yreg[j][1].y, yreg[j][1].z, yreg[j][1].w};
+                const int room = p.out_w - col0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = q < room ? v[q] : 0.f;
-            uint4 h, l;
-            split8(v, sc, &h, &l);
-            if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; yl[d & 0xffffu] = l; }
-        }
+                for (int q = 0; q < 8; ++q) v[q] = q < room ? v[q] : 0.f;
+                uint4 h, l;
+                split8<SC>(v, sc, &h, &l);
+                if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; yl[d & 0xffffu] = l; }
+            }
+        };
+        if (scaled) items(std::true_type{}); else items(std::false_type{});
     };
 
     if (t_begin < t_end) {
