@@ -400,7 +400,10 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4* 
         const float f = SCALED ? v[q] * scale : v[q];
         const __bf16 t = (__bf16)f;
         hh[q] = t;
-        ll[q] = (__bf16)(f - (float)t);
+        const float tf = (float)t;
+        float dlo;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dlo) : "v"(f), "v"(tf));      // plain, not packed: v_pk_add_f32 stalls the matrix pipe (profiles/pmc_r01.md); +3..4 % at >= 64 channels
+        ll[q] = (__bf16)dlo;
     }
     *h = *reinterpret_cast<uint4*>(&hh);
     *l = *reinterpret_cast<uint4*>(&ll);
