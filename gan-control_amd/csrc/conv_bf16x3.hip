@@ -1021,8 +1021,18 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     const int iy0 = qy0 - 1, ix0 = qx0 - 1;
 
     uint4 wreg_h[C::NWU], wreg_l[C::NWU];
-    float preg[C::NPU][8];
-    float sreg[8];
+    // Patch staging as in conv_bf16x3_kernel: a lane fetches FOUR consecutive pixels of a channel with one 16-byte load (eight
+    // channels = eight loads) and transposes them in registers into four channel-last units.  The texture-address unit spends
+    // ~16 cycles per wave-level load whatever its width; with 24 dword loads per lane per chunk that was more than the MFMAs of a
+    // chunk at <= 64 output channels.  A patch row is the halo column (one pixel, "edge" task) + TPW / 4 aligned groups.
+    constexpr int GR = TPW / 4, TASKS = C::PH * (GR + 1);
+    static_assert(TASKS <= 128, "one staging task per lane and channel group");
+    __shared__ __attribute__((aligned(16))) float s_si[MAX_K_BF16X3 + KCB];     // in_scale of this sample, zero past K (a ragged last chunk contributes nothing)
+    for (int k = tid; k < ((p.K + KCB - 1) / KCB) * KCB; k += 256) s_si[k] = k < p.K ? (sib ? sib[k] : 1.f) : 0.f;
+    const int kgl_p = __builtin_amdgcn_readfirstlane(tid >> 7), tb = tid & 127;     // waves 0,1: channel group 0; waves 2,3: group 1
+    const int t_row = tb / (GR + 1), t_g = tb % (GR + 1);
+    const int t_col = t_g == 0 ? 0 : 4 * t_g - 3, t_used = tb < TASKS ? (t_g == 0 ? 1 : 4) : 0;
+    uint4 preg[8];
     const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)p.K * chan * 4u);
     const unsigned wbytes = 9u * a.kgroups * p.N * 16u;
     const __amdgpu_buffer_rsrc_t rwh = make_rsrc(a.wh, wbytes), rwl = make_rsrc(a.wl, wbytes);
@@ -1039,24 +1049,13 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
             wreg_h[j] = buf_load_u128(rwh, gb, 0);
             wreg_l[j] = buf_load_u128(rwl, gb, 0);
         }
-        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), pbase = t_ & 127;
+        const int iy = iy0 + t_row, ix = ix0 + t_col;
+        const bool ok = t_used > 0 && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
+        const unsigned boff_ = ok ? (unsigned)(iy * p.in_w + ix) * 4u : OOB;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            const int k = k0 + kgl * 8 + q;
-            sreg[q] = sib ? sib[min(k, p.K - 1)] : 1.f;
-        }
-#pragma unroll
-        for (int j = 0; j < C::NPU; ++j) {
-            const int pos = pbase + 128 * j;
-            const int r = pos / PWD, c = pos % PWD;
-            const int iy = iy0 + r, ix = ix0 + c;
-            const bool ok = pos < PLANE && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-            const unsigned boff_ = ok ? (unsigned)(iy * p.in_w + ix) * 4u : OOB;
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = min(k0 + kgl * 8 + q, p.K - 1);
-                preg[j][q] = buf_load_f32(rx, boff_, (unsigned)k * chan * 4u);
-            }
+            const int k = min(k0 + kgl_p * 8 + q, p.K - 1);          // wave-uniform -> scalar offset
+            preg[q] = buf_load_u128(rx, boff_, (unsigned)k * chan * 4u);
         }
     };
     auto commit = [&](int k0) {
@@ -1067,26 +1066,36 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
             const int u = t_ + 256 * j;
             if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; wl_l[u] = wreg_l[j]; }
         }
-        const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), pbase = t_ & 127;
+        const float4 sa = *reinterpret_cast<const float4*>(&s_si[k0 + kgl_p * 8]), sb = *reinterpret_cast<const float4*>(&s_si[k0 + kgl_p * 8 + 4]);
+        const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+        const int inrow = p.in_w - (ix0 + t_col);                    // pixels of this group that are still inside the image row
+        const int ubase = kgl_p * PLANE + t_row * PWD + t_col;
 #pragma unroll
-        for (int j = 0; j < C::NPU; ++j) {
-            const int pos = pbase + 128 * j;
-            float v[8];
+        for (int i = 0; i < 4; ++i) {
+            bf16x8 h, l;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) v[q] = (k0 + kgl * 8 + q < p.K) ? preg[j][q] : 0.f;
-            uint4 h, l;
-            split8v(v, sreg, &h, &l);
-            if (pos < PLANE) { p_h[kgl * PLANE + pos] = h; p_l[kgl * PLANE + pos] = l; }
+            for (int q = 0; q < 8; ++q) {
+                const unsigned raw = i == 0 ? preg[q].x : (i == 1 ? preg[q].y : (i == 2 ? preg[q].z : preg[q].w));
+                const float v = i < inrow ? __uint_as_float(raw) * sc[q] : 0.f;
+                const __bf16 hh = (__bf16)v;
+                h[q] = hh;
+                l[q] = (__bf16)(v - (float)hh);
+            }
+            if (i < t_used) {
+                p_h[ubase + i] = *reinterpret_cast<uint4*>(&h);
+                p_l[ubase + i] = *reinterpret_cast<uint4*>(&l);
+            }
         }
     };
 
     prefetch(0);
+    __syncthreads();        // s_si
     commit(0);
     __syncthreads();
     for (int k0 = 0; k0 < p.K; k0 += KCB) {
         wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
         const bool more = k0 + KCB < p.K;
-        if (more) prefetch(k0 + KCB);
+        prefetch(more ? k0 + KCB : k0);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
         __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
 #pragma unroll
         for (int dyi = 0; dyi < 2; ++dyi) {
