@@ -658,18 +658,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
 // of D's 3x3 / 1x1 stride-2 convolutions and (operands swapped) of G's transposed convolutions.  Each input row is
 // staged DE-INTERLEAVED: units of 8 even columns and units of 8 odd columns, so tap tx = 0 reads an even unit,
 // tx = 1 an odd unit and tx = 2 the even units funnel-shifted by one pixel -- every ds_read_b128 stays aligned.
-__device__ __forceinline__ void split8v(const float (&v)[8], const float (&sc)[8], uint4* h, uint4* l) {
-    bf16x8 hh, ll;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const float f = v[q] * sc[q];
-        const __bf16 t = (__bf16)f;
-        hh[q] = t;
-        ll[q] = (__bf16)(f - (float)t);
-    }
-    *h = *reinterpret_cast<uint4*>(&hh);
-    *l = *reinterpret_cast<uint4*>(&ll);
-}
 
 template <int TR, int KS, int WK>
 struct WgS2Cfg {
@@ -967,7 +955,7 @@ struct TCfg {
     static constexpr int PH = TQH + 1, PWD = TPW + 1, PLANE = PH * PWD;
     static constexpr int WUNITS = 9 * KG * OCT, PUNITS = KG * PLANE;
     static constexpr int SMEM_UNITS = 2 * (WUNITS + PUNITS);
-    static constexpr int NWU = (WUNITS + 255) / 256, NPU = (PLANE + 127) / 128;
+    static constexpr int NWU = (WUNITS + 255) / 256;
 };
 
 // EPI: 0 = store the accumulators as they are (input-gradient launches), 1 = out_scale only (modulated up-sampling
