@@ -936,7 +936,9 @@ WgPlan plan_wg(const gc_conv_desc* d) {
 }
 
 bool wg_eligible(const gc_conv_desc* d) {
-    if (d->up != 1 || d->out_w <= 16 || pointwise_thin(d)) return false;
+    // Narrow planes included: a 4 .. 16-pixel row fills an eighth .. half of the 32-pixel tile (the rest is masked zeros), and the
+    // split-bf16 kernels are still 2-3x the fp32 MFMA path there (512 -> 512 @16^2, B = 8: 96 vs 298 us; @4^2: 48 vs 90 us).
+    if (d->up != 1 || d->out_w < 4 || pointwise_thin(d)) return false;
     if (d->down == 1) return d->in_ch >= 32 && d->out_ch >= 32 && d->pad_x >= 0 && d->pad_x <= 1;
     return d->in_ch >= 32 && d->out_ch >= 64 && d->pad_x == 0 && d->pad_y == 0;      // stride-2 kernel: 64 (or 32) k x 64 n tiles, no padding
 }
@@ -1245,7 +1247,9 @@ int dispatch(const Bf16Args& a, hipStream_t s) {
 // shapes the split-bf16 kernel is built for; everything else runs on the exact fp32 kernel
 bool eligible(const gc_conv_desc* d) {
     const int qw = gc::ceil_div(d->out_w, d->up);
-    if (d->in_ch < 16 || d->in_ch > MAX_K_BF16X3 || qw <= 16 || pointwise_thin(d)) return false;
+    // 9 .. 16-pixel rows fill part of the 32-pixel tile only, yet beat the fp32 MFMA path (512 -> 512 @16^2, B = 8: 97 vs 201 us;
+    // stride 2 @33^2: 128 vs 281 us); at <= 8 pixels the fp32 kernel with its split over K is faster (36 vs 92 us @8^2)
+    if (d->in_ch < 16 || d->in_ch > MAX_K_BF16X3 || qw <= 8 || pointwise_thin(d)) return false;
     // the staging scheme wants the patch rows to start at most EDGE floats before a 32-float boundary (see BCfg)
     if (d->up == 1) {
         const int pwd = 31 * d->down + d->kw, edge = pwd - 32 * (pwd % 32 == 0 ? pwd / 32 : (pwd - 1) / 32);

@@ -17,14 +17,14 @@ def conv_variant(geom, n_out, batch=1, k_in=64, mode='f32'):
     """Name of the conv_mfma_kernel tile configuration gc_conv2d_f32 selects (csrc/conv.hip, dispatch_conv).
 
     Template arguments: <WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW>; the (up, down, taps) triple follows.  In bf16x3 mode
-    the same shapes run on conv_bf16x3_kernel (planes wider than 16 px and >= 16 input channels).
+    the same shapes run on conv_bf16x3_kernel (planes wider than 8 px and >= 16 input channels).
     """
     qw, qh = -(-geom.out_w // geom.up), -(-geom.out_h // geom.up)
     geo = '|up%d,down%d,k%d' % (geom.up, geom.down, geom.kh)
     if geom.kh == 1 and geom.up == 1 and geom.down == 1 and geom.pad_y == 0 and geom.pad_x == 0 and (k_in <= 4 or n_out <= 4) \
             and geom.out_h * geom.out_w * batch >= 1 << 18:
         return ('pw_narrow_kernel' if n_out <= 4 else 'pw_widen_kernel') + geo      # csrc/pointwise.hip
-    if mode == 'bf16x3' and 16 <= k_in <= 1024 and qw > 16:
+    if mode == 'bf16x3' and 16 <= k_in <= 1024 and qw > 8:
         if geom.up == 2 and geom.kh == 3 and geom.pad_y == 2 and geom.pad_x == 2:
             # convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, EPI> (dispatch_t): the four output phases in one workgroup
             tq = -(-geom.out_w // 2)
