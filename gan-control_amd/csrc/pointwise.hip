@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(PwWgArgs a) {
     float ts[MAXS];
 #pragma unroll
     for (int s = 0; s < MAXS; ++s) ts[s] = (a.st && s < a.S) ? a.st[(size_t)b * a.S + s] : 1.f;
-    for (int l0 = 0; l0 < a.L; l0 += CHUNK) {
+    {       // one chunk of 16 wide-side channels per workgroup (blockIdx.z): a 256^2 plane has only 8 pixel blocks per sample
+        const int l0 = blockIdx.z * CHUNK;
         float acc[CHUNK][MAXS];
 #pragma unroll
         for (int q = 0; q < CHUNK; ++q)
@@ -258,8 +259,9 @@ int gcconv::pointwise_wgrad(const gc_conv_desc* d, const float* x, const float* 
     const int blocks = wgrad_blocks(a.plane);
     a.groups_per_block = (int)(((a.plane + 3) / 4 + blocks - 1) / blocks);
     hipStream_t s = (hipStream_t)stream;
-    if (a.vec) hipLaunchKernelGGL(pw_wgrad_kernel<true>, dim3(blocks, d->batch), dim3(256), 0, s, a);
-    else       hipLaunchKernelGGL(pw_wgrad_kernel<false>, dim3(blocks, d->batch), dim3(256), 0, s, a);
+    const dim3 grid(blocks, d->batch, (a.L + CHUNK - 1) / CHUNK);
+    if (a.vec) hipLaunchKernelGGL(pw_wgrad_kernel<true>, grid, dim3(256), 0, s, a);
+    else       hipLaunchKernelGGL(pw_wgrad_kernel<false>, grid, dim3(256), 0, s, a);
     int rc = gc::check_launch("gc_conv2d_wgrad_f32(pointwise)");
     if (rc) return rc;
     const int kn = d->in_ch * d->out_ch;
