@@ -663,7 +663,7 @@ extern "C" int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float*
 
 extern "C" size_t gc_conv2d_wgrad_workspace(const gc_conv_desc* d) {
     if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->out_h <= 0 || d->out_w <= 0) return 0;
-    if (pointwise_thin(d)) return pointwise_wgrad_workspace(d);
+    if (pointwise_thin_wgrad(d)) return pointwise_wgrad_workspace(d);
     const WgradPlan pl = plan_wgrad(d);
     return (size_t)pl.parts * d->kh * d->kw * d->in_ch * d->out_ch * sizeof(float);
 }
@@ -683,7 +683,7 @@ extern "C" int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const 
     const WgradPlan pl = plan_wgrad(d);
     const size_t need = gc_conv2d_wgrad_workspace(d);
     if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_f32: workspace %zu < %zu bytes", workspace_bytes, need);
-    if (pointwise_thin(d)) return pointwise_wgrad(d, x, dy, in_scale, out_scale, dw, workspace, stream);
+    if (pointwise_thin_wgrad(d)) return pointwise_wgrad(d, x, dy, in_scale, out_scale, dw, workspace, stream);
     WgradArgs a{x, dy, in_scale, out_scale, pl.parts == 1 ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w,
                 d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
     if (d->kh == 3) rc = d->down == 2 ? dispatch_wgrad<2, 3>(a, pl, s) : dispatch_wgrad<1, 3>(a, pl, s);

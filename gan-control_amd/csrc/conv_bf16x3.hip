@@ -938,7 +938,7 @@ WgPlan plan_wg(const gc_conv_desc* d) {
 bool wg_eligible(const gc_conv_desc* d) {
     // Narrow planes included: a 4 .. 16-pixel row fills an eighth .. half of the 32-pixel tile (the rest is masked zeros), and the
     // split-bf16 kernels are still 2-3x the fp32 MFMA path there (512 -> 512 @16^2, B = 8: 96 vs 298 us; @4^2: 48 vs 90 us).
-    if (d->up != 1 || d->out_w < 4 || pointwise_thin(d)) return false;
+    if (d->up != 1 || d->out_w < 4 || pointwise_thin_wgrad(d)) return false;
     if (d->down == 1) return d->in_ch >= 32 && d->out_ch >= 32 && d->pad_x >= 0 && d->pad_x <= 1;
     return d->in_ch >= 32 && d->out_ch >= 64 && d->pad_x == 0 && d->pad_y == 0;      // stride-2 kernel: 64 (or 32) k x 64 n tiles, no padding
 }

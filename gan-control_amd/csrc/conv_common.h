@@ -141,6 +141,7 @@ __device__ __forceinline__ void wait_staged_loads() { __builtin_amdgcn_s_waitcnt
 
 // defined in pointwise.hip: 1x1 convolutions with <= 4 channels on one side (ToRGB / FromRGB) on the vector ALUs
 bool pointwise_thin(const gc_conv_desc* d);
+bool pointwise_thin_wgrad(const gc_conv_desc* d);
 int pointwise_conv(const gc_conv_desc* d, const float* x, const float* w, const float* in_scale, const float* out_scale,
                    const gc_conv_epilogue* ep, float* y, gc_stream_t stream);
 size_t pointwise_wgrad_workspace(const gc_conv_desc* d);

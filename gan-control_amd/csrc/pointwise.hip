@@ -212,6 +212,14 @@ int wgrad_blocks(long long plane) {
 
 }  // namespace
 
+// the weight gradient splits over 16-channel chunks as well (pw_wgrad_kernel), so it fills the chip on smaller planes than the forward kernels
+bool gcconv::pointwise_thin_wgrad(const gc_conv_desc* d) {
+    constexpr int lg = 14;       // pixels x batch; scan: 3 -> 128 @256^2 B = 2: 54 -> 32 us, 512 -> 3 @64^2: 30 -> 24 us, nothing below
+    return d && d->kh == 1 && d->kw == 1 && d->up == 1 && d->down == 1 && d->pad_x == 0 && d->pad_y == 0 &&
+           (d->in_ch <= MAXS || d->out_ch <= MAXS) && d->batch <= 65535 &&
+           (long long)d->out_h * d->out_w * d->batch >= (1LL << lg);
+}
+
 bool gcconv::pointwise_thin(const gc_conv_desc* d) {
     // only where the launch is a bandwidth problem: one lane per 4 pixels must still fill the chip (>= 256 workgroups);
     // the low-resolution ToRGB layers (512 channels, <= 128 x 128) stay on the matrix kernels with their split over K

@@ -7,7 +7,8 @@ import torch
 from gan_control_amd.models.op import _backend
 from gan_control_amd.models.op._backend import ConvGeom
 be = _backend.get(); be.conv_mode = 'bf16x3'
-for B, K, N, H in [(4, 32, 3, 1024), (4, 64, 3, 512), (4, 128, 3, 256), (8, 3, 32, 1024), (2, 3, 64, 512), (2, 128, 3, 256), (4, 40, 3, 300)]:
+for B, K, N, H in [(4, 32, 3, 1024), (4, 64, 3, 512), (4, 128, 3, 256), (8, 3, 32, 1024), (2, 3, 64, 512), (2, 128, 3, 256), (4, 40, 3, 300),
+                   (2, 3, 128, 256), (4, 256, 3, 128), (2, 256, 3, 128), (4, 512, 3, 64), (2, 512, 3, 64), (4, 512, 3, 32), (4, 512, 3, 16), (4, 512, 3, 8), (8, 3, 512, 32)]:
     g = ConvGeom(1, 1, 1, 1, 0, 0, H, H)
     x = torch.randn(B, K, H, H, device='cuda'); dy = torch.randn(B, N, H, H, device='cuda')
     si, so = torch.rand(B, K, device='cuda') + 0.5, torch.rand(B, N, device='cuda') + 0.5
