@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_reduce_kernel(
     const float* __restrict__ noise_w, float* __restrict__ dx, float* __restrict__ psum, float* __restrict__ pdot, float* __restrict__ pself,
     int channels, int64_t inner, int chunks, int64_t chunk_len, float pos, float neg) {
     __shared__ float lds[4];
-    const int plane = blockIdx.y, j = blockIdx.x;
+    const int plane = blockIdx.x / chunks, j = blockIdx.x - plane * chunks;      // 1-D grid, plane-major: no 65535 limit on planes
     const int b = plane / channels, c = plane % channels;
     const size_t base = (size_t)plane * inner;
     const float* np = NOISE ? noise + (size_t)b * inner : nullptr;
@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_reduce_adjoint_kernel(
     const float* __restrict__ noise_w, float* __restrict__ g_dy, float* __restrict__ g_yref, float* __restrict__ pgb, float* __restrict__ pgn,
     int channels, int64_t inner, int chunks, int64_t chunk_len, float pos, float neg) {
     __shared__ float lds[4];
-    const int plane = blockIdx.y, j = blockIdx.x;
+    const int plane = blockIdx.x / chunks, j = blockIdx.x - plane * chunks;      // 1-D grid, plane-major: no 65535 limit on planes
     const int b = plane / channels, c = plane % channels;
     const size_t base = (size_t)plane * inner, pj = (size_t)plane * chunks + j;
     const float* np = noise ? noise + (size_t)b * inner : nullptr;
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void bias_act_bwd_reduce_adjoint_kernel(
 __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial,
                                                         int64_t inner, int chunks, int64_t chunk_len) {
     __shared__ float lds[4];
-    const int plane = blockIdx.y, j = blockIdx.x;
+    const int plane = blockIdx.x / chunks, j = blockIdx.x - plane * chunks;      // 1-D grid, plane-major: no 65535 limit on planes
     const size_t base = (size_t)plane * inner;
     const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
     float acc = 0.f;
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ x, float* __restrict__ partial,
                                                           int batch, int channels, int64_t inner, int chunks, int64_t chunk_len) {
     __shared__ float lds[4];
-    const int plane = blockIdx.y, j = blockIdx.x;
+    const int plane = blockIdx.x / chunks, j = blockIdx.x - plane * chunks;      // 1-D grid, plane-major: no 65535 limit on planes
     const int c = plane % channels, b = plane / channels;
     const float* xp = x + (size_t)plane * inner;
     const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
@@ -317,14 +317,14 @@ extern "C" int gc_channel_sum_f32(const float* x, float* out, int batch, int cha
                                   void* workspace, size_t workspace_bytes, gc_stream_t stream) {
     if (!x || !out) return gc::fail(GC_ERR_BAD_ARG, "gc_channel_sum_f32: null pointer");
     if (batch <= 0 || channels <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_channel_sum_f32: bad extents");
-    if ((int64_t)batch * channels > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_channel_sum_f32: more than 65535 planes");
+    if ((int64_t)batch * channels * gc_bias_act_bwd_chunks(inner) > INT32_MAX) return gc::fail(GC_ERR_UNSUPPORTED, "gc_channel_sum_f32: more than 2^31 blocks");
     const size_t need = gc_channel_sum_workspace(batch, channels, inner);
     if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_channel_sum_f32: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     int chunks; int64_t len;
     channel_sum_plan(inner, &chunks, &len);
     float* partial = static_cast<float*>(workspace);
-    hipLaunchKernelGGL(channel_sum_stage1, dim3(chunks, batch * channels), dim3(256), 0, s, x, partial, batch, channels, inner, chunks, len);
+    hipLaunchKernelGGL(channel_sum_stage1, dim3((unsigned)chunks * (unsigned)(batch * channels)), dim3(256), 0, s, x, partial, batch, channels, inner, chunks, len);
     int rc = gc::check_launch("gc_channel_sum_f32(stage1)");
     if (rc) return rc;
     hipLaunchKernelGGL(channel_sum_stage2, dim3(channels), dim3(256), 0, s, partial, out, batch * chunks);
@@ -346,11 +346,11 @@ extern "C" int gc_bias_act_bwd_reduce_self_f32(const float* dy, const float* y_r
     if (pself && noise && !noise_w) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_f32: pself with noise needs noise_w");
     if (pself && (slope == 0.f || gain == 0.f)) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_f32: pself needs an invertible activation (slope, gain != 0)");
     if (batch <= 0 || channels <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_f32: bad extents");
-    if ((int64_t)batch * channels > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_f32: more than 65535 planes");
     hipStream_t s = (hipStream_t)stream;
     int chunks; int64_t len;
     channel_sum_plan(inner, &chunks, &len);
-    dim3 grid(chunks, batch * channels);
+    if ((int64_t)batch * channels * chunks > INT32_MAX) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_f32: more than 2^31 blocks");
+    dim3 grid((unsigned)chunks * (unsigned)(batch * channels));
 #define GC_LAUNCH(N, S) hipLaunchKernelGGL((bias_act_bwd_reduce_kernel<N, S>), grid, dim3(256), 0, s, dy, y_ref, noise, bias, noise_w, dx, psum, pdot, pself, \
                                            channels, inner, chunks, len, gain, gain * slope)
     if (noise) { if (pself) GC_LAUNCH(true, true); else GC_LAUNCH(true, false); }
@@ -368,10 +368,10 @@ extern "C" int gc_bias_act_bwd_reduce_adjoint_f32(const float* ggx, const float*
     if (cd && !noise) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_adjoint_f32: cd needs noise");
     if (slope == 0.f || gain == 0.f) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_adjoint_f32: needs an invertible activation (slope, gain != 0)");
     if (batch <= 0 || channels <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_bias_act_bwd_reduce_adjoint_f32: bad extents");
-    if ((int64_t)batch * channels > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_adjoint_f32: more than 65535 planes");
     int chunks; int64_t len;
     channel_sum_plan(inner, &chunks, &len);
-    hipLaunchKernelGGL(bias_act_bwd_reduce_adjoint_kernel, dim3(chunks, batch * channels), dim3(256), 0, (hipStream_t)stream, ggx, cs, cd, cw, y_ref, dx,
+    if ((int64_t)batch * channels * chunks > INT32_MAX) return gc::fail(GC_ERR_UNSUPPORTED, "gc_bias_act_bwd_reduce_adjoint_f32: more than 2^31 blocks");
+    hipLaunchKernelGGL(bias_act_bwd_reduce_adjoint_kernel, dim3((unsigned)chunks * (unsigned)(batch * channels)), dim3(256), 0, (hipStream_t)stream, ggx, cs, cd, cw, y_ref, dx,
                        noise, bias, noise_w, g_dy, g_yref, pgb, pgn, channels, inner, chunks, len, gain, gain * slope);
     return gc::check_launch("gc_bias_act_bwd_reduce_adjoint_f32");
 }
@@ -385,9 +385,9 @@ extern "C" int gc_bias_act_bwd_reduce_f32(const float* dy, const float* y_ref, c
 extern "C" int gc_plane_dot_f32(const float* a, const float* b, float* partial, int planes, int64_t inner, gc_stream_t stream) {
     if (!a || !b || !partial) return gc::fail(GC_ERR_BAD_ARG, "gc_plane_dot_f32: null pointer");
     if (planes <= 0 || inner <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_plane_dot_f32: bad extents");
-    if (planes > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_plane_dot_f32: more than 65535 planes");
     int chunks; int64_t len;
     channel_sum_plan(inner, &chunks, &len);
-    hipLaunchKernelGGL(plane_dot_kernel, dim3(chunks, planes), dim3(256), 0, (hipStream_t)stream, a, b, partial, inner, chunks, len);
+    if ((int64_t)planes * chunks > INT32_MAX) return gc::fail(GC_ERR_UNSUPPORTED, "gc_plane_dot_f32: more than 2^31 blocks");
+    hipLaunchKernelGGL(plane_dot_kernel, dim3((unsigned)chunks * (unsigned)planes), dim3(256), 0, (hipStream_t)stream, a, b, partial, inner, chunks, len);
     return gc::check_launch("gc_plane_dot_f32");
 }

@@ -200,6 +200,9 @@ class StyledConv(nn.Module):
 
     def forward(self, input, style, noise=None):
         conv = self.conv
+        if noise is not None and noise.shape[0] == 1 and input.shape[0] > 1:
+            # the registered [1, 1, h, w] buffers of randomize_noise=False broadcast over the batch (gan_model.py:343-345)
+            noise = noise.expand(input.shape[0], -1, -1, -1)
         if _FUSE_EPILOGUE and not conv.upsample:
             # conv -> noise -> bias + leaky-ReLU in one launch (the activation runs in the convolution's epilogue)
             if noise is None:

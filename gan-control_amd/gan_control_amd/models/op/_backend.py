@@ -34,6 +34,27 @@ def want_param_grads():
     return not _ACT_GRADS_ONLY[0]
 
 
+# The reference's leaky-ReLU backward reads the activation's INPUT to pick the slope, so in a double-backward every parameter
+# upstream of an activation is part of the graph and receives an exactly-zero gradient "through the mask".  The fused ops
+# take the mask from the OUTPUT and cut that path (None instead of zeros; the trainer restores the zeros, _fill_missing_grads).
+# The trainer's dry run (generator_trainer.py:301-327: which parameters have grad None under the regularisers?) needs the
+# reference's graph connectivity: inside `strict_zero_grads()` the activation backward hands on zero tensors instead of None.
+_STRICT_ZERO = [False]
+
+
+class strict_zero_grads:
+    def __enter__(self):
+        self.prev = _STRICT_ZERO[0]
+        _STRICT_ZERO[0] = True
+
+    def __exit__(self, *exc):
+        _STRICT_ZERO[0] = self.prev
+
+
+def strict_zeros():
+    return _STRICT_ZERO[0]
+
+
 # Geometry of the generalised convolution (gc_conv_desc minus batch/channels/in-size, which come from tensors)
 ConvGeom = namedtuple('ConvGeom', 'kh kw up down pad_y pad_x out_h out_w')
 

@@ -130,6 +130,8 @@ class _BiasActGradReduce(Function):
                 g_bias = -pgb.sum((0, 2))
             if cw is not None and ctx.has_noise and ctx.needs_input_grad[6]:
                 g_nw = -pgn.sum().reshape(noise_w.shape)
+            if g_y is None and ctx.needs_input_grad[1] and _backend.strict_zeros():
+                g_y = torch.zeros_like(y)
             return (g_gy if ctx.needs_input_grad[0] else None), g_y, None, None, None, g_bias, g_nw, None
         noise4 = noise.reshape(b, 1, *y.shape[2:]) if ctx.has_noise else None
         total = torch.zeros_like(y) if ggx is None else ggx
@@ -156,6 +158,8 @@ class _BiasActGradReduce(Function):
             if ctx.has_noise and ctx.needs_input_grad[6]:
                 g_nw = -(wg * noise4).sum().reshape(noise_w.shape)
         g_gy = _BiasActGrad.apply(total, y, slope, gain) if ctx.needs_input_grad[0] else None
+        if g_y is None and ctx.needs_input_grad[1] and _backend.strict_zeros():
+            g_y = torch.zeros_like(y)
         return g_gy, g_y, None, None, None, g_bias, g_nw, None
 
 
@@ -173,8 +177,8 @@ class _BiasActGrad(Function):
         y, = ctx.saved_tensors
         slope, gain = ctx.cfg
         ggy = _BiasActGrad.apply(ggx, y, slope, gain) if ctx.needs_input_grad[0] else None
-        # d/dy of the mask is zero almost everywhere: no gradient flows to the forward output
-        return ggy, None, None, None
+        # d/dy of the mask is zero almost everywhere: no gradient flows to the forward output (zeros only for the dry run)
+        return ggy, (torch.zeros_like(y) if (ctx.needs_input_grad[1] and _backend.strict_zeros()) else None), None, None
 
 
 def fused_noise_bias_act(input, bias=None, noise=None, noise_weight=None, negative_slope=0.2, scale=2 ** 0.5):

@@ -11,6 +11,18 @@ Bucket size: on the fully connected 8-GPU xGMI mesh (7 links x ~153 GB/s per GPU
 all-reduce moves 2*(N-1)/N of the payload per GPU; 32 MiB buckets are large enough to be
 bandwidth- rather than latency-bound yet leave 4 buckets per network in flight to hide behind
 the remaining backward.
+
+Storage: every bucket owns ONE persistent flat buffer.  When the last expected gradient of a
+bucket arrives, the gradients are gathered into it by a single multi-tensor copy, the buffer is
+all-reduced in place (RCCL averages in the collective itself), and ``.grad`` of each parameter
+is re-pointed at its slice of the buffer: no ``cat``, no copy back.
+
+Which gradients to wait for: the four backward passes of an iteration (D step, R1, G step,
+path-length) each touch a different subset of the parameters (R1 and path-length run under
+``activation_grads_only`` for their first-order pass and leave the additive biases without a
+gradient).  The subset of a pass is a property of the graph, so the reducer learns it per
+``phase`` the first time that phase runs (that first run reduces from ``finish()``); from then
+on a bucket launches from the hook of the last gradient *that phase* produces.
 """
 import os
 
@@ -51,24 +63,35 @@ def all_reduce_mean_(t):
 
 
 class _Bucket:
-    __slots__ = ('params', 'pending', 'work', 'flat', 'ready')
+    __slots__ = ('params', 'offsets', 'numel', 'flat', 'pending', 'work', 'ready', 'late', 'from_hook')
 
     def __init__(self, params):
-        self.params, self.pending, self.work, self.flat, self.ready = params, 0, None, None, []
+        self.params = params
+        self.offsets, off = {}, 0
+        for p in params:
+            self.offsets[p] = off
+            off += p.numel()
+        self.numel = off
+        self.flat = None          # allocated on first use (the parameters may still move to a device after construction)
+        self.pending, self.work, self.ready, self.late, self.from_hook = 0, None, [], [], False
+
+    def view(self, p):
+        off = self.offsets[p]
+        return self.flat[off:off + p.numel()].view_as(p)
 
 
 class GradientReducer:
     """Mean-reduces ``.grad`` of ``module``'s parameters across ranks, bucket by bucket.
 
-    Usage per optimiser step:  ``reducer.begin()`` -> backward(s) -> ``reducer.finish()`` ->
+    Usage per optimiser step:  ``reducer.begin(phase=...)`` -> backward(s) -> ``reducer.finish()`` ->
     optimiser.step().  With gradient accumulation call ``begin(sync=False)`` for all but the
     last micro-batch.  Parameters whose grad stays None (identical on all ranks by construction)
-    are skipped.
+    are skipped.  After ``finish()`` the ``.grad`` tensors are views into the bucket buffers.
     """
 
     def __init__(self, module, bucket_bytes=32 << 20, group=None):
         self.group = group
-        self.enabled = False
+        self.enabled = self._armed = False
         params = [p for p in module.parameters()]
         # reverse registration order approximates the order in which backward produces gradients
         self.buckets, cur, size = [], [], 0
@@ -85,54 +108,98 @@ class GradientReducer:
             for p in b.params:
                 self._bucket_of[p] = b
                 self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self._expected = {}       # phase -> set of parameters that received a gradient the last time the phase ran
+        self._phase = None
+        self._fired = set()
+        self.report = {}          # phase -> {'hook': buckets launched from a hook, 'finish': buckets launched in finish()}
 
     def remove(self):
         for h in self._handles:
             h.remove()
         self._handles = []
 
-    def begin(self, sync=True):
+    def begin(self, sync=True, phase=None):
+        """Arm the reducer for one backward pass.  ``phase`` names the pass (any hashable); passes with the same name must
+        produce gradients for the same parameters (a pass that does not is still reduced correctly, just later)."""
         self.enabled = sync and is_dist()
+        self._armed = is_dist()
+        self._phase = phase
+        expected = self._expected.get(phase)
+        self._cur_expected = expected if expected is not None else ()
         for b in self.buckets:
-            b.pending = sum(1 for p in b.params if p.requires_grad)
-            b.work, b.flat, b.ready = None, None, []
+            if expected is None:
+                b.pending = -1                       # unknown pass: reduce everything from finish()
+            else:
+                b.pending = sum(1 for p in b.params if p in expected)
+            b.work, b.ready, b.late, b.from_hook = None, [], [], False
 
     def _on_grad(self, p):
+        if not self._armed:
+            return
+        self._fired.add(p)           # also during accumulation passes (sync=False): the gradient exists from then on
         if not self.enabled:
             return
         b = self._bucket_of[p]
+        if b.work is not None:                       # not in the learned set of this phase: reduced on its own in finish()
+            b.late.append(p)
+            return
         b.ready.append(p)
-        b.pending -= 1
-        if b.pending == 0:
-            self._launch(b)
+        if b.pending > 0 and p in self._cur_expected:
+            b.pending -= 1
+            if b.pending == 0:
+                self._launch(b, b.ready)
+                b.from_hook = True
 
-    def _launch(self, b):
-        seen = {id(p) for p in b.ready}
-        ready = [p for p in b.params if p.grad is not None and id(p) in seen]
+    def _reduce(self, t):
+        world = dist.get_world_size(self.group)
+        if dist.get_backend(self.group) == 'nccl':
+            return dist.all_reduce(t, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        t.div_(world)                                # gloo has no averaging reduction
+        return dist.all_reduce(t, group=self.group, async_op=True)
+
+    def _launch(self, b, ready):
+        ready = [p for p in ready if p.grad is not None]
         b.ready = ready
         if not ready:
             return
-        b.flat = torch.cat([p.grad.reshape(-1) for p in ready])
-        b.flat.div_(dist.get_world_size(self.group))
-        b.work = dist.all_reduce(b.flat, group=self.group, async_op=True)
+        g0 = ready[0].grad
+        if b.flat is None or b.flat.device != g0.device or b.flat.dtype != g0.dtype:
+            b.flat = torch.empty(b.numel, dtype=g0.dtype, device=g0.device)
+        views = [b.view(p) for p in ready]
+        src = [p.grad for p in ready]
+        moved = [(v, s) for v, s in zip(views, src) if v.data_ptr() != s.data_ptr()]     # accumulation passes already live in the buffer
+        if moved:
+            torch._foreach_copy_([v for v, _ in moved], [s for _, s in moved])
+        for p, v in zip(ready, views):
+            p.grad = v
+        # the slice that spans every ready gradient; gaps (parameters without a gradient in this pass) ride along unused
+        lo = min(b.offsets[p] for p in ready)
+        hi = max(b.offsets[p] + p.numel() for p in ready)
+        b.work = self._reduce(b.flat[lo:hi])
 
     def finish(self):
-        """Launch what backward did not complete (parameters without gradients), wait, scatter back."""
+        """Launch what the hooks did not (unknown pass, stragglers), wait for every bucket."""
         if not self.enabled:
             return
-        for b in self.buckets:
-            if b.work is None and b.flat is None:
-                b.ready = [p for p in b.params if p.grad is not None]
-                self._launch(b)
+        hook = fin = 0
         for b in self.buckets:
             if b.work is None:
-                continue
-            b.work.wait()
-            off = 0
-            for p in b.ready:
-                n = p.numel()
-                if p.grad is not None:          # set_grad_none may have dropped it after the launch
-                    p.grad.copy_(b.flat[off:off + n].view_as(p.grad))
-                off += n
-            b.work, b.flat = None, None
+                self._launch(b, [p for p in b.params if p.grad is not None and p in self._fired])
+                fin += b.work is not None
+            else:
+                hook += 1
+        late = []
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+            for p in b.late:
+                if p.grad is not None:
+                    late.append(self._reduce(p.grad))
+        for w in late:
+            w.wait()
+        if self._phase is not None:
+            self._expected[self._phase] = set(self._fired)
+        self.report[self._phase] = {'hook': hook, 'finish': fin, 'late': len(late)}
+        self._fired = set()
         self.enabled = False

@@ -42,15 +42,45 @@ def default_config(size=512, batch=16):
     }
 
 
-def none_grad_names(generator, discriminator):
-    """Parameters the reference's dry_run (:301-327) finds with ``grad is None`` under the regularisers.
+def none_grad_names(generator, discriminator, latent_size=512, img_channels=3, size=None):
+    """The reference's dry_run (:301-327), run on the product's own graph: one latent through the path-length
+    regulariser, one random image through R1, then collect the parameters whose ``grad is None``.
 
-    They are exactly the parameters that enter the output additively (no second-order path):
-    every ToRGB bias of G and the last linear bias of D (pinned by
-    tests/golden/step.npz).
+    The reference's ATen graph reaches a parameter "through a mask" (leaky-ReLU's backward reads its input to pick
+    the slope) with an exactly-zero gradient, while the fused ops here cut such paths (their mask comes from the
+    output).  ``strict_zero_grads`` makes the activation backward hand on zero tensors for those paths during the dry
+    run, so ``grad is None`` means what it means in the reference: the parameter is not part of the double-backward
+    graph at all (every ToRGB bias of G, the last linear bias of D: SURVEY.md Appendix C #5; pinned against the
+    reference's own dry run by tests/golden/step*.npz).
     """
-    none_g = {n for n, _ in generator.named_parameters() if n.split('.')[-1] == 'bias' and n.startswith('to_rgb') and '.conv.' not in n}
-    none_d = {n for n, _ in discriminator.named_parameters() if n == 'final_linear.1.bias'}
+    dev = next(generator.parameters()).device
+    size = size if size is not None else generator.size
+    saved = [(p, p.grad, p.requires_grad) for m in (generator, discriminator) for p in m.parameters()]
+    rng = torch.get_rng_state()
+    cuda_rng = torch.cuda.get_rng_state(dev) if dev.type == 'cuda' else None
+    try:
+        for p, _, _ in saved:
+            p.grad = None
+            p.requires_grad_(True)
+        with _backend.strict_zero_grads():
+            test_in = torch.randn(1, latent_size, device=dev)
+            fake, latent = generator([test_in], return_latents=True)
+            noise = torch.randn_like(fake) / math.sqrt(fake.shape[2] * fake.shape[3])
+            grad, = autograd.grad((fake * noise).sum(), latent, create_graph=True)             # g_path_regularize :601-615
+            GeneratorTrainer.g_path_regularize_grad(grad, 0)[0].backward()
+            none_g = {n for n, p in generator.named_parameters() if p.grad is None}
+            test_img = torch.randn(1, img_channels, size, size, device=dev, requires_grad=True)
+            pred, _ = discriminator(test_img)
+            grad_real, = autograd.grad(pred.sum(), test_img, create_graph=True)                # d_r1_loss :713-719
+            grad_real.pow(2).reshape(1, -1).sum(1).mean().backward()
+            none_d = {n for n, p in discriminator.named_parameters() if p.grad is None}
+    finally:
+        for p, g, r in saved:
+            p.grad = g
+            p.requires_grad_(r)
+        torch.set_rng_state(rng)
+        if cuda_rng is not None:
+            torch.cuda.set_rng_state(cuda_rng, dev)
     return none_g, none_d
 
 
@@ -79,6 +109,11 @@ class GeneratorTrainer:
         torch.manual_seed(seed)          # identical initial weights on every rank
         self.init_models_and_optim(fused_adam)
         self.dry_run()
+        # Every rank must draw its OWN injected noise, path-length noise and ADA transforms (the single-process reference
+        # draws one independent sample per image of the global batch): re-seed the global CPU / device generators per rank
+        # now that the replicas are identical.  Python's ``random`` (style-mixing coin, inject index) stays in lock-step:
+        # those are one draw per step for the whole global batch in the reference too.
+        torch.manual_seed(seed * 1000 + self.rank + 1)
         self.mean_path_length = 0
         self.ada = AdaptiveAugmentState(tc['augment'], self.device)        # generator_trainer.py:333-339
         self.accum = 0.5 ** (tc['batch'] / tc['g_moving_average'])
@@ -111,7 +146,12 @@ class GeneratorTrainer:
         self.d_reducer = ddp.GradientReducer(self.discriminator)
 
     def dry_run(self):
-        self.none_g_grads, self.none_d_grads = none_grad_names(self.generator, self.discriminator)
+        """generator_trainer.py:301-327.  ``training_config['parallel']`` is NOT honoured here on purpose: with
+        nn.DataParallel the reference's names carry a 'module.' prefix and never match in set_grad_none (the ToRGB
+        biases then keep a zero gradient and Adam steps them on momentum); this trainer implements the
+        single-process semantics the reference intends (SURVEY.md Appendix C #5)."""
+        mc = self.model_config
+        self.none_g_grads, self.none_d_grads = none_grad_names(self.generator, self.discriminator, mc['latent_size'], mc['img_channels'], mc['size'])
 
     def state_dict(self):
         """Checkpoint layout of save_nets (:852-865) plus the state the reference forgets (Appendix C #4)."""
@@ -181,7 +221,7 @@ class GeneratorTrainer:
         self.discriminator.zero_grad(set_to_none=True)
         n = len(mini_real_inputs)
         for k, (real, z) in enumerate(zip(mini_real_inputs, mini_noise_inputs)):
-            self.d_reducer.begin(sync=(k == n - 1))
+            self.d_reducer.begin(sync=(k == n - 1), phase='d')
             fake_img, _ = self.generator(z, noise=noise)
             if self.training_config['augment']['enabled']:                       # generator_trainer.py:651-653
                 real, _ = augment(real, self.ada.p)
@@ -192,15 +232,15 @@ class GeneratorTrainer:
             d_loss = d_loss / (len(real) * self.world)
             self.stats['d_loss'] = self.stats['d_loss'] + d_loss.detach()
             d_loss.backward()
-        self._fill_missing_grads(self.discriminator, ())
         self.d_reducer.finish()
+        self._fill_missing_grads(self.discriminator, ())          # zeros are the same on every rank: nothing to reduce
         self.d_optim.step()
         self.last_real_pred = real_pred.detach()
-        if self.training_config['augment']['enabled']:
-            # ADA statistic on the last mini-batch's real predictions (generator_trainer.py:669-688), summed over ranks
-            reduce_sum = (lambda t: ddp.all_reduce_mean_(t).mul_(ddp.world_size())) if ddp.is_dist() else None
-            self.stats['ada_aug_p'] = self.ada.update(self.last_real_pred, reduce_sum)
-            self.stats['r_t_stat'] = self.ada.r_t
+        # ADA statistic on the last mini-batch's real predictions (generator_trainer.py:669-688), summed over ranks; tracked
+        # on every D step like the reference, p only moves when augmentation is enabled
+        reduce_sum = (lambda t: ddp.all_reduce_mean_(t).mul_(ddp.world_size())) if ddp.is_dist() else None
+        self.stats['ada_aug_p'] = self.ada.update(self.last_real_pred, reduce_sum, self.world)
+        self.stats['r_t_stat'] = self.ada.r_t
 
     def discriminate_pair(self, fake_img, real_img):
         """D(fake), D(real) as the reference computes them (:655-656), in ONE pass over the interleaved batch
@@ -223,15 +263,15 @@ class GeneratorTrainer:
         self.discriminator.zero_grad(set_to_none=True)
         n = len(mini_real_inputs)
         for k, real in enumerate(mini_real_inputs):
-            self.d_reducer.begin(sync=(k == n - 1))
+            self.d_reducer.begin(sync=(k == n - 1), phase='r1')
             real = real.detach().requires_grad_(True)
             real_pred, _ = self.discriminator(real)
             r1_loss = self.d_r1_loss(real_pred, real) / n
             self.stats['d_r1_loss'] = self.stats['d_r1_loss'] + r1_loss.detach()
             (tc['r1'] / 2 * r1_loss * tc['d_reg_every'] + 0 * real_pred[0]).backward()
             set_grad_none(self.discriminator, self.none_d_grads)
-        self._fill_missing_grads(self.discriminator, self.none_d_grads)
         self.d_reducer.finish()
+        self._fill_missing_grads(self.discriminator, self.none_d_grads)
         self.d_optim.step()
 
     def discriminator_update(self, i, real_img, noise=None):
@@ -251,7 +291,7 @@ class GeneratorTrainer:
         self.generator.zero_grad(set_to_none=True)
         n = len(mini_noise_inputs)
         for k, z in enumerate(mini_noise_inputs):
-            self.g_reducer.begin(sync=(k == n - 1))
+            self.g_reducer.begin(sync=(k == n - 1), phase='g')
             fake_img, _ = self.generator(z, noise=noise)
             if self.training_config['augment']['enabled']:                       # generator_trainer.py:421-424
                 fake_for_d, _ = augment(fake_img, self.ada.p)
@@ -261,8 +301,8 @@ class GeneratorTrainer:
             g_loss = self.g_nonsaturating_loss(fake_pred) / n
             self.stats['g_adv_loss'] = self.stats['g_adv_loss'] + g_loss.detach()
             g_loss.backward()
-        self._fill_missing_grads(self.generator, ())
         self.g_reducer.finish()
+        self._fill_missing_grads(self.generator, ())
         self.g_optim.step()
 
     def generator_regularize_step(self, noise=None, pl_noise=None, z=None):
@@ -275,8 +315,9 @@ class GeneratorTrainer:
         self.generator.zero_grad(set_to_none=True)
         n = len(mini_z)
         reduce_mean = ddp.all_reduce_mean_ if ddp.is_dist() else None
+        self.stats['g_path_loss'] = self.stats['g_path_length'] = self.stats['g_mean_path_length'] = 0
         for k, zk in enumerate(mini_z):
-            self.g_reducer.begin(sync=(k == n - 1))
+            self.g_reducer.begin(sync=(k == n - 1), phase='pl')
             fake_img, latent = self.generator(zk, noise=noise, return_latents=True)
             grad = Generator.g_path_regularize_grad(fake_img, latent, pl_noise=pl_noise)
             path_loss, self.mean_path_length, path_lengths = self.g_path_regularize_grad(grad, self.mean_path_length, reduce_mean=reduce_mean)
@@ -286,12 +327,13 @@ class GeneratorTrainer:
                 weighted = weighted + 0 * fake_img[0, 0, 0, 0]
             weighted.backward()
             set_grad_none(self.generator, self.none_g_grads)
-            self.stats['g_path_loss'] = path_loss.detach()
-            self.stats['g_path_length'] = path_lengths.detach().mean()
-            self.stats['g_mean_path_length'] = self.mean_path_length
+            # accumulated over the mini-batches like the reference's tracker (:592-596); path_loss already carries the 1 / n
+            self.stats['g_path_loss'] = self.stats['g_path_loss'] + path_loss.detach()
+            self.stats['g_path_length'] = self.stats['g_path_length'] + path_lengths.detach().mean() / n
+            self.stats['g_mean_path_length'] = self.stats['g_mean_path_length'] + self.mean_path_length / n
             self.stats['path_lengths'] = path_lengths.detach()
-        self._fill_missing_grads(self.generator, self.none_g_grads)
         self.g_reducer.finish()
+        self._fill_missing_grads(self.generator, self.none_g_grads)
         self.g_optim.step()
 
     def generator_update(self, i, noise=None):

@@ -232,20 +232,28 @@ class AdaptiveAugmentState:
         self.cfg = augment_config
         self.p = augment_config['p'] if augment_config['p'] > 0 else 0.0
         self.step = augment_config['ada_target'] / augment_config['ada_length']
-        self.accum = torch.zeros(2, device=device)       # [sum sign(real_pred), count]
+        self.accum = torch.zeros(2, device=device)       # [sum sign(real_pred), count] of THIS rank since the last decision
+        self.count = 0                                   # the same count summed over ranks, kept on the host
         self.r_t = 0.0
 
-    def update(self, real_pred, reduce_sum=None):
-        """Accumulate sign statistics of D's real predictions; every > 255 predictions move p towards the target."""
-        self.accum += torch.stack([torch.sign(real_pred).sum(), torch.tensor(float(real_pred.shape[0]), device=real_pred.device)])
-        stats = self.accum.clone()
-        if reduce_sum is not None:
-            stats = reduce_sum(stats)
-        if float(stats[1]) > 255:
+    def update(self, real_pred, reduce_sum=None, world=1):
+        """Accumulate sign statistics of D's real predictions; every > 255 predictions (over all ranks) move p towards the
+        target.  The prediction count is known on the host, so the device is only read (one scalar, and one all-reduce when
+        ``reduce_sum`` is given) in the iterations that cross the threshold -- every 256 / global-batch steps -- instead of
+        a host synchronisation per D step (generator_trainer.py:669-671 does ``.item()`` every step)."""
+        n = int(real_pred.shape[0])
+        self.accum[0] += torch.sign(real_pred).sum()
+        self.accum[1] += n
+        self.count += n * world
+        if self.count > 255:
+            stats = self.accum.clone()
+            if reduce_sum is not None:
+                stats = reduce_sum(stats)
             signs, count = stats.tolist()
             self.r_t = signs / count
             if self.cfg['enabled'] and self.cfg['p'] == 0:
                 sign = 1 if self.r_t > self.cfg['ada_target'] else -1
                 self.p = min(1.0, max(0.0, self.p + sign * self.step * count))
             self.accum.zero_()
+            self.count = 0
         return self.p

@@ -287,7 +287,7 @@ def build_ref(size, fc_config=None):
 
 def golden_networks():
     out = {}
-    for size, batch in [(32, 4), (64, 2), (256, 2), (1024, 1)]:
+    for size, batch in [(32, 4), (64, 2), (256, 2), (512, 2), (1024, 1)]:
         torch.manual_seed(0)
         g, d, g_sd, d_sd = build_ref(size)
         gen = torch.Generator().manual_seed(1000 + size)
@@ -345,14 +345,14 @@ def golden_networks():
     print('networks ok')
 
 
-def golden_step():
-    """One full iteration (i = 0: D step, R1, G step, path-length, EMA) at 32x32, batch 4.
+def golden_step(size=32, batch=4, name='step'):
+    """One full iteration (i = 0: D step, R1, G step, path-length, EMA) at 32x32, batch 4 by default; main() also
+    runs it at the BASELINE resolutions (512x512 batch 4, 1024x1024 batch 2: what fits this container's 64 GiB).
 
     The reference side is driven with the reference's own modules, helper functions
     (trainers/utils.py) and trainer maths (GeneratorTrainer static methods), following
     generator_trainer.py:301-369, 407-436, 568-599, 645-711 with batch == mini_batch.
     """
-    size, batch = 32, 4
     g, d, g_sd, d_sd = build_ref(size)
     g_ema = ref_gm.Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True)
     g_ema.load_state_dict(g_sd)
@@ -392,6 +392,7 @@ def golden_step():
     d_loss.div_(len(real))
     d_loss.backward(retain_graph=True)
     stats['d_grad_norm'] = torch.stack([p.grad.norm() for p in d.parameters()]).norm()
+    grad_samples = {'d': sample_grads(d)}
     d_optim.step()
     stats['d_loss'] = d_loss.detach()
     stats['real_pred_d'] = real_pred.detach()
@@ -403,6 +404,7 @@ def golden_step():
     (cfg['r1'] / 2 * r1 * cfg['d_reg_every'] + 0 * real_pred[0]).backward()
     ref_tu.set_grad_none(d, none_d)
     stats['r1_grad_norm'] = torch.stack([p.grad.norm() for p in d.parameters() if p.grad is not None]).norm()
+    grad_samples['r1'] = sample_grads(d)
     d_optim.step()
     stats['d_r1_loss'] = r1.detach()
     # G step
@@ -413,6 +415,7 @@ def golden_step():
     g_loss = RT.g_nonsaturating_loss(fake_pred)
     g_loss.backward()
     stats['g_grad_norm'] = torch.stack([p.grad.norm() for p in g.parameters()]).norm()
+    grad_samples['g'] = sample_grads(g)
     g_optim.step()
     stats['g_adv_loss'] = g_loss.detach()
     # path-length regulariser with an injected pl_noise (Generator.g_path_regularize_grad gan_model.py:803-811)
@@ -424,6 +427,7 @@ def golden_step():
     (cfg['path_regularize'] * cfg['g_reg_every'] * path_loss + 0 * fake[0, 0, 0, 0]).backward()
     ref_tu.set_grad_none(g, none_g)
     stats['pl_grad_norm'] = torch.stack([p.grad.norm() for p in g.parameters() if p.grad is not None]).norm()
+    grad_samples['pl'] = sample_grads(g)
     g_optim.step()
     stats.update(g_path_loss=path_loss.detach(), g_mean_path_length=mean_path, path_lengths=lengths.detach())
     ref_tu.accumulate(g_ema, g, 0.5 ** (batch / cfg['g_moving_average']))
@@ -434,18 +438,30 @@ def golden_step():
     for k in ['d_loss', 'd_r1_loss', 'g_adv_loss', 'g_path_loss', 'g_mean_path_length']:
         close(torch.tensor(o.stats[k]), stats[k], 2e-4, f'step/{k}')
     close(o.stats['path_lengths'], stats['path_lengths'], 2e-4, 'step/path_lengths')
-    worst = 0.0
-    for n, p in g.named_parameters():
-        worst = max(worst, (o.g_params[n] - p).abs().max().item())
-    for n, p in d.named_parameters():
-        worst = max(worst, (o.d_params[n] - p).abs().max().item())
-    print('step: max |param_oracle - param_ref| after the iteration = %.3e' % worst)
-    assert worst < 5e-4     # Adam's first steps are +-lr regardless of gradient scale; sign flips only at ~0 grads
+    worst, moved, total = 0.0, 0, 0
+    for params, mod in ((o.g_params, g), (o.d_params, d)):
+        for n, p in mod.named_parameters():
+            diff = (params[n] - p).abs()
+            worst = max(worst, diff.max().item())
+            moved += int((diff > 5e-4).sum())
+            total += diff.numel()
+    print('%s: max |param_oracle - param_ref| after the iteration = %.3e; %d of %d elements differ by more than 5e-4' % (name, worst, moved, total))
+    # Adam's first steps are +-lr whatever the gradient's scale: an element whose gradient is at rounding-noise level (R1 on
+    # smooth procedural weights) may step the other way.  32x32: none; at the BASELINE sizes a handful of ~60 M elements.
+    assert moved <= 1e-5 * total and worst < 1e-2
 
     out = {'real': real, 'z_d': z_d, 'z_g': z_g, 'z_pl': z_pl, 'pl_noise': pl_noise,
            'noise_seeds': np.array([11, 12, 13]), 'none_g': np.array(none_g), 'none_d': np.array(none_d),
-           'zero_d_r1': np.array(zero_d)}
+           'zero_d_r1': np.array(zero_d), 'input_seed': np.array(2024)}
+    if size > 64:
+        # the image-sized inputs (25 MB at 1024x1024) are not stored: tests redraw them from `input_seed` in the order used
+        # above (real, z_d, z_g, z_pl, pl_noise; tests/step_checks.py::step_inputs) and check the redraw against the stored latents
+        del out['real'], out['pl_noise']
     out.update({f'stat/{k}': v for k, v in stats.items()})
+    out['cfg'] = np.array([size, batch])
+    for phase, (names, norms) in grad_samples.items():          # per-parameter gradient norms of each of the four backward passes
+        out[f'gradnorm/{phase}/names'] = np.array(names)
+        out[f'gradnorm/{phase}/vals'] = torch.stack(norms)
     gen2 = torch.Generator().manual_seed(8)
     for tag, mod in (('g', g), ('d', d), ('g_ema', g_ema)):
         names, vals = [], []
@@ -456,8 +472,18 @@ def golden_step():
                 vals.append(p.detach().reshape(-1)[j])
         out[f'param/{tag}/names'] = np.array(names)
         out[f'param/{tag}/vals'] = torch.stack(vals)
-    np.savez_compressed(os.path.join(GOLD, 'step.npz'), **to_np(out))
-    print('step ok; none_g =', none_g, '; none_d =', none_d, '; zero-grad-under-R1 D params:', len(zero_d))
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **to_np(out))
+    print(name, 'ok; none_g =', none_g, '; none_d =', none_d, '; zero-grad-under-R1 D params:', len(zero_d))
+
+
+def sample_grads(module):
+    """(names, norms): the gradient norm of every parameter that has a gradient -- a per-layer pin of each backward pass."""
+    names, norms = [], []
+    for n, p in module.named_parameters():
+        if p.grad is not None:
+            names.append(n)
+            norms.append(p.grad.detach().norm())
+    return names, norms
 
 
 def golden_augment():
@@ -562,18 +588,40 @@ def golden_controller():
     print('controller ok')
 
 
+def golden_configs():
+    """The hot-path fields of the three shipped training configurations (configs/ffhq.json:5-84, metfaces.json, afhq.json:
+    numbers and switches, no code) plus what the reference's MiniBatchUtils.get_fc_config (mini_batch_multi_split_utils.py:
+    103-115) derives from each ``sub_groups_dict``: the fixture the product's config ingestion is checked against."""
+    import json
+    from gan_control.utils.mini_batch_multi_split_utils import MiniBatchUtils
+    keep = ['parallel_grad_regularize_step', 'iter', 'start_iter', 'batch', 'mini_batch', 'mini_batch_mode', 'transfer_learning_model',
+            'augment', 'sub_groups_dict', 'r1', 'd_every', 'g_reg_every', 'd_reg_every', 'lr_g', 'lr_d', 'g_moving_average',
+            'path_regularize', 'path_batch_shrink', 'mixing', 'parallel']
+    out = {}
+    for name in ('ffhq', 'metfaces', 'afhq'):
+        cfg = json.load(open(f'/root/reference/src/gan_control/configs/{name}.json'))
+        tc = cfg['training_config']
+        mb = MiniBatchUtils(tc['mini_batch'], tc['sub_groups_dict'], total_batch=tc['batch'])
+        fc = mb.get_fc_config()
+        out[name] = {'model_config': cfg['model_config'], 'training_config': {k: tc[k] for k in keep},
+                     'fc_config': {'in_order_group_names': list(fc.in_order_group_names),
+                                   'groups': {n: {'latent_place': list(fc.groups[n]['latent_place']), 'latent_size': int(fc.groups[n]['latent_size'])}
+                                              for n in fc.in_order_group_names}}}
+    with open(os.path.join(GOLD, 'configs.json'), 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    print('configs ok')
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
-    golden_upfirdn2d()
-    golden_bias_act()
-    golden_convs()
-    golden_misc()
-    golden_networks()
-    golden_step()
-    golden_augment()
-    golden_fid()
-    golden_controller()
+    jobs = {'upfirdn2d': golden_upfirdn2d, 'bias_act': golden_bias_act, 'convs': golden_convs, 'misc': golden_misc,
+            'networks': golden_networks, 'step': golden_step,
+            # the BASELINE resolutions: ~15 min and ~40 GiB on 8 cores (1024x1024 at batch 4 does not fit this container's 64 GiB)
+            'step_512': lambda: golden_step(512, 4, 'step_512'), 'step_1024': lambda: golden_step(1024, 2, 'step_1024'),
+            'augment': golden_augment, 'fid': golden_fid, 'controller': golden_controller, 'configs': golden_configs}
+    for name in (sys.argv[1:] or list(jobs)):
+        jobs[name]()
     total = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))
     print('fixtures written to %s (%.1f KiB)' % (GOLD, total / 1024))
 

@@ -194,3 +194,144 @@ def check_network(size, device, tol=TOL):
     assert rel_err(logits, r['logits']) <= tol
     assert rel_err(lat[:, 0, :16], r['w0']) <= tol
     return g, d, img
+
+
+MISC = load_golden('misc')
+
+
+def fixture_fc_groups():
+    return [(str(n), tuple(int(v) for v in b)) for n, b in zip(NET['split32/group_names'], NET['split32/group_bounds'])]
+
+
+def check_split_fc(device, tol=TOL):
+    """Product Generator with the per-group mapping networks (split_fc, MultiFcStack gan_model.py:489-502, 619-631) against the
+    reference image; the groups are built by the product's own config ingestion from a sub_groups_dict."""
+    from gan_control_amd.utils.fc_config import fc_config_from_sub_groups
+    r = group(NET, 'split32')
+    groups = fixture_fc_groups()
+    # the sub_groups_dict the fixture was generated from, listed out of latent order on purpose
+    sub = {n: {'place_in_latent': list(b), 'place_in_mini_batch': None} for n, b in reversed(groups)}
+    fc = fc_config_from_sub_groups(sub, 512)
+    assert fc.in_order_group_names == [n for n, _ in groups]
+    assert [tuple(fc.groups[n]['latent_place']) for n in fc.in_order_group_names] == [b for _, b in groups]
+    g, _ = build_models(32, device, fc_groups=groups)
+    with torch.no_grad():
+        img, _ = g([r['z'].to(device)], noise=seeded_noise(32, 2, int(r['noise_seed']), device))
+    assert rel_err(img, r['img']) <= tol
+    return g
+
+
+def check_mixing_truncation(device, tol=TOL):
+    """Two-style forward with inject_index and truncation towards a mean latent (gan_model.py:744-769)."""
+    r = group(NET, 'mix32')
+    g, _ = build_models(32, device)
+    noise = seeded_noise(32, 2, int(r['noise_seed']), device)
+    with torch.no_grad():
+        img, lat = g([r['z'].to(device), r['z2'].to(device)], noise=noise, inject_index=3, truncation=0.7,
+                     truncation_latent=r['mean_w'].to(device), return_latents=True)
+        assert rel_err(img, r['img']) <= tol
+        assert lat.shape == (2, g.n_latent, 512) and torch.equal(lat[:, 0], lat[:, 2]) and torch.equal(lat[:, 3], lat[:, -1])
+        # the same latent fed back with input_is_latent reproduces the image (gan_model.py:738-743, 757-760)
+        img2, _ = g([lat], input_is_latent=True, noise=noise)
+        assert rel_err(img2, r['img']) <= tol
+        # randomize_noise=False uses the registered [1, 1, h, w] noise buffers, broadcast over the batch (gan_model.py:728-734)
+        stored = [getattr(g.noises, f'noise_{i}') for i in range(g.num_layers)]
+        a, _ = g([r['z'].to(device)], randomize_noise=False)
+        b, _ = g([r['z'].to(device)], noise=[n.expand(2, -1, -1, -1) for n in stored])
+        assert rel_err(a, b) <= 1e-6
+
+
+def check_transfer_learning(device, tol=TOL):
+    """load_transfer_learning_model (gan_model.py:645-656): a regular-mapping checkpoint into a split_fc generator keeps the
+    synthesis network and leaves the new mapping network alone; a mismatch in the main network is refused."""
+    from gan_control_amd.models.gan_model import Generator
+    src, _ = build_models(32, device)
+    dst, _ = build_models(32, device, fc_groups=fixture_fc_groups())
+    before = {k: v.clone() for k, v in dst.state_dict().items() if k.startswith('style.')}
+    with torch.no_grad():
+        for p in dst.convs.parameters():
+            p.add_(1.0)
+    dst.load_transfer_learning_model(src)
+    sd_src, sd_dst = src.state_dict(), dst.state_dict()
+    for k, v in sd_dst.items():
+        if k.startswith('style.'):
+            assert torch.equal(v, before[k]), k
+        else:
+            assert torch.equal(v, sd_src[k]), k
+    # both now synthesise the same image from the same w
+    r = group(NET, 's32')
+    noise = seeded_noise(32, int(r['batch']), int(r['noise_seed']), device)
+    with torch.no_grad():
+        w = src.style(r['z'].to(device))
+        a, _ = src([w], input_is_latent=True, noise=noise)
+        b, _ = dst([w], input_is_latent=True, noise=noise)
+    assert rel_err(a, r['img']) <= tol and torch.equal(a, b)
+    other = Generator(64, 512, 8, channel_multiplier=2, conv_transpose=True).to(device)
+    try:
+        dst.load_transfer_learning_model(other)
+    except ValueError as e:
+        assert 'main network' in str(e)
+    else:
+        raise AssertionError('a checkpoint with a different synthesis network must be refused')
+
+
+def check_misc(device):
+    """EqualLinear (lr_mul 0.01 + fused lrelu, plain), PixelNorm and minibatch-stddev of the PRODUCT against the reference."""
+    from gan_control_amd.models.gan_model import EqualLinear, PixelNorm, minibatch_stddev
+    for name, act in (('lin_map', 'fused_lrelu'), ('lin_plain', None)):
+        r = group(MISC, name)
+        lr_mul = float(r['lr_mul'])
+        m = EqualLinear(r['w'].shape[1], r['w'].shape[0], lr_mul=lr_mul, activation=act).to(device)
+        with torch.no_grad():
+            m.weight.copy_(r['w'])
+            m.bias.copy_(r['b'])
+            assert rel_err(m(r['x'].to(device)), r['out']) <= TIGHT, name
+    r = group(MISC, 'pixel_norm')
+    assert rel_err(PixelNorm()(r['x'].to(device)), r['out']) <= TIGHT
+    for name in ('mbstd8', 'mbstd2', 'mbstd4'):
+        r = group(MISC, name)
+        assert rel_err(minibatch_stddev(r['x'].to(device)), r['out']) <= TIGHT, name
+
+
+def load_configs():
+    import json
+    import os
+    from conftest import GOLDEN
+    with open(os.path.join(GOLDEN, 'configs.json')) as f:
+        return json.load(f)
+
+
+def check_config_ingestion(device, name='ffhq', size=32, batch=8):
+    """The product trainer built from the hot-path fields of a shipped configuration (configs/ffhq.json:5-84 etc.; resolution and
+    batch reduced so it runs in seconds): fc_config_from_sub_groups == the reference's MiniBatchUtils.get_fc_config
+    (mini_batch_multi_split_utils.py:103-115), the split mapping network has the reference's parameter names, Adam and EMA
+    follow generator_trainer.py:161-173, 332, and one full iteration runs."""
+    import copy
+    from gan_control_amd.trainers.generator_trainer import GeneratorTrainer
+    from gan_control_amd.utils.fc_config import fc_config_from_sub_groups
+    ref = load_configs()[name]
+    fc = fc_config_from_sub_groups(ref['training_config']['sub_groups_dict'], ref['model_config']['latent_size'])
+    assert fc.in_order_group_names == ref['fc_config']['in_order_group_names']
+    assert {n: {'latent_place': list(g['latent_place']), 'latent_size': g['latent_size']} for n, g in fc.groups.items()} == ref['fc_config']['groups']
+    cfg = copy.deepcopy({'model_config': ref['model_config'], 'training_config': ref['training_config']})
+    cfg['model_config']['size'] = size
+    cfg['training_config']['batch'] = cfg['training_config']['mini_batch'] = batch
+    tr = GeneratorTrainer(cfg, device=device, seed=0, fused_adam=False)
+    names = [n for n, _ in tr.generator.named_parameters() if n.startswith('style.')]
+    assert sorted({n.split('.')[1] for n in names}) == sorted(fc.in_order_group_names)
+    for n in fc.in_order_group_names:
+        w = dict(tr.generator.named_parameters())
+        width = fc.groups[n]['latent_size']
+        assert w[f'style.{n}.1.weight'].shape == (256, width) and w[f'style.{n}.8.weight'].shape == (width, 256)
+    tc = ref['training_config']
+    gr, dr = tc['g_reg_every'] / (tc['g_reg_every'] + 1), tc['d_reg_every'] / (tc['d_reg_every'] + 1)
+    pg, pd = tr.g_optim.param_groups[0], tr.d_optim.param_groups[0]
+    assert abs(pg['lr'] - tc['lr_g'] * gr) < 1e-12 and pg['betas'] == (0 ** gr, 0.99 ** gr)
+    assert abs(pd['lr'] - tc['lr_d'] * dr) < 1e-12 and pd['betas'] == (0 ** dr, 0.99 ** dr)
+    assert abs(tr.accum - 0.5 ** (batch / tc['g_moving_average'])) < 1e-15
+    assert tr.ada.cfg['enabled'] == tc['augment']['enabled']
+    tr.train_iteration(0, tr.synthetic_batch())
+    stats = tr.reduced_stats()
+    for k in ('d_loss', 'd_r1_loss', 'g_adv_loss', 'g_path_loss'):
+        assert stats[k] == stats[k] and abs(stats[k]) < 1e6, (k, stats[k])
+    return tr

@@ -38,11 +38,21 @@ def _reducer_worker(rank, world, port, out):
     red = GradientReducer(net, bucket_bytes=4096)
     assert len(red.buckets) > 2
     x = torch.randn(8, 10, generator=torch.Generator().manual_seed(1))
-    # two micro-batches with accumulation, reduce only on the last
+    # two micro-batches with accumulation, reduce only on the last; the first optimiser step of a phase learns which
+    # parameters the pass produces (reduced from finish()), the second launches every bucket from a gradient hook
     xs = x[rank::world]
-    red.begin(sync=False); net(xs[:2]).mean().mul(0.5).backward()
-    red.begin(sync=True); net(xs[2:]).mean().mul(0.5).backward()
-    red.finish()
+    for it in range(2):
+        net.zero_grad(set_to_none=True)
+        red.begin(sync=False, phase='step'); net(xs[:2]).mean().mul(0.5).backward()
+        red.begin(sync=True, phase='step'); net(xs[2:]).mean().mul(0.5).backward()
+        if it == 1:
+            assert all(b.work is not None for b in red.buckets if any(p is not unused for p in b.params)), 'a bucket did not launch from its hook'
+        red.finish()
+        assert red.report['step']['late'] == 0
+        assert (red.report['step']['finish'] == 0) == (it == 1), red.report
+        for b in red.buckets:                       # gradients live in the bucket buffer afterwards: no copy back
+            for p in b.params:
+                assert p.grad is None or p.grad.data_ptr() == b.view(p).data_ptr()
     if rank == 0:
         torch.save({n: p.grad for n, p in net.named_parameters()}, out)
     dist.destroy_process_group()
@@ -101,7 +111,12 @@ def _run_iteration(rank, world):
 def _trainer_worker(rank, world, port, out):
     _setup(rank, world, port)
     state = _run_iteration(rank, world)
-    # replicas must stay bit-identical across ranks
+    # every rank draws its own noise from the global generators (NoiseInjection, path-length noise, ADA transforms) ...
+    draw = torch.randn(16)
+    both = [torch.empty(16) for _ in range(world)]
+    dist.all_gather(both, draw)
+    assert not torch.equal(both[0], both[1]), 'ranks share the global RNG stream: the global batch would see identical injected noise'
+    # ... but replicas must stay bit-identical across ranks
     for k, v in state['g'].items():
         ref = v.detach().clone()
         dist.broadcast(ref, 0)

@@ -50,3 +50,24 @@ def test_no_cpu_fallback():
         upfirdn2d(torch.zeros(1, 1, 4, 4), torch.ones(2, 2))
     with pytest.raises(RuntimeError):
         fused_leaky_relu(torch.zeros(1, 2, 4, 4), torch.zeros(2))
+
+
+def test_split_fc(emu_backend):
+    oc.check_split_fc('cpu')
+
+
+def test_mixing_truncation_and_stored_noise(emu_backend):
+    oc.check_mixing_truncation('cpu')
+
+
+def test_transfer_learning_load(emu_backend):
+    oc.check_transfer_learning('cpu')
+
+
+def test_misc_modules(emu_backend):
+    oc.check_misc('cpu')
+
+
+@pytest.mark.parametrize('name', ['ffhq', 'metfaces', 'afhq'])
+def test_trainer_from_shipped_config(name, emu_backend):
+    oc.check_config_ingestion('cpu', name, size=16, batch=4)
