@@ -48,6 +48,7 @@ def parse():
     ap.add_argument('--precision', default=os.environ.get('GANCONTROL_CONV_PRECISION', 'bf16x3'), choices=['f32', 'bf16x3'],
                     help='conv arithmetic: bf16x3 = split-bf16 MFMA (fp32 storage, ~5e-6 relative error per layer), f32 = exact fp32 MFMA')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-fp32-leg', action='store_true', help='skip the second timed region in exact fp32 arithmetic ("fp32_exact" in the JSON line)')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--timer', default='roofline', choices=['roofline', 'all'], help='which launches get HIP-event brackets in the timed region')
     ap.add_argument('--cpu-baseline-size', type=int, default=None, help='resolution of the CPU sample (default: --size)')
@@ -55,17 +56,21 @@ def parse():
 
 
 def cpu_baseline(size):
-    """Time the oracle's D step + G step at batch 1 on the host cores (kind = "port")."""
+    """Time the oracle (CPU restatement of the reference FUSED=False path, kind = "port") on the host cores with the SAME step
+    definition as the GPU line: each of the four phases of an iteration is run once at batch 1 -- D step, R1 step, G step,
+    path-length step (its batch is max(1, 1 // path_batch_shrink) = 1) -- and the lazy regularisers enter at their cadence:
+    seconds per iteration = t_D + t_G + t_R1 / 16 + t_PL / 4."""
     from gan_control_amd.models.gan_model import Generator, Discriminator
     from oracle.step import OracleStep
     import warnings
     warnings.filterwarnings('ignore')
-    cores = os.cpu_count() or 1
+    host_cores = os.cpu_count() or 1
+    avail = host_cores
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(cores, 32)       # MKL-DNN grouped convs stop scaling (and thrash) far below a 256-thread host
+    cores = min(avail, 32)       # MKL-DNN grouped convs stop scaling (and thrash) far below a 256-thread host
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     g = Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True)
@@ -73,17 +78,25 @@ def cpu_baseline(size):
     o = OracleStep(g.state_dict(), d.state_dict(), size, 1)
     gen = torch.Generator().manual_seed(0)
     real = torch.rand(1, 3, size, size, generator=gen) * 2 - 1
-    reps, t0 = 0, time.perf_counter()
-    while True:
-        o.d_step(real, torch.randn(1, 512, generator=gen))
-        o.g_step(torch.randn(1, 512, generator=gen))
-        reps += 1
-        el = time.perf_counter() - t0
-        if el >= 10.0 or reps >= 2:
-            break
-    return {'value': reps / el, 'unit': 'images/sec', 'cores': cores, 'kind': 'port',
-            'sample': f'{reps} x (D step + G step, no lazy regularisers) at {size}x{size}, batch 1, fp32, '
-                      f'oracle/step.py OracleStep on {cores} host threads, {el:.1f} s'}
+    phases = {}
+
+    def timed(name, fn, *a):
+        t0 = time.perf_counter()
+        fn(*a)
+        phases[name] = time.perf_counter() - t0
+
+    timed('d_step', o.d_step, real, torch.randn(1, 512, generator=gen))
+    timed('r1_step', o.d_reg, real)
+    timed('g_step', o.g_step, torch.randn(1, 512, generator=gen))
+    timed('pl_step', o.g_reg, torch.randn(1, 512, generator=gen))
+    per_iter = phases['d_step'] + phases['g_step'] + phases['r1_step'] / 16 + phases['pl_step'] / 4
+    plain = phases['d_step'] + phases['g_step']
+    return {'value': 1.0 / per_iter, 'unit': 'images/sec', 'cores': cores, 'host_cores': host_cores, 'kind': 'port',
+            'phase_seconds': {k: round(v, 2) for k, v in phases.items()},
+            'value_without_regularisers': 1.0 / plain,
+            'sample': f'one call of each phase (D step, R1, G step, path length) at {size}x{size}, batch 1, fp32, oracle/step.py OracleStep on '
+                      f'{cores} of {host_cores} host threads, {sum(phases.values()):.1f} s; images/sec = 1 / (t_D + t_G + t_R1/16 + t_PL/4), '
+                      f'the cadence of the GPU step (the lazy regularisers are {100 * (per_iter / plain - 1):.0f} % of the CPU iteration)'}
 
 
 def main():
@@ -125,6 +138,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def roofline_of(timer_summary, elapsed_s):
+        convs = {k: v for k, v in timer_summary.items() if k.startswith('conv_')}
+        if not convs:
+            return None
+        name, dom = max(convs.items(), key=lambda kv: kv[1]['total_ms'])
+        ach = dom['work'] / (dom['total_ms'] * 1e-3) / 1e12
+        split = name.startswith('conv_bf16x3')
+        peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
+        return {'bound': 'mfma', 'kernel': name, 'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
+                'launches': dom['launches'], 'avg_launch_us': dom['avg_us'], 'gpu_time_share': dom['total_ms'] / (1e3 * elapsed_s)}
+
     it = 0
     # Discovery during the (untimed) warm-up: every convolution launch is bracketed to find the variant that takes the most
     # GPU time; in the timed region only that variant (and the FIR tile kernel, for the HBM line) gets HIP events, so the
@@ -163,6 +187,40 @@ def main():
     elapsed = float(t.item())
     stats = trainer.reduced_stats()
 
+    # The same workload once more in exact fp32 arithmetic (the reference's precision): the headline `value` above is the
+    # split-bf16 mode (fp32 in HBM, ~16 mantissa bits in the products), so the line carries the fp32 figure next to it.
+    fp32_exact = None
+    if precision != 'f32' and not args.no_fp32_leg:
+        _backend.get().conv_mode = 'f32'
+        disc32 = KernelTimer(only=('conv',)) if (rank == 0 and not args.no_kernel_timer) else None
+        _backend.get().timer = disc32
+        for _ in range(args.warmup):
+            trainer.train_iteration(it, real)
+            it += 1
+        timer32 = None
+        if disc32 is not None:
+            torch.cuda.synchronize()
+            found = disc32.summary()
+            timer32 = KernelTimer(only=('conv',), names={max(found.items(), key=lambda kv: kv[1]['total_ms'])[0]} if found else set())
+        _backend.get().timer = timer32
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            trainer.train_iteration(it, real)
+            it += 1
+        barrier()
+        el32 = time.perf_counter() - t0
+        _backend.get().timer = None
+        _backend.get().conv_mode = precision
+        t = torch.tensor([el32], dtype=torch.float64, device='cuda')
+        if use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el32 = float(t.item())
+        fp32_exact = {'value': args.steps * args.batch_per_gpu * world / el32, 'unit': 'images/sec', 'ms_per_step': 1e3 * el32 / args.steps,
+                      'steps': args.steps, 'warmup': args.warmup, 'dtype': 'f32'}
+        if timer32 is not None:
+            fp32_exact['roofline'] = roofline_of(timer32.summary(), el32)
+
     if rank == 0:
         images = args.steps * args.batch_per_gpu * world
         out = {
@@ -185,14 +243,9 @@ def main():
                               'achieved': round(rate, 2), 'unit': 'TFLOP/s' if unit_tf else 'GB/s'}
             out['kernels'] = kernels
             if convs:
-                name, dom = max(convs.items(), key=lambda kv: kv[1]['total_ms'])
-                ach = dom['work'] / (dom['total_ms'] * 1e-3) / 1e12
-                split = name.startswith('conv_bf16x3')
-                peak = PEAK_BF16_MFMA_TFLOPS if split else PEAK_FP32_MFMA_TFLOPS
-                out['roofline'] = {'bound': 'mfma', 'kernel': name,
-                                   'achieved': ach, 'peak': peak, 'unit': 'TFLOP/s', 'frac': ach / peak, 'traffic': None,
-                                   'launches': dom['launches'], 'avg_launch_us': dom['avg_us'],
-                                   'gpu_time_share': dom['total_ms'] / (1e3 * elapsed)}
+                out['roofline'] = roofline_of(summ, elapsed)
+                name = out['roofline']['kernel']
+                ach, peak, split = out['roofline']['achieved'], out['roofline']['peak'], name.startswith('conv_bf16x3')
                 traffic_file = os.path.join(REPO, 'profiles', 'pmc_r01_traffic.json')
                 if os.path.exists(traffic_file):      # separate rocprofv3 --pmc passes (tools/pmc_mix.py), launch-weighted over this kernel's shape mix
                     pmc = json.load(open(traffic_file))
@@ -209,6 +262,8 @@ def main():
                 ach = fir['work'] / (fir['total_ms'] * 1e-3) / 1e9
                 out['roofline_hbm'] = {'bound': 'hbm', 'kernel': 'fir44_tile_kernel', 'achieved': ach, 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': ach / PEAK_HBM_GBS, 'traffic': None, 'launches': fir['launches'], 'avg_launch_us': fir['avg_us']}
+        if fp32_exact is not None:
+            out['fp32_exact'] = fp32_exact
         if not args.no_cpu_baseline and world == 1:
             out['cpu_baseline'] = cpu_baseline(args.cpu_baseline_size or args.size)
         print(json.dumps(out), flush=True)

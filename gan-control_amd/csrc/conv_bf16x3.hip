@@ -1267,27 +1267,43 @@ extern "C" size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d) {
     return 2 * units * sizeof(uint4);
 }
 
-extern "C" int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
-                                          const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
-                                          void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+extern "C" size_t gc_conv2d_bf16x3_packed_bytes(const gc_conv_desc* d) {
+    if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !eligible(d)) return 0;
+    return 2 * (size_t)d->kh * d->kw * ((d->in_ch + 7) / 8) * d->out_ch * sizeof(uint4);
+}
+
+extern "C" int gc_conv2d_pack_weights_bf16x3(const gc_conv_desc* d, const float* w, void* packed, size_t packed_bytes, gc_stream_t stream) {
+    int rc = validate(d, "gc_conv2d_pack_weights_bf16x3", false);
+    if (rc) return rc;
+    const size_t need = gc_conv2d_bf16x3_packed_bytes(d);
+    if (need == 0) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_pack_weights_bf16x3: this shape runs on the fp32 kernel and takes no packed weights");
+    if (!w || !packed || packed_bytes < need || (reinterpret_cast<uintptr_t>(packed) & 15))
+        return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_pack_weights_bf16x3: buffer %zu < %zu bytes (or null / not 16-byte aligned)", packed_bytes, need);
+    const int kgroups = (d->in_ch + 7) / 8, taps = d->kh * d->kw;
+    const size_t units = (size_t)taps * kgroups * d->out_ch;
+    uint4* wh = static_cast<uint4*>(packed);
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<size_t>((units + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
+                       w, wh, wh + units, taps, d->in_ch, d->out_ch, kgroups);
+    return gc::check_launch("gc_conv2d_pack_weights_bf16x3");
+}
+
+extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const float* x, const float* w, const void* packed, size_t packed_bytes,
+                                                 const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
+                                                 void* workspace, size_t workspace_bytes, gc_stream_t stream) {
     int rc = validate(d, "gc_conv2d_bf16x3_f32", false);
     if (rc) return rc;
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_bf16x3_f32: null pointer");
     if (d->batch == 0) return GC_OK;
     if ((rc = validate_epilogue(ep, "gc_conv2d_bf16x3_f32"))) return rc;
     if (!eligible(d)) return conv2d_f32_ws(d, x, w, in_scale, out_scale, ep, y, workspace, workspace_bytes, stream);
-    const size_t need = gc_conv2d_bf16x3_workspace(d);
-    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
-        return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_bf16x3_f32: workspace %zu < %zu bytes (or not 16-byte aligned)", workspace_bytes, need);
+    const size_t need = gc_conv2d_bf16x3_packed_bytes(d);
+    if (!packed || packed_bytes < need || (reinterpret_cast<uintptr_t>(packed) & 15))
+        return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_bf16x3_f32: packed weights %zu < %zu bytes (or null / not 16-byte aligned)", packed_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     const int kgroups = (d->in_ch + 7) / 8, taps = d->kh * d->kw;
     const size_t units = (size_t)taps * kgroups * d->out_ch;
-    uint4* wh = static_cast<uint4*>(workspace);
-    uint4* wl = wh + units;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<size_t>((units + 255) / 256, 4096)), dim3(256), 0, s,
-                       w, wh, wl, taps, d->in_ch, d->out_ch, kgroups);
-    rc = gc::check_launch("gc_conv2d_bf16x3_f32(pack)");
-    if (rc) return rc;
+    const uint4* wh = static_cast<const uint4*>(packed);
+    const uint4* wl = wh + units;
     Bf16Args a{{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
                 d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups, 1, 1};
     set_epilogue(a.c, ep);
@@ -1298,6 +1314,21 @@ extern "C" int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x,
     }
     if (d->up == 2) return dispatch<2, 1, 1>(a, s);
     return d->down == 2 ? dispatch<1, 2, 1>(a, s) : dispatch<1, 1, 1>(a, s);
+}
+
+extern "C" int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
+                                          const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
+                                          void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    int rc = validate(d, "gc_conv2d_bf16x3_f32", false);
+    if (rc) return rc;
+    if (d->batch == 0) return GC_OK;
+    const size_t need = gc_conv2d_bf16x3_packed_bytes(d);
+    if (need == 0) return gc_conv2d_fused_bf16x3_packed_f32(d, x, w, nullptr, 0, in_scale, out_scale, ep, y, workspace, workspace_bytes, stream);
+    if (!workspace || workspace_bytes < need || (reinterpret_cast<uintptr_t>(workspace) & 15))
+        return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_bf16x3_f32: workspace %zu < %zu bytes (or not 16-byte aligned)", workspace_bytes, need);
+    if (!w) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_bf16x3_f32: null pointer");
+    if ((rc = gc_conv2d_pack_weights_bf16x3(d, w, workspace, workspace_bytes, stream))) return rc;
+    return gc_conv2d_fused_bf16x3_packed_f32(d, x, w, workspace, workspace_bytes, in_scale, out_scale, ep, y, nullptr, 0, stream);
 }
 
 extern "C" int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,

@@ -5,6 +5,7 @@ implementation shipped is ``HipBackend`` (ctypes -> libgancontrol_hip.so).  Test
 emulation of the same interface to validate the autograd wiring on machines without a GPU;
 the product never does.
 """
+import contextlib
 import ctypes
 import os
 from collections import namedtuple
@@ -12,6 +13,7 @@ from collections import namedtuple
 import torch
 
 from ... import _lib
+from . import weight_cache
 
 # ctx.needs_input_grad of a custom Function is fixed at forward time: inside `autograd.grad(outputs, inputs=[...])` a backward
 # cannot see that only the listed inputs are wanted.  R1 (gradient w.r.t. the real images) and the path-length regulariser
@@ -306,10 +308,21 @@ class HipBackend:
             if noise is not None and noise.numel() != x.shape[0] * geom.out_h * geom.out_w:
                 raise RuntimeError('conv2d epilogue: noise has %d elements, expected %d' % (noise.numel(), x.shape[0] * geom.out_h * geom.out_w))
             ep = ctypes.byref(_lib.ConvEpilogue(_lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), float(slope), float(gain), int(bool(activate)), _lib.ptr(residual)))
-        ws = None
+        ws = packed = None
         if self.conv_mode == 'bf16x3':
-            nbytes = lib.gc_conv2d_bf16x3_workspace(desc)
-            ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
+            pbytes = lib.gc_conv2d_bf16x3_packed_bytes(desc)
+            if pbytes:
+                # hi / lo split of the weights: once per (weight, optimiser step) when w_t derives from a parameter (weight_cache.py)
+                def pack():
+                    buf = torch.empty(pbytes // 4, dtype=torch.float32, device=dev)
+                    with (self._guard(dev) or contextlib.nullcontext()):
+                        _lib.check(lib.gc_conv2d_pack_weights_bf16x3(desc, _lib.ptr(w_t), _lib.ptr(buf), pbytes, _lib.stream_of(w_t)), 'gc_conv2d_pack_weights_bf16x3')
+                    return buf
+                packed = weight_cache.derive(w_t, ('pack_bf16x3',), pack)
+                ws = packed          # not used as a workspace; keeps the call below uniform
+            else:
+                nbytes = lib.gc_conv2d_bf16x3_workspace(desc)
+                ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
         elif self.conv_mode != 'f32':
             raise RuntimeError('GANCONTROL_CONV_PRECISION must be f32 or bf16x3, got %r' % self.conv_mode)
         g = self._guard(dev)
@@ -322,9 +335,12 @@ class HipBackend:
         try:
             if ws is None:
                 rc = lib.gc_conv2d_fused_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y), _lib.stream_of(x))
+            elif packed is not None:
+                rc = lib.gc_conv2d_fused_bf16x3_packed_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(packed), packed.numel() * 4, _lib.ptr(in_scale),
+                                                           _lib.ptr(out_scale), ep, _lib.ptr(y), None, 0, _lib.stream_of(x))
             else:
-                rc = lib.gc_conv2d_fused_bf16x3_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y),
-                                                    _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
+                rc = lib.gc_conv2d_fused_bf16x3_packed_f32(desc, _lib.ptr(x), _lib.ptr(w_t), None, 0, _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y),
+                                                           _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
         finally:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_conv2d_fused_f32')

@@ -1,0 +1,85 @@
+"""Derived forms of a weight tensor, computed once per optimiser step instead of once per call.
+
+A convolution weight enters the kernels as ``w_t`` (kernel layout, scaled), as ``adj(w_t)`` (input-gradient
+weights) and -- in split-bf16 mode -- as the hi / lo packs of both.  The reference recomputes ``weight * scale`` and
+the layout permutes of ``aten::convolution_backward`` on every call (gan_model.py:154, 284, 295-303); the parameter,
+however, only changes when the optimiser steps, while one training iteration uses it 2-4 times (D step: forward +
+input gradient over the interleaved fake / real batch; R1; the G forward of the D step and of the G step, ...).
+
+The cache is keyed on the ROOT tensor (the parameter, or the leaf a test passes in) and its autograd version counter
+(every in-place update -- Adam, ``load_state_dict``, EMA -- bumps it), so an entry can never be stale.  Derived tensors
+register their storage address, which lets a derivation of a derivation (``adj(w_t)``, ``pack(adj(w_t))``) find its
+root without any attribute travelling through ``save_for_backward``.  The cache owns the derived tensors while they
+are valid, so a registered address cannot be re-used by another live tensor.  Results are bit-identical to
+recomputing (same kernels, same inputs).  ``GANCONTROL_WEIGHT_CACHE=0`` turns it off.
+"""
+import os
+import weakref
+
+import torch
+
+ENABLED = os.environ.get('GANCONTROL_WEIGHT_CACHE', '1') != '0'
+
+_roots = {}      # id(root) -> [weakref(root), version, {key: tensor}]
+_derived = {}    # data_ptr of a cached tensor -> (id(root), key)
+stats = {'hit': 0, 'miss': 0, 'bypass': 0}
+
+
+def _drop(rid):
+    entry = _roots.pop(rid, None)
+    if entry is not None:
+        for t in entry[2].values():
+            _derived.pop(t.data_ptr(), None)
+
+
+def _root_of(src):
+    """(root id, key prefix) of a tensor the cache may derive from, or None."""
+    if src.numel() == 0:
+        return None
+    hit = _derived.get(src.data_ptr())
+    if hit is not None:
+        entry = _roots.get(hit[0])
+        if entry is not None and entry[0]() is not None and entry[0]()._version == entry[1] and hit[1] in entry[2] \
+                and entry[2][hit[1]].shape == src.shape:
+            return hit
+    root = src._base if src._is_view() and src._base is not None else src
+    if root.grad_fn is None and (isinstance(root, torch.nn.Parameter) or root.requires_grad) and root.is_contiguous() and src.is_contiguous():
+        rid = id(root)
+        entry = _roots.get(rid)
+        if entry is None or entry[0]() is not root:
+            _drop(rid)
+            _roots[rid] = entry = [weakref.ref(root, lambda _, rid=rid: _drop(rid)), root._version, {}]
+        elif entry[1] != root._version:
+            for t in entry[2].values():
+                _derived.pop(t.data_ptr(), None)
+            entry[1], entry[2] = root._version, {}
+        return (rid, (src.storage_offset(), tuple(src.shape)))
+    return None
+
+
+def derive(src, op, make):
+    """``make()`` -- a tensor computed from ``src`` alone by the operation named ``op`` (hashable) -- cached for as
+    long as the root of ``src`` keeps its version.  Returns the cached tensor itself: callers must not modify it, and an
+    autograd Function must return an alias (``.detach()``), not this object."""
+    where = _root_of(src) if ENABLED else None
+    if where is None:
+        stats['bypass'] += 1
+        return make()
+    rid, prefix = where
+    key = prefix + (op,)
+    bucket = _roots[rid][2]
+    out = bucket.get(key)
+    if out is None:
+        stats['miss'] += 1
+        out = make()
+        if out.numel() > 0 and out.data_ptr() not in _derived:
+            bucket[key] = out
+            _derived[out.data_ptr()] = (rid, key)
+    else:
+        stats['hit'] += 1
+    return out
+
+
+def clear():
+    for rid in list(_roots):
+        _drop(rid)

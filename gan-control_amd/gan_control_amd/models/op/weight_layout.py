@@ -8,6 +8,7 @@ scale) and the closure needed for R1 / path-length double-backward is immediate.
 from torch.autograd import Function
 
 from . import _backend
+from . import weight_cache
 
 
 class _Relayout(Function):
@@ -18,7 +19,11 @@ class _Relayout(Function):
         taps, k, n, src_stride, dst_shape, dst_stride, flip = spec
         ctx.inverse = (taps, k, n, dst_stride, tuple(src.shape), src_stride, flip)
         ctx.scale = scale
-        return _backend.get().weight_layout(src.contiguous(), taps, k, n, src_stride, dst_shape, dst_stride, flip, scale)
+        # once per (weight, optimiser step): the result is cached on the weight's version counter (weight_cache.py); .detach() = a
+        # fresh alias for autograd to attach this node to
+        out = weight_cache.derive(src, ('layout', taps, k, n, tuple(src_stride), tuple(dst_shape), tuple(dst_stride), bool(flip), float(scale)),
+                                  lambda: _backend.get().weight_layout(src.contiguous(), taps, k, n, src_stride, dst_shape, dst_stride, flip, scale))
+        return out.detach()
 
     @staticmethod
     def backward(ctx, g):

@@ -213,6 +213,20 @@ int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x, const floa
                                const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
                                void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
+/* The split weights as a separate, reusable object.  A parameter changes once per optimiser step but is used by several
+ * launches in between (forward and input gradient of D over the fake and real batches, R1, the generator passes of the D and G
+ * steps), so the caller may split a weight tensor ONCE -- gc_conv2d_pack_weights_bf16x3 into a buffer of
+ * gc_conv2d_bf16x3_packed_bytes(d) bytes, 16-byte aligned; the buffer depends on (kh, kw, in_ch, out_ch) and w only -- and hand
+ * it to every launch that uses the same w (the reference recomputes `weight * scale` per call, gan_model.py:154, 284).
+ * gc_conv2d_bf16x3_packed_bytes returns 0 for shapes that run on the fp32 kernel: pass packed = NULL and a workspace of
+ * gc_conv2d_bf16x3_workspace(d) bytes then.  Same results as gc_conv2d_fused_bf16x3_f32, bit for bit.
+ */
+size_t gc_conv2d_bf16x3_packed_bytes(const gc_conv_desc* d);
+int gc_conv2d_pack_weights_bf16x3(const gc_conv_desc* d, const float* w, void* packed, size_t packed_bytes, gc_stream_t stream);
+int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const float* x, const float* w, const void* packed, size_t packed_bytes,
+                                      const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
+                                      void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
 /* Weight gradient of the same contraction (up must be 1):
  *
  *   dw[ty,tx,k,n] = sum_{b,oy,ox} in_scale[b,k] * x[b,k, oy*down + ty - pad_y, ox*down + tx - pad_x]

@@ -71,3 +71,44 @@ def test_misc_modules(emu_backend):
 @pytest.mark.parametrize('name', ['ffhq', 'metfaces', 'afhq'])
 def test_trainer_from_shipped_config(name, emu_backend):
     oc.check_config_ingestion('cpu', name, size=16, batch=4)
+
+
+def test_weight_cache_reuse_and_invalidation(emu_backend):
+    """Derived weight forms (kernel layout, its adjoint) are computed once per weight version: reused by the next call, recomputed
+    after an in-place update, and never change a result or a gradient."""
+    from gan_control_amd.models.op import conv2d_gradfix, weight_cache
+    weight_cache.clear()
+    gen = torch.Generator().manual_seed(0)
+    w = torch.nn.Parameter(torch.randn(6, 5, 3, 3, generator=gen))
+    x = torch.randn(2, 5, 8, 8, generator=gen, requires_grad=True)
+
+    def run():
+        y = conv2d_gradfix.conv2d(x, w, padding=1, weight_scale=0.5)
+        gx, gw = torch.autograd.grad(y.square().sum(), [x, w])
+        return y.detach(), gx, gw
+
+    before = dict(weight_cache.stats)
+    a = run()
+    first = {k: weight_cache.stats[k] - before[k] for k in before}
+    b = run()
+    second = {k: weight_cache.stats[k] - before[k] - first[k] for k in before}
+    assert first['miss'] == 2 and first['hit'] == 0, first            # kernel layout + its adjoint (input-gradient weights)
+    assert second['miss'] == 0 and second['hit'] == 2, second
+    for u, v in zip(a, b):
+        assert torch.equal(u, v)
+    with torch.no_grad():
+        w.mul_(2.0)                                                      # what an optimiser step does: bumps the version counter
+    c = run()
+    assert weight_cache.stats['miss'] - before['miss'] == 4
+    assert torch.allclose(c[0], 2 * a[0], rtol=1e-6) and torch.allclose(c[2], 2 * a[2], rtol=1e-5)
+    weight_cache.ENABLED, prev = False, weight_cache.ENABLED
+    try:
+        d = run()
+    finally:
+        weight_cache.ENABLED = prev
+    for u, v in zip(c, d):
+        assert torch.equal(u, v)
+    del w
+    import gc
+    gc.collect()
+    weight_cache.clear()
