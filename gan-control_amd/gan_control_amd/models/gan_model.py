@@ -243,11 +243,19 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, out_channels, 1, style_dim, demodulate=False, conv_transpose=conv_transpose)
         self.bias = nn.Parameter(torch.zeros(1, out_channels, 1, 1))
 
-    def forward(self, input, style, skip=None):
-        out = self.conv(input, style) + self.bias
-        if skip is not None:
-            out = out + self.upsample(skip)
-        return out
+    def forward(self, input, style, skip=None, fork=False):
+        """fork=True returns (rgb, input') where input' is `input` for its second consumer (the next up-sampling layer): that
+        consumer's gradient is then added inside this layer's input-gradient kernel instead of by a separate pass."""
+        conv = self.conv
+        if not _FUSE_EPILOGUE:
+            out = conv(input, style) + self.bias
+            if skip is not None:
+                out = out + self.upsample(skip)
+            return (out, input) if fork else out
+        # 1x1 modulated conv + bias + up-sampled skip in ONE launch: the two adds run in the convolution's epilogue
+        up = self.upsample(skip) if skip is not None else None
+        return modulated_conv2d(input, conv.weight, conv.modulation(style), demodulate=conv.demodulate, padding=conv.padding,
+                                bias=self.bias, residual=up, fork=fork)
 
 
 class MultiFcStack(nn.Module):
@@ -370,12 +378,13 @@ class Generator(nn.Module):
         # one unbind instead of 26 slices: its backward is a single stack, a slice's backward is a zero-fill + add of the whole latent
         lat = latent.unbind(1)
         out = self.conv1(out, lat[0], noise=noise[0])
-        skip = self.to_rgb1(out, lat[1])
+        # every StyledConv output feeds ToRGB and the next up-sampling layer: ToRGB forks it (see ToRGB.forward)
+        skip, out = self.to_rgb1(out, lat[1], fork=True)
         i = 1
         for up_conv, conv, n1, n2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2], self.to_rgbs):
             out = up_conv(out, lat[i], noise=n1)
             out = conv(out, lat[i + 1], noise=n2)
-            skip = to_rgb(out, lat[i + 2], skip)
+            skip, out = to_rgb(out, lat[i + 2], skip, fork=True)
             i += 2
         image = skip
         if return_grad:

@@ -40,11 +40,14 @@ class _GConv(Function):
         ctx.geom = geom
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.save_for_backward(x, w_t)
+        ctx.set_materialize_grads(False)
         ep = None if residual is None else (None, None, None, 1.0, 1.0, False, residual.contiguous())
         return _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None, None, geom, epilogue=ep)
 
     @staticmethod
     def backward(ctx, gy):
+        if gy is None:
+            return (None,) * len(ctx.needs_input_grad)
         x, w_t = ctx.saved_tensors
         g = ctx.geom
         gx = gw = None
@@ -70,10 +73,13 @@ class _WGrad(Function):
         ctx.geom = geom
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.save_for_backward(x, gy)
+        ctx.set_materialize_grads(False)
         return _backend.get().conv2d_wgrad(x.contiguous(), gy.contiguous(), None, None, geom)
 
     @staticmethod
     def backward(ctx, ggw):
+        if ggw is None:
+            return None, None, None
         x, gy = ctx.saved_tensors
         g = ctx.geom
         gx = ggy = None
@@ -100,6 +106,7 @@ class _GConvAct(Function):
         ctx.geom, ctx.cfg = geom, (slope, gain)
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.save_for_backward(x, w_t, out)
+        ctx.set_materialize_grads(False)
         return (out, x.view_as(x)) if fork else out
 
     @staticmethod

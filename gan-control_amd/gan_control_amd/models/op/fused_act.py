@@ -22,10 +22,13 @@ class _ChannelSum(Function):
     @staticmethod
     def forward(ctx, t):
         ctx.shape = t.shape
+        ctx.set_materialize_grads(False)
         return _backend.get().channel_sum(t.contiguous())
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None
         shape = ctx.shape
         return g.reshape([1, -1] + [1] * (len(shape) - 2)).expand(shape)
 
@@ -37,6 +40,8 @@ class _BiasAct(Function):
         ctx.cfg = (slope, gain)
         ctx.has_bias, ctx.has_noise = bias is not None, noise is not None
         ctx.save_for_backward(y, noise if noise is not None else y.new_empty(0), noise_w if noise_w is not None else y.new_empty(0))
+        # (default gradient materialisation on purpose: the reference's leaky-ReLU yields ZERO second-order gradients through its mask,
+        # and this public op keeps that None-vs-zero structure; the internal Functions below pass None on instead of zeros)
         return y
 
     @staticmethod
@@ -109,10 +114,13 @@ class _BiasActGradReduce(Function):
             dead.append(pself)
         if dead:
             ctx.mark_non_differentiable(*dead)
+        ctx.set_materialize_grads(False)        # cotangents of outputs nobody used arrive as None: the adjoint pass skips their terms
         return gx, psum, pdot, pself
 
     @staticmethod
     def backward(ctx, ggx, gpsum, gpdot, gpself):
+        if ggx is None and gpsum is None and gpdot is None and gpself is None:
+            return (None,) * 8
         y, noise, bias, noise_w, gx = ctx.saved_tensors
         slope, gain = ctx.cfg
         b = y.shape[0]
@@ -170,10 +178,13 @@ class _BiasActGrad(Function):
     def forward(ctx, gy, y, slope, gain):
         ctx.save_for_backward(y)
         ctx.cfg = (slope, gain)
+        ctx.set_materialize_grads(False)
         return _backend.get().bias_act_bwd(gy.contiguous(), y, slope, gain)
 
     @staticmethod
     def backward(ctx, ggx):
+        if ggx is None:
+            return None, None, None, None
         y, = ctx.saved_tensors
         slope, gain = ctx.cfg
         ggy = _BiasActGrad.apply(ggx, y, slope, gain) if ctx.needs_input_grad[0] else None

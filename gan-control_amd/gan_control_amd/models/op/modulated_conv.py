@@ -59,45 +59,76 @@ class _PlaneDot(Function):
     @staticmethod
     def forward(ctx, a, b):
         ctx.save_for_backward(a, b)
+        ctx.set_materialize_grads(False)
         return _backend.get().plane_dot(a.contiguous(), b.contiguous())
 
     @staticmethod
     def backward(ctx, g):
+        if g is None:
+            return None, None
         a, b = ctx.saved_tensors
         g4 = g[:, :, None, None]
         return (g4 * b if ctx.needs_input_grad[0] else None), (g4 * a if ctx.needs_input_grad[1] else None)
 
 
 class _ModConv(Function):
-    """y = so * gconv(si * x, w_t); si / so may be None."""
+    """y = so * gconv(si * x, w_t) [+ bias] [+ residual]; si / so may be None.
+
+    bias [N] and residual (shaped like y) ride in the convolution's epilogue (gc_conv_epilogue): ToRGB's `+ self.bias` and
+    `+ self.upsample(skip)` (gan_model.py:430-433) cost no pass of their own.  fork=True additionally returns x itself as a second
+    output for the OTHER consumer of x (the StyledConv output feeds both ToRGB and the next up-sampling layer): that consumer's
+    gradient then arrives here as the second output-gradient and is added inside the input-gradient convolution (its residual
+    epilogue) instead of by autograd's separate elementwise add over the largest tensors of G."""
 
     @staticmethod
-    def forward(ctx, x, w_t, si, so, geom):
+    def forward(ctx, x, w_t, si, so, geom, bias=None, residual=None, fork=False):
+        ep = None
+        if bias is not None or residual is not None:
+            ep = (bias, None, None, 1.0, 1.0, False, None if residual is None else residual.contiguous())
         y = _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None if si is None else si.contiguous(),
-                                  None if so is None else so.contiguous(), geom)
+                                  None if so is None else so.contiguous(), geom, epilogue=ep)
         ctx.geom, ctx.in_hw = geom, (x.shape[2], x.shape[3])
-        ctx.has_si, ctx.has_so = si is not None, so is not None
+        ctx.has_si, ctx.has_so, ctx.has_bias, ctx.has_res = si is not None, so is not None, bias is not None, residual is not None
+        ctx.set_materialize_grads(False)        # an output nobody differentiated arrives as None, not as a tensor of zeros
         empty = x.new_empty(0)
-        ctx.save_for_backward(x, w_t, si if si is not None else empty, so if so is not None else empty, y)
-        return y
+        # the out_scale gradient needs the convolution part of y only: keep what was added on top of it
+        keep_res = residual if (residual is not None and so is not None) else empty
+        keep_bias = bias if (bias is not None and so is not None) else empty
+        ctx.save_for_backward(x, w_t, si if si is not None else empty, so if so is not None else empty, y, keep_res, keep_bias)
+        return (y, x.view_as(x)) if fork else y
 
     @staticmethod
-    def backward(ctx, gy):
-        x, w_t, si, so, y = ctx.saved_tensors
+    def backward(ctx, gy, gfork=None):
+        x, w_t, si, so, y, res, bias = ctx.saved_tensors
         si = si if ctx.has_si else None
         so = so if ctx.has_so else None
         g = ctx.geom
-        gx = gw = gsi = gso = None
-        need_si = ctx.has_si and ctx.needs_input_grad[2]
-        if ctx.needs_input_grad[0] or need_si:
-            gx = _ModConv.apply(gy, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw))
-        if ctx.needs_input_grad[1] and _backend.want_param_grads():
+        need = ctx.needs_input_grad
+        gx = gw = gsi = gso = gb = gres = None
+        if gy is None:                      # only the forked copy was used downstream (or nothing at all)
+            return (gfork if need[0] else None), None, None, None, None, None, None, None
+        need_si = ctx.has_si and need[2]
+        if need[0] or need_si:
+            gx = _ModConv.apply(gy, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw), None, gfork if need[0] else None)
+        if need[1] and _backend.want_param_grads():
             gw = _mod_weight_grad(x, gy, si, so, g)
         if need_si:
-            gsi = _PlaneDot.apply(x, gx) / _safe(si)
-        if ctx.has_so and ctx.needs_input_grad[3]:
-            gso = _PlaneDot.apply(gy, y) / _safe(so)
-        return (gx if ctx.needs_input_grad[0] else None), gw, gsi, gso, None
+            # d/dsi sees the convolution only, not the forked gradient that was added in the epilogue
+            conv_part = gx if (gfork is None or not need[0]) else gx - gfork
+            gsi = _PlaneDot.apply(x, conv_part) / _safe(si)
+        if ctx.has_so and need[3]:
+            conv_part = y
+            if ctx.has_res:
+                conv_part = conv_part - res
+            if ctx.has_bias:
+                conv_part = conv_part - bias.reshape(1, -1, 1, 1)
+            gso = _PlaneDot.apply(gy, conv_part) / _safe(so)
+        if ctx.has_bias and need[5] and _backend.want_param_grads():
+            from .fused_act import _channel_sum
+            gb = _channel_sum(gy)
+        if ctx.has_res and need[6]:
+            gres = gy
+        return (gx if need[0] else None), gw, gsi, gso, None, gb, gres, None
 
 
 class _ModConvAct(Function):
@@ -118,6 +149,7 @@ class _ModConvAct(Function):
         ctx.has = (si is not None, so is not None, bias is not None, noise is not None)
         empty = x.new_empty(0)
         ctx.save_for_backward(x, w_t, *[t if t is not None else empty for t in (si, so, bias, noise, noise_w)], out)
+        ctx.set_materialize_grads(False)
         return out
 
     @staticmethod
@@ -130,7 +162,7 @@ class _ModConvAct(Function):
         g, (slope, gain) = ctx.geom, ctx.cfg
         need = ctx.needs_input_grad
         gx = gw = gsi = gso = gb = gnw = None
-        if not any(need[:7]):
+        if gy is None or not any(need[:7]):
             return (None,) * 10
         want_so = has_so and need[3]
         if not _backend.want_param_grads():
@@ -173,11 +205,14 @@ class _ModWGrad(Function):
         ctx.has_si, ctx.has_so = si is not None, so is not None
         empty = x.new_empty(0)
         ctx.save_for_backward(x, gy, si if si is not None else empty, so if so is not None else empty)
+        ctx.set_materialize_grads(False)
         return _backend.get().conv2d_wgrad(x.contiguous(), gy.contiguous(), None if si is None else si.contiguous(),
                                            None if so is None else so.contiguous(), geom)
 
     @staticmethod
     def backward(ctx, ggw):
+        if ggw is None:
+            return None, None, None, None, None
         x, gy, si, so = ctx.saved_tensors
         si = si if ctx.has_si else None
         so = so if ctx.has_so else None
@@ -196,7 +231,8 @@ class _ModWGrad(Function):
         return (gx if ctx.needs_input_grad[0] else None), (ggy if ctx.needs_input_grad[1] else None), gsi, gso, None
 
 
-def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=None, blur_pad=None, padding=None, apply_blur=True):
+def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=None, blur_pad=None, padding=None, apply_blur=True,
+                     bias=None, residual=None, fork=False):
     """x [B,IC,H,W]; weight [1,OC,IC,k,k] (the reference parameter layout); s [B,IC] = modulation(style).
 
     plain:    conv2d(padding = k // 2)                                    gan_model.py:325-329
@@ -206,6 +242,8 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
     scale = 1.0 / math.sqrt(ic * k * k)
     d = demod_coefficients(weight, s, scale) if demodulate else None
     if upsample:
+        if bias is not None or residual is not None or fork:
+            raise NotImplementedError('modulated_conv2d: bias / residual / fork are built for the plain branch only')
         w_t = kernel_layout(weight.view(oc, ic, k, k), scale, flip=True)                   # correlation form, [k,k,IC,OC]
         oh, ow = (x.shape[2] - 1) * 2 + k, (x.shape[3] - 1) * 2 + k
         y = _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 2, 1, k - 1, k - 1, oh, ow))
@@ -213,7 +251,10 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
     pad = k // 2 if padding is None else padding
     w_t = kernel_layout(weight.view(oc, ic, k, k), scale)
     oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1
-    return _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow))
+    if bias is None and residual is None and not fork:
+        return _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow))
+    # plain branch only: `+ bias` / `+ residual` in the convolution's epilogue, fork = (y, x for its other consumer)
+    return _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow), None if bias is None else bias.reshape(-1).contiguous(), residual, bool(fork))
 
 
 def modulated_conv2d_act(x, weight, s, bias, noise, noise_weight, demodulate=True, padding=None, negative_slope=0.2, act_scale=2 ** 0.5):

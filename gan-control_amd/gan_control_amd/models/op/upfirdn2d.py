@@ -22,12 +22,13 @@ class _UpFirDn2d(Function):
             raise ValueError(f'upfirdn2d: empty output for input {h}x{w}, kernel {kh}x{kw}, up={up}, down={down}, pad=({p0},{p1})')
         ctx.save_for_backward(kernel)
         ctx.cfg = (up, down, p0, p1, h, w)
+        ctx.set_materialize_grads(False)        # a gradient nobody asked for arrives as None, not as a tensor of zeros to push through the kernels
         return _backend.get().upfirdn2d(x.contiguous(), kernel, up, down, p0, p0, oh, ow, True)
 
     @staticmethod
     def backward(ctx, gy):
         kernel, = ctx.saved_tensors
-        gx = _UpFirDn2dAdjoint.apply(gy, kernel, ctx.cfg) if ctx.needs_input_grad[0] else None
+        gx = _UpFirDn2dAdjoint.apply(gy, kernel, ctx.cfg) if (ctx.needs_input_grad[0] and gy is not None) else None
         return gx, None, None, None, None, None
 
 
@@ -40,6 +41,7 @@ class _UpFirDn2dAdjoint(Function):
         kh, kw = kernel.shape
         ctx.save_for_backward(kernel)
         ctx.cfg = cfg
+        ctx.set_materialize_grads(False)        # a gradient nobody asked for arrives as None, not as a tensor of zeros to push through the kernels
         return _backend.get().upfirdn2d(gy.contiguous(), kernel, down, up, kw - 1 - p0, kh - 1 - p0, h, w, False)
 
     @staticmethod
@@ -47,7 +49,7 @@ class _UpFirDn2dAdjoint(Function):
         kernel, = ctx.saved_tensors
         up, down, p0, p1, h, w = ctx.cfg
         # the adjoint of the adjoint is the forward operator
-        ggy = _UpFirDn2d.apply(ggx, kernel, up, down, p0, p1) if ctx.needs_input_grad[0] else None
+        ggy = _UpFirDn2d.apply(ggx, kernel, up, down, p0, p1) if (ctx.needs_input_grad[0] and ggx is not None) else None
         return ggy, None, None
 
 
@@ -70,6 +72,7 @@ class _UpFirDn2dAct(Function):
         ctx.has_bias, ctx.has_noise = bias is not None, noise is not None
         empty = x.new_empty(0)
         ctx.save_for_backward(kernel, out, noise if noise is not None else empty, noise_w if noise_w is not None else empty)
+        ctx.set_materialize_grads(False)        # a gradient nobody asked for arrives as None, not as a tensor of zeros to push through the kernels
         return out
 
     @staticmethod
@@ -81,7 +84,7 @@ class _UpFirDn2dAct(Function):
         gx = gb = gnw = None
         params = _backend.want_param_grads()
         want_b, want_nw = ctx.has_bias and need[4] and params, ctx.has_noise and need[6] and params
-        if not (need[0] or want_b or want_nw):
+        if gy is None or not (need[0] or want_b or want_nw):
             return (None,) * 9
         if want_b or want_nw:
             g_pre, psum, pdot = _BiasActGradReduce.apply(gy, out, noise if want_nw else None, slope, gain)[:3]

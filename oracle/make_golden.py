@@ -432,6 +432,42 @@ def golden_step(size=32, batch=4, name='step'):
     stats.update(g_path_loss=path_loss.detach(), g_mean_path_length=mean_path, path_lengths=lengths.detach())
     ref_tu.accumulate(g_ema, g, 0.5 ** (batch / cfg['g_moving_average']))
 
+    # --- every backward pass once more IN ISOLATION: from the un-updated procedural weights, no optimiser step in between.
+    # The first Adam steps are sign-like (+-lr whatever the gradient's size), so in the sequential iteration above an element
+    # whose gradient is ~0 may step either way and every later pass inherits that noise; the isolated passes pin each
+    # backward's gradients (per-parameter norms) without it.  'd' needs no re-run: it is the first pass of the iteration.
+    del fake, fake_pred, real_pred, g_loss, d_loss, grad, path_loss, lengths, r1, real_r
+    gi, di, _, _ = build_ref(size)
+    iso = {}
+    ref_tu.requires_grad(gi, False); ref_tu.requires_grad(di, True)
+    real_r = real.clone().requires_grad_(True)
+    real_pred, _ = di(real_r)
+    r1 = RT.d_r1_loss(None, real_pred, real_r)
+    (cfg['r1'] / 2 * r1 * cfg['d_reg_every'] + 0 * real_pred[0]).backward()
+    ref_tu.set_grad_none(di, none_d)
+    iso['r1'] = sample_grads(di)
+    iso_stats = {'d_r1_loss': r1.detach()}
+    del real_r, real_pred, r1
+    di.zero_grad()
+    ref_tu.requires_grad(gi, True); ref_tu.requires_grad(di, False)
+    fake, _ = gi([z_g], noise=noise_g)
+    fake_pred, _ = di(fake)
+    g_loss = RT.g_nonsaturating_loss(fake_pred)
+    g_loss.backward()
+    iso['g'] = sample_grads(gi)
+    iso_stats['g_adv_loss'] = g_loss.detach()
+    del fake, fake_pred, g_loss
+    gi.zero_grad()
+    fake, latent = gi([z_pl], noise=noise_pl, return_latents=True)
+    with mock.patch.object(torch, 'randn_like', lambda t: pl_noise):
+        grad = ref_gm.Generator.g_path_regularize_grad(fake, latent)
+    path_loss, _, lengths = RT.g_path_regularize_grad(grad, 0)
+    (cfg['path_regularize'] * cfg['g_reg_every'] * path_loss + 0 * fake[0, 0, 0, 0]).backward()
+    ref_tu.set_grad_none(gi, none_g)
+    iso['pl'] = sample_grads(gi)
+    iso_stats.update(g_path_loss=path_loss.detach(), path_lengths=lengths.detach())
+    del fake, latent, grad, path_loss, lengths, gi, di
+
     # --- the oracle's own step must reproduce all of it -------------------------------------------
     o = step.OracleStep(g_sd, d_sd, size, batch, none_g=none_g, none_d=none_d)
     o.iteration(0, real, z_d, z_g, z_pl=z_pl, noise_d=noise_d, noise_g=noise_g, noise_pl=noise_pl, pl_noise=pl_noise)
@@ -462,6 +498,10 @@ def golden_step(size=32, batch=4, name='step'):
     for phase, (names, norms) in grad_samples.items():          # per-parameter gradient norms of each of the four backward passes
         out[f'gradnorm/{phase}/names'] = np.array(names)
         out[f'gradnorm/{phase}/vals'] = torch.stack(norms)
+    for phase, (names, norms) in iso.items():                    # ... and of the passes run in isolation
+        out[f'iso/{phase}/names'] = np.array(names)
+        out[f'iso/{phase}/vals'] = torch.stack(norms)
+    out.update({f'iso/stat/{k}': v for k, v in iso_stats.items()})
     gen2 = torch.Generator().manual_seed(8)
     for tag, mod in (('g', g), ('d', d), ('g_ema', g_ema)):
         names, vals = [], []

@@ -556,8 +556,9 @@ def test_step_golden_baseline_sizes(name, mode):
 
 
 def test_headline_iteration_bf16x3_vs_f32():
-    """The bench workload itself (1024x1024, 4 images: no CPU fixture fits the build container): the split-bf16 iteration against
-    the exact-fp32 iteration on the same inputs -- losses, path lengths and the gradient norm of every parameter."""
+    """The bench workload itself (1024x1024, 4 images: no CPU fixture fits the build container): each of the four backward passes of
+    the iteration in split-bf16 arithmetic against the same pass in exact fp32 on the same inputs and weights -- losses, path lengths
+    and the gradient norm of every parameter.  Every pass starts from the un-updated weights (see step_checks.check_step)."""
     import step_checks
     from gan_control_amd.trainers.utils import requires_grad
     hip, _ = _be()
@@ -568,38 +569,46 @@ def test_headline_iteration_bf16x3_vs_f32():
     runs = {}
     prev = hip.conv_mode
     try:
+        tr = step_checks.make_trainer(DEV, size=1024, batch=4)
+        fresh_g = {k: v.detach().clone() for k, v in tr.generator.state_dict().items()}
+        fresh_d = {k: v.detach().clone() for k, v in tr.discriminator.state_dict().items()}
+        grads = lambda m: {n: p.grad.norm().clone() for n, p in m.named_parameters() if p.grad is not None}
         for mode in ('f32', 'bf16x3'):
             hip.conv_mode = mode
-            tr = step_checks.make_trainer(DEV, size=1024, batch=4)
             rec = {}
-            requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
-            tr.discriminator_step([[z_d]], [real], noise=oc.seeded_noise(1024, 4, 1, DEV))
-            rec['d'] = {n: p.grad.norm() for n, p in tr.discriminator.named_parameters()}
-            tr.discriminator_regularize_step([real])
-            rec['r1'] = {n: p.grad.norm() for n, p in tr.discriminator.named_parameters() if p.grad is not None}
-            requires_grad(tr.generator, True); requires_grad(tr.discriminator, False)
-            tr.generator_step([[z_g]], noise=oc.seeded_noise(1024, 4, 2, DEV))
-            rec['g'] = {n: p.grad.norm() for n, p in tr.generator.named_parameters()}
-            tr.generator_regularize_step(noise=oc.seeded_noise(1024, 2, 3, DEV), pl_noise=pl_noise, z=[z_pl])
-            rec['pl'] = {n: p.grad.norm() for n, p in tr.generator.named_parameters() if p.grad is not None}
+            for phase in ('d', 'r1', 'g', 'pl'):
+                tr.generator.load_state_dict(fresh_g)
+                tr.discriminator.load_state_dict(fresh_d)
+                tr.mean_path_length = 0
+                on_d = phase in ('d', 'r1')
+                requires_grad(tr.generator, not on_d); requires_grad(tr.discriminator, on_d)
+                if phase == 'd':
+                    tr.discriminator_step([[z_d]], [real], noise=oc.seeded_noise(1024, 4, 1, DEV))
+                elif phase == 'r1':
+                    tr.discriminator_regularize_step([real])
+                elif phase == 'g':
+                    tr.generator_step([[z_g]], noise=oc.seeded_noise(1024, 4, 2, DEV))
+                else:
+                    tr.generator_regularize_step(noise=oc.seeded_noise(1024, 2, 3, DEV), pl_noise=pl_noise, z=[z_pl])
+                rec[phase] = grads(tr.discriminator if on_d else tr.generator)
             rec['stats'] = {k: tr.stats[k].clone() if torch.is_tensor(tr.stats[k]) else tr.stats[k] for k in tr.stats}
             runs[mode] = rec
-            del tr
-            torch.cuda.empty_cache()
     finally:
         hip.conv_mode = prev
+        del tr
+        torch.cuda.empty_cache()
     a, b = runs['bf16x3'], runs['f32']
-    for k in ('d_loss', 'd_r1_loss', 'g_adv_loss', 'g_path_loss', 'g_mean_path_length'):
-        assert abs(float(a['stats'][k]) - float(b['stats'][k])) <= 2e-3 * max(1.0, abs(float(b['stats'][k]))), k
-    assert rel_err(a['stats']['path_lengths'], b['stats']['path_lengths']) <= 2e-3
-    for phase, tol in (('d', 2e-3), ('r1', 6e-3), ('g', 2e-3), ('pl', 6e-3)):
+    for k in ('d_loss', 'd_r1_loss', 'g_adv_loss', 'g_path_loss'):
+        assert abs(float(a['stats'][k]) - float(b['stats'][k])) <= 1e-3 * max(1e-3 if k == 'd_r1_loss' else 1.0, abs(float(b['stats'][k]))), k
+    assert rel_err(a['stats']['path_lengths'], b['stats']['path_lengths']) <= 1e-3
+    for phase, tol in (('d', 1e-3), ('r1', 3e-3), ('g', 1e-3), ('pl', 3e-3)):
         assert a[phase].keys() == b[phase].keys()
         total = float(torch.stack(list(b[phase].values())).norm())
         for n in b[phase]:
-            if a[phase][n].numel() == 1 and n.endswith('noise.weight'):
+            if n.endswith('noise.weight'):
                 continue            # cancelling scalar sums: compared as a group in step_checks
             ref = float(b[phase][n])
-            assert abs(float(a[phase][n]) - ref) <= tol * max(ref, 1e-4 * total), (phase, n, float(a[phase][n]), ref)
+            assert abs(float(a[phase][n]) - ref) <= tol * max(ref, 1e-3 * total), (phase, n, float(a[phase][n]), ref)
 
 
 def test_split_fc_gpu():
