@@ -18,6 +18,7 @@ from torch.nn import functional as F
 
 import os
 _FUSE_EPILOGUE = os.environ.get('GANCONTROL_FUSE_EPILOGUE', '1') != '0'   # debugging knob: 0 = convolution and activation as two launches
+_FORK_TORGB = os.environ.get('GANCONTROL_FORK_TORGB', '1') != '0'         # debugging knob: 0 = autograd sums the two gradients of a StyledConv output
 from .op import _backend
 from .op import (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, upfirdn2d_bias_act, conv2d_gradfix, modulated_conv2d,
                  modulated_conv2d_act)
@@ -379,12 +380,13 @@ class Generator(nn.Module):
         lat = latent.unbind(1)
         out = self.conv1(out, lat[0], noise=noise[0])
         # every StyledConv output feeds ToRGB and the next up-sampling layer: ToRGB forks it (see ToRGB.forward)
-        skip, out = self.to_rgb1(out, lat[1], fork=True)
+        rgb = (lambda m, x, w, sk: m(x, w, sk, fork=True)) if _FORK_TORGB else (lambda m, x, w, sk: (m(x, w, sk), x))
+        skip, out = rgb(self.to_rgb1, out, lat[1], None)
         i = 1
         for up_conv, conv, n1, n2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2], self.to_rgbs):
             out = up_conv(out, lat[i], noise=n1)
             out = conv(out, lat[i + 1], noise=n2)
-            skip, out = to_rgb(out, lat[i + 2], skip, fork=True)
+            skip, out = rgb(to_rgb, out, lat[i + 2], skip)
             i += 2
         image = skip
         if return_grad:
