@@ -85,9 +85,13 @@ def none_grad_names(generator, discriminator, latent_size=512, img_channels=3, s
 
 
 class GeneratorTrainer:
-    def __init__(self, config, device='cuda', seed=0, fused_adam=None, fuse_d_pair=True):
+    def __init__(self, config, device='cuda', seed=0, fused_adam=None, fuse_d_pair=True, loss_models=None):
+        """loss_models: {config name ('embedding_loss', 'orientation_loss', ...): losses.LossModelClass} -- the attribute /
+        contrastive losses of the controllable generator step (generator_trainer.py:407-547), used when ``model_config.vanilla``
+        is false.  Their pretrained predictors are external; without loss_models the step is the adversarial one."""
         self.config = config
         self.fuse_d_pair = fuse_d_pair
+        self.loss_models = dict(loss_models or {})
         self.model_config = config['model_config']
         self.training_config = config['training_config']
         self.device = torch.device(device)
@@ -99,11 +103,19 @@ class GeneratorTrainer:
         self.local_batch = tc['batch'] // self.world
         # the reference chunks the global batch into mini-batches on ONE process; here each rank
         # takes its shard of every mini-batch
-        if tc['mini_batch'] % self.world != 0:
+        if tc['mini_batch'] % self.world != 0 and not self.loss_models:
             raise ValueError('mini_batch %d is not divisible by the world size %d' % (tc['mini_batch'], self.world))
-        self.local_mini_batch = tc['mini_batch'] // self.world
+        self.local_mini_batch = tc['mini_batch'] // self.world if not self.loss_models else min(tc['mini_batch'], self.local_batch)
         if self.local_mini_batch >= 4 and self.local_mini_batch % 4 != 0:
             raise ValueError('per-GPU mini-batch must be a multiple of 4 (minibatch-stddev groups, gan_model.py:1005-1011)')
+        self.batch_utils = None
+        if self.loss_models and not self.model_config.get('vanilla', True):
+            # the same / not-same pairs are positions inside ONE mini-batch (mini_batch_multi_split_utils.py:64-69): every rank must
+            # run whole mini-batches (last row)
+            if self.local_mini_batch != tc['mini_batch']:
+                raise ValueError('attribute losses need whole mini-batches per rank: batch / world must be a multiple of mini_batch')
+            from ..utils.mini_batch_utils import MiniBatchUtils
+            self.batch_utils = MiniBatchUtils(tc['mini_batch'], tc['sub_groups_dict'], total_batch=tc['batch'], latent_size=self.model_config['latent_size'])
         self.gen = torch.Generator(device=self.device)
         self.gen.manual_seed(seed * 1000 + self.rank)
         torch.manual_seed(seed)          # identical initial weights on every rank
@@ -290,8 +302,12 @@ class GeneratorTrainer:
         self.stats['g_adv_loss'] = 0
         self.generator.zero_grad(set_to_none=True)
         n = len(mini_noise_inputs)
+        for name in (self.loss_models if self.batch_utils is not None else ()):
+            self.stats['g_' + name] = 0
         for k, z in enumerate(mini_noise_inputs):
             self.g_reducer.begin(sync=(k == n - 1), phase='g')
+            if self.batch_utils is not None:
+                z = self.batch_utils.re_arrange_z([t.clone() for t in z], k)           # generator_trainer.py:412-415
             fake_img, _ = self.generator(z, noise=noise)
             if self.training_config['augment']['enabled']:                       # generator_trainer.py:421-424
                 fake_for_d, _ = augment(fake_img, self.ada.p)
@@ -300,10 +316,27 @@ class GeneratorTrainer:
             fake_pred, _ = self.discriminator(fake_for_d)
             g_loss = self.g_nonsaturating_loss(fake_pred) / n
             self.stats['g_adv_loss'] = self.stats['g_adv_loss'] + g_loss.detach()
+            if self.batch_utils is not None:
+                g_loss = g_loss + self.attribute_losses(fake_img, n)                    # calc_id_losses + calc_pose_losses :432-435
             g_loss.backward()
         self.g_reducer.finish()
         self._fill_missing_grads(self.generator, ())
         self.g_optim.step()
+
+    def attribute_losses(self, fake_img, n_mini_batches):
+        """Sum over the enabled predictor losses of weight * (pull the same-attribute pairs together + push the rest apart)
+        (calc_id_losses / calc_pose_losses, generator_trainer.py:438-547: the same three lines per loss)."""
+        total = 0
+        for name, model in self.loss_models.items():
+            cfg = self.training_config[name]
+            if not cfg.get('enabled', True):
+                continue
+            feats = model.calc_features(fake_img)
+            same, other = self.batch_utils.extract_same_not_same_from_list(feats, cfg['same_group_name'])
+            loss = model.calc_mini_batch_loss(last_layer_same_features=same, last_layer_not_same_features=other) / n_mini_batches
+            self.stats['g_' + name] = self.stats['g_' + name] + loss.detach()
+            total = total + loss
+        return total
 
     def generator_regularize_step(self, noise=None, pl_noise=None, z=None):
         tc = self.training_config

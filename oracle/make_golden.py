@@ -628,6 +628,63 @@ def golden_controller():
     print('controller ok')
 
 
+def golden_losses():
+    """Same / not-same hinge losses and the mini-batch re-arrangement, from the reference's own LossModelClass (no_model=True:
+    the loss on given features, loss_model.py:18-38, 121-199) and MiniBatchUtils (mini_batch_multi_split_utils.py:55-87)."""
+    import json
+    from oracle import losses as olosses
+    from gan_control.utils.mini_batch_multi_split_utils import MiniBatchUtils
+    stubs = {n: mock.MagicMock() for n in ['gan_control.evaluation.orientation'] if n not in sys.modules}
+    with mock.patch.dict(sys.modules, stubs):
+        from gan_control.losses.loss_model import LossModelClass
+    cfg = json.load(open('/root/reference/src/gan_control/configs/ffhq.json'))['training_config']
+    groups, mini = cfg['sub_groups_dict'], cfg['mini_batch']
+    mb = MiniBatchUtils(mini, groups, total_batch=cfg['batch'])
+    gen = torch.Generator().manual_seed(404)
+    out = {}
+    # re_arrange_z: one style code and two (mixing)
+    for tag, count in (('z1', 1), ('z2', 2)):
+        z = [torch.randn(mini, 512, generator=gen) for _ in range(count)]
+        ref = mb.re_arrange_z([t.clone() for t in z], 0)
+        ora = olosses.re_arrange_z(z, groups)
+        for a, b in zip(ora, ref):
+            assert torch.equal(a, b), 're_arrange_z'
+        for i in range(count):
+            out[f'{tag}/in{i}'], out[f'{tag}/out{i}'] = z[i], ref[i]
+    # the hinge itself: three criteria, intermediate levels switched on for one of them
+    cases = {'embedding_loss': [(mini, 8, 6, 6), (mini, 4, 3, 3), (mini, 24)], 'expression_loss': [(mini, 6, 5, 5), (mini, 3, 10)], 'age_loss': [(mini, 101)]}
+    for name, shapes in cases.items():
+        lc = dict(cfg[name])
+        lc['intermediate_layers_weights'] = [0.5, 0.0, 0.25, 1.0][:len(shapes) - 1]
+        lc['lower_thres'], lc['upper_thres'] = list(lc['lower_thres'])[:len(shapes) - 1], list(lc['upper_thres'])[:len(shapes) - 1]
+        lc['focus_on_list'] = (['not_same_as_last_layer', 'same_as_last_layer', 'not_same_as_last_layer'][:len(shapes) - 1]) + ['same_as_last_layer']
+        scale = {'embedding_loss': 0.25, 'expression_loss': 1.5, 'age_loss': 2.0}[name]
+        feats = [(torch.randn(*sh, generator=gen) * scale).requires_grad_(True) for sh in shapes]
+        loss_class = LossModelClass(lc, loss_name=name, mini_batch_size=mini, no_model=True)
+        same, other = mb.extract_same_not_same_from_list(feats, lc['same_group_name'])
+        ref = loss_class.calc_mini_batch_loss(last_layer_same_features=same, last_layer_not_same_features=other)
+        grads = autograd.grad(ref, feats, allow_unused=True)
+        so, oo = olosses.split_same_not_same([f.detach() for f in feats], groups, lc['same_group_name'], mini)
+        close(olosses.hinge_pair_loss(so, oo, lc, name), ref, 1e-6, f'hinge/{name}')
+        out[f'{name}/cfg'] = np.array(json.dumps(lc))
+        out[f'{name}/loss'] = ref.detach()
+        for i, (f, g) in enumerate(zip(feats, grads)):
+            out[f'{name}/f{i}'] = f.detach()
+            out[f'{name}/g{i}'] = torch.zeros_like(f) if g is None else g
+    # the age predictor head and the controller criterion of the phase-2 attribute_rec objective (deep_age_criterion.py:24-40)
+    from gan_control.losses.deep_expectation_age.deep_age_criterion import DeepAgeCriterion
+    crit = DeepAgeCriterion()
+    logits = torch.randn(5, 101, generator=gen) * 3
+    target = torch.rand(5, generator=gen) * 80
+    out['age_head/logits'], out['age_head/target'] = logits, target
+    out['age_head/pred'] = crit.predict(logits)
+    out['age_head/criterion'] = crit.controller_criterion(crit.predict(logits), target)
+    out['sub_groups'] = np.array(json.dumps(groups))
+    out['mini_batch'] = np.array(mini)
+    np.savez_compressed(os.path.join(GOLD, 'losses.npz'), **to_np(out))
+    print('losses ok')
+
+
 def golden_configs():
     """The hot-path fields of the three shipped training configurations (configs/ffhq.json:5-84, metfaces.json, afhq.json:
     numbers and switches, no code) plus what the reference's MiniBatchUtils.get_fc_config (mini_batch_multi_split_utils.py:
@@ -659,7 +716,7 @@ def main():
             'networks': golden_networks, 'step': golden_step,
             # the BASELINE resolutions: ~15 min and ~40 GiB on 8 cores (1024x1024 at batch 4 does not fit this container's 64 GiB)
             'step_512': lambda: golden_step(512, 4, 'step_512'), 'step_1024': lambda: golden_step(1024, 2, 'step_1024'),
-            'augment': golden_augment, 'fid': golden_fid, 'controller': golden_controller, 'configs': golden_configs}
+            'augment': golden_augment, 'fid': golden_fid, 'controller': golden_controller, 'configs': golden_configs, 'losses': golden_losses}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()
     total = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))

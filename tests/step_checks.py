@@ -31,7 +31,7 @@ def step_inputs(s, size, batch):
     return {'real': real, 'z_d': z_d, 'z_g': z_g, 'z_pl': z_pl, 'pl_noise': pl_noise}
 
 
-def _check_grads(module, s, prefix, ref_total, tol):
+def _check_grads(module, s, prefix, ref_total, tol, param_tol=None):
     """Gradients of one backward pass against the reference's: the set of parameters that have one, the global norm and the
     norm of every single parameter's gradient (``<prefix>/names``, ``<prefix>/vals``)."""
     got = {n: p.grad for n, p in module.named_parameters() if p.grad is not None}
@@ -45,6 +45,7 @@ def _check_grads(module, s, prefix, ref_total, tol):
     # A parameter whose gradient is below 0.1 % of the pass's norm is bounded absolutely: such gradients (e.g. what reaches D's
     # activation biases under R1 only through the minibatch-stddev channel, ~1e-4 of the total) sit below the rounding noise of the pass.
     floor = 1e-3 * ref_total
+    param_tol = tol if param_tol is None else param_tol
     worst = 0.0
     scalars = []
     for n, ref in zip(names, refs):
@@ -56,16 +57,16 @@ def _check_grads(module, s, prefix, ref_total, tol):
             continue
         err = abs(val - ref) / max(ref, floor)
         worst = max(worst, err)
-        assert err <= tol, (prefix, n, val, ref)
+        assert err <= param_tol, (prefix, n, val, ref)
     if scalars:
         a, b = torch.tensor(scalars, dtype=torch.float64).unbind(1)
         err = float((a - b).norm() / b.norm().clamp_min(floor))
         worst = max(worst, err)
-        assert err <= tol, (prefix, 'scalar parameters', scalars)
+        assert err <= param_tol, (prefix, 'scalar parameters', scalars)
     return worst
 
 
-def check_step(device, tol=2e-3, name='step'):
+def check_step(device, tol=2e-3, name='step', param_tol=None):
     """One full iteration (D step, R1, G step, path-length, EMA) of the product trainer against the iteration captured from
     the reference.  ``name`` selects the fixture: 'step' (32x32, batch 4), 'step_512' (512x512, batch 4), 'step_1024'
     (1024x1024, batch 2).
@@ -79,7 +80,10 @@ def check_step(device, tol=2e-3, name='step'):
     Tolerances: `tol` for the plain backward passes, 3 * tol for the two double-backward passes: in fp64 the product reproduces the
     oracle's double-backward gradients to 1e-15, in fp32 ONE leaky-ReLU whose pre-activation is within rounding of zero (expected
     ~0.4 per million activations) takes the other slope and moves a whole layer's second-order gradient by ~5e-4
-    (tools/pl_error_probe.py)."""
+    (tools/pl_error_probe.py).  ``param_tol`` (default: tol) bounds the per-parameter gradient norms separately from the losses and
+    the global norms: a single parameter's gradient is a sum over batch x pixels that cancels to ~1/700 of its terms on the worst
+    parameter, which amplifies the arithmetic's rounding error (fp32: 3e-7 -> 2e-4 measured; split-bf16: 5e-6 -> 4e-3 measured)."""
+    pt = param_tol if param_tol is not None else tol
     from gan_control_amd.trainers.utils import requires_grad, accumulate
     s = load_golden(name)
     size, batch = [int(v) for v in s['cfg']]
@@ -97,7 +101,7 @@ def check_step(device, tol=2e-3, name='step'):
     worst = {}
     requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
     tr.discriminator_step([[t('z_d')]], [real], noise=noise(batch, 0))
-    worst['d'] = _check_grads(tr.discriminator, s, 'gradnorm/d', float(s['stat/d_grad_norm']), tol)
+    worst['d'] = _check_grads(tr.discriminator, s, 'gradnorm/d', float(s['stat/d_grad_norm']), tol, pt)
     tr.discriminator_regularize_step([real])
     requires_grad(tr.generator, True); requires_grad(tr.discriminator, False)
     tr.generator_step([[t('z_g')]], noise=noise(batch, 1))
@@ -115,18 +119,18 @@ def check_step(device, tol=2e-3, name='step'):
     reset()
     requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
     tr.discriminator_regularize_step([real])
-    worst['r1'] = _check_grads(tr.discriminator, s, 'iso/r1', None, 3 * tol)
+    worst['r1'] = _check_grads(tr.discriminator, s, 'iso/r1', None, 3 * tol, 3 * pt)
     ref = float(s['iso/stat/d_r1_loss'])
     assert abs(float(tr.stats['d_r1_loss']) - ref) <= tol * max(1e-3, abs(ref)), ('iso d_r1_loss', float(tr.stats['d_r1_loss']), ref)
     reset()
     requires_grad(tr.generator, True); requires_grad(tr.discriminator, False)
     tr.generator_step([[t('z_g')]], noise=noise(batch, 1))
-    worst['g'] = _check_grads(tr.generator, s, 'iso/g', None, tol)
+    worst['g'] = _check_grads(tr.generator, s, 'iso/g', None, tol, pt)
     ref = float(s['iso/stat/g_adv_loss'])
     assert abs(float(tr.stats['g_adv_loss']) - ref) <= tol * max(1.0, abs(ref)), ('iso g_adv_loss', float(tr.stats['g_adv_loss']), ref)
     reset()
     tr.generator_regularize_step(noise=noise(batch // 2, 2), pl_noise=t('pl_noise'), z=[t('z_pl')])
-    worst['pl'] = _check_grads(tr.generator, s, 'iso/pl', None, 3 * tol)
+    worst['pl'] = _check_grads(tr.generator, s, 'iso/pl', None, 3 * tol, 3 * pt)
     ref = float(s['iso/stat/g_path_loss'])
     assert abs(float(tr.stats['g_path_loss']) - ref) <= tol * max(1.0, abs(ref)), ('iso g_path_loss', float(tr.stats['g_path_loss']), ref)
     assert rel_err(tr.stats['path_lengths'], torch.from_numpy(s['iso/stat/path_lengths'])) <= tol

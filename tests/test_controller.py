@@ -87,6 +87,9 @@ def test_re_arrange_latent_and_loss_choices(emu_backend):
     mse = ControllerTrainer(cfg, CHUNK, device='cpu', seed=0)
     assert isinstance(mse.rec_loss, torch.nn.MSELoss)
     cfg['training_config']['losses'] = ['latent_rec', 'attribute_rec']
+    with pytest.raises(ValueError, match='attribute_rec'):
+        ControllerTrainer(cfg, CHUNK, device='cpu')          # needs a generator and the attribute predictor
+    cfg['training_config']['losses'] = ['latent_adv']
     with pytest.raises(NotImplementedError):
         ControllerTrainer(cfg, CHUNK, device='cpu')
     with pytest.raises(RuntimeError):
@@ -136,3 +139,66 @@ def test_loader_feeds_the_step(emu_backend):
     tr = ControllerTrainer(cfg, (4, 12), device='cpu', seed=1)
     epochs = [float(np.mean([tr.controller_update(batch) for batch in loader])) for _ in range(40)]
     assert epochs[-1] < 0.8 * epochs[0]
+
+
+class _StubAge(torch.nn.Module):
+    """Stands in for the pretrained DEX age network: image -> [101 age logits]."""
+
+    def __init__(self):
+        super().__init__()
+        self.register_buffer('proj', torch.randn(3 * 16, 101, generator=torch.Generator().manual_seed(2)) * 0.5)
+
+    def forward(self, img):
+        return [torch.nn.functional.adaptive_avg_pool2d(img, 4).flatten(1) @ self.proj]
+
+
+def check_attribute_rec(device, tol):
+    """attribute_rec (controller_trainer.py:231-239): product (controller -> splice -> frozen HIP generator -> predictor -> criterion)
+    against the same composition built from the oracle's functional networks; loss value and every controller gradient."""
+    import op_checks as oc
+    from gan_control_amd.losses import LossModelClass
+    from oracle import networks
+    size, chunk, batch = 32, (320, 384), 3
+    g, _ = oc.build_models(size, device)
+    g_sd = {k: v.detach().cpu().clone() for k, v in g.state_dict().items()}
+    cfg = default_controller_config(1, 64, 3, batch=batch)
+    cfg['training_config'].update(losses=['latent_rec', 'attribute_rec'], attribute_rec_w=0.7)
+    stub = _StubAge().to(device)
+    lc = {'lower_thres': [], 'upper_thres': [], 'last_lower_thres': 0.4, 'last_upper_thres': 1.4, 'intermediate_layers_weights': [],
+          'last_layer_weight': 0.15, 'focus_on_list': ['same_as_last_layer']}
+    tr = ControllerTrainer(cfg, chunk, device=device, generator=g, seed=3, loss_class=LossModelClass(lc, 'age_loss', skeleton_model=stub))
+    gen = torch.Generator().manual_seed(12)
+    controls = torch.rand(batch, 1, generator=gen) * 60 + 10
+    w = torch.randn(batch, 512, generator=gen)
+    # the generator draws fresh noise maps inside: fix the stream on both sides by seeding, and use stored noise on the oracle side
+    ws = [tr.fc_controller.fc_stack[i].weight.detach().cpu().double().requires_grad_(True) for i in range(3)]
+    bs = [tr.fc_controller.fc_stack[i].bias.detach().cpu().double().requires_grad_(True) for i in range(3)]
+    noise = oc.seeded_noise(size, batch, 77)
+    # product, with the same explicit noise maps (Generator.forward's `noise` argument)
+    orig = tr.generator.forward
+    tr.generator.forward = lambda styles, **kw: orig(styles, noise=[n.to(device) for n in noise], **kw)
+    loss = tr.controller_update((controls, w))
+    pred = octl.fc_stack_forward(controls.double(), ws, bs, 0.01)
+    lat = w.double().clone()
+    lat[:, chunk[0]:chunk[1]] = pred
+    img, _ = networks.generator_forward({k: v.double() for k, v in g_sd.items()}, [lat], size, noise=[n.double() for n in noise], input_is_latent=True)
+    logits = torch.nn.functional.adaptive_avg_pool2d(img, 4).flatten(1) @ stub.proj.cpu().double()
+    age = (torch.softmax(logits, -1) * torch.arange(101, dtype=torch.float64)).sum(-1)
+    ref = (pred - w.double()[:, chunk[0]:chunk[1]]).abs().mean() + 0.7 * torch.nn.functional.mse_loss(age, controls.double())
+    assert abs(loss - float(ref)) <= tol * abs(float(ref)), (loss, float(ref))
+    assert abs(tr.evaluation_dict['attribute_loss'] - float(torch.nn.functional.mse_loss(age, controls.double()))) <= tol * float(ref)
+    grads = torch.autograd.grad(ref, ws + bs)
+    # the product already stepped: compare the gradients it left in .grad
+    for i in range(3):
+        assert rel_err(tr.fc_controller.fc_stack[i].weight.grad, grads[i]) <= tol, i
+        assert rel_err(tr.fc_controller.fc_stack[i].bias.grad, grads[3 + i]) <= tol, i
+    assert all(p.grad is None for p in tr.generator.parameters()), 'the generator is frozen'
+
+
+def test_attribute_rec_emulated(emu_backend):
+    check_attribute_rec('cpu', 2e-3)
+
+
+@pytest.mark.gpu
+def test_attribute_rec_hip():
+    check_attribute_rec('cuda', 2e-3)

@@ -541,7 +541,7 @@ def test_network_golden_bf16x3(size, bf16x3_mode):
 
 def test_step_golden_bf16x3(bf16x3_mode):
     import step_checks
-    step_checks.check_step(DEV)
+    step_checks.check_step(DEV, param_tol=1e-2)
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
@@ -554,9 +554,9 @@ def test_step_golden_baseline_sizes(name, mode):
     hip, _ = _be()
     prev, hip.conv_mode = hip.conv_mode, mode
     try:
-        # split-bf16 keeps ~16 mantissa bits per product: gradients (sums over batch x pixels with cancellation, through ~30 layers)
-        # come out at up to ~2e-3 of the fp32 result, so that mode gets twice the tolerance
-        step_checks.check_step(DEV, tol=2e-3 if mode == 'f32' else 4e-3, name=name)
+        # losses and global gradient norms: 2e-3 in both modes.  Per-parameter gradient norms: 2e-3 in exact fp32, 1e-2 in split-bf16
+        # (16 mantissa bits per product; the worst parameter's gradient cancels to ~1/700 of its terms: measured up to 4.3e-3)
+        step_checks.check_step(DEV, tol=2e-3, name=name, param_tol=None if mode == 'f32' else 1e-2)
     finally:
         hip.conv_mode = prev
         torch.cuda.empty_cache()
