@@ -403,6 +403,88 @@ __global__ __launch_bounds__(256) void generic_kernel(
     }
 }
 
+// Large square filters with up = 2 or down = 2 (the 12 x 12 sym6 anti-aliasing passes of the ADA warp, non_leaking.py:321-359,
+// and their adjoints): a 256-thread workgroup makes a 64 x 16 output tile of one plane from an input patch staged ONCE in LDS
+// (zero-filled outside the image), taps in LDS in multiplication order; a lane owns 4 consecutive outputs of a row and walks
+// only the taps that meet a non-zero sample of the zero-stuffed input (K*K/UP^2 of them).  Replaces generic_kernel's one
+// output per lane with up to K*K global reads each.
+template <int K, int UP, int DOWN>
+struct FirKCfg {
+    static constexpr int TW = 64, TH = 16;
+    static constexpr int PW = ((TW - 1) * DOWN + K - 1) / UP + 2, PH = ((TH - 1) * DOWN + K - 1) / UP + 2;
+    static constexpr int PITCH = PW | 1;            // odd pitch: the stride-DOWN column walks of a wave spread over the banks
+};
+
+template <int K, int UP, int DOWN>
+__global__ __launch_bounds__(256) void firK_tile_kernel(
+    const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
+    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip) {
+    using C = FirKCfg<K, UP, DOWN>;
+    __shared__ float patch[C::PH * C::PITCH];
+    __shared__ float T[K * K];
+    const int tid = threadIdx.x;
+    const int ox0 = blockIdx.x * C::TW, oy0 = blockIdx.y * C::TH;
+    const size_t plane = blockIdx.z;
+    const float* xp = x + plane * (size_t)in_h * in_w;
+    float* yp = y + plane * (size_t)out_h * out_w;
+    for (int i = tid; i < K * K; i += 256) T[i] = flip ? taps[K * K - 1 - i] : taps[i];
+    // zero-stuffed coordinate of tap (0, 0) at the tile origin, and the input sample at / below it
+    const int ux_base = ox0 * DOWN - pad_x0, uy_base = oy0 * DOWN - pad_y0;
+    const int ixb = gc::floor_div(ux_base, UP), iyb = gc::floor_div(uy_base, UP);
+    for (int i = tid; i < C::PH * C::PW; i += 256) {
+        const int r = i / C::PW, c = i - r * C::PW;
+        const int iy = iyb + r, ix = ixb + c;
+        patch[r * C::PITCH + c] = (iy >= 0 && iy < in_h && ix >= 0 && ix < in_w) ? xp[(size_t)iy * in_w + ix] : 0.f;
+    }
+    __syncthreads();
+    const int ty = tid >> 4, tx = (tid & 15) * 4;
+    const int oy = oy0 + ty;
+    if (oy >= out_h) return;
+    const int uy0 = oy * DOWN - pad_y0;
+    const int a0 = gc::pos_mod(-uy0, UP);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    int b0[4], cx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ux0 = (ox0 + tx + i) * DOWN - pad_x0;
+        b0[i] = gc::pos_mod(-ux0, UP);
+        cx[i] = (ux0 + b0[i] - ixb * UP) / UP;          // patch column of this output's first live tap
+    }
+    constexpr int NA = (K + UP - 1) / UP;
+#pragma unroll 2
+    for (int aa = 0; aa < NA; ++aa) {
+        const int a = a0 + aa * UP;
+        if (a >= K) break;
+        const float* prow = patch + ((uy0 + a - iyb * UP) / UP) * C::PITCH;
+        const float* trow = T + a * K;
+#pragma unroll
+        for (int bb = 0; bb < NA; ++bb) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int b = b0[i] + bb * UP;
+                if (UP == 1 || b < K) acc[i] = fmaf(trow[b], prow[cx[i] + bb], acc[i]);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (ox0 + tx + i < out_w) yp[(size_t)oy * out_w + ox0 + tx + i] = acc[i];
+}
+
+template <int K>
+int launch_firK(const float* x, const float* taps, float* y, int planes, int in_h, int in_w, int out_h, int out_w,
+                int up, int down, int pad_x0, int pad_y0, int flip, hipStream_t s) {
+    using C = FirKCfg<K, 1, 1>;
+    dim3 grid(gc::ceil_div(out_w, C::TW), gc::ceil_div(out_h, C::TH), planes);
+    if (up == 2 && down == 1)
+        hipLaunchKernelGGL((firK_tile_kernel<K, 2, 1>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip);
+    else if (up == 1 && down == 2)
+        hipLaunchKernelGGL((firK_tile_kernel<K, 1, 2>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip);
+    else
+        hipLaunchKernelGGL((firK_tile_kernel<K, 1, 1>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip);
+    return gc::check_launch("gc_upfirdn2d_f32(firK_tile)");
+}
+
 }  // namespace
 
 namespace {
@@ -458,6 +540,9 @@ int upfirdn2d_impl(const float* x, const float* taps, float* y,
 #undef GC_UP2
         return gc::check_launch("gc_upfirdn2d_f32(fir44_up2)");
     }
+    // 12 x 12 taps (sym6 x sym6) with (up, down) in {(2, 1), (1, 2), (1, 1)} on planes worth tiling: the ADA anti-aliasing passes
+    if (kh == 12 && kw == 12 && up_x == up_y && down_x == down_y && up_x * down_x <= 2 && planes <= 65535 && out_w >= 32 && out_h >= 8)
+        return launch_firK<12>(x, taps, y, planes, in_h, in_w, out_h, out_w, up_x, down_x, pad_x0, pad_y0, flip_taps, s);
     if (kh * kw > MAX_GENERIC_TAPS) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_f32: %d x %d taps exceed %d", kh, kw, MAX_GENERIC_TAPS);
     const size_t total = (size_t)planes * out_h * out_w;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 256 * 16);

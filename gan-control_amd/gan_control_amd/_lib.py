@@ -56,6 +56,8 @@ SIGNATURES = {
     'gc_conv2d_wgrad_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_bf16x3_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_wgrad_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'gc_affine_warp_bilinear_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 7 + [_vp]),
+    'gc_reflect_pad_f32': (_i32, [_vp, _vp] + [_i32] * 8 + [_vp]),
     'gc_weight_layout_f32': (_i32, [_vp, _vp, _i32, _i32, _i32, ctypes.POINTER(_i64 * 3), ctypes.POINTER(_i64 * 3), _i32, _f32, _vp]),
 }
 

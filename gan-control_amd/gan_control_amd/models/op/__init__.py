@@ -9,6 +9,7 @@ from .fused_act import FusedLeakyReLU, fused_leaky_relu, fused_noise_bias_act
 from .upfirdn2d import upfirdn2d, upfirdn2d_bias_act
 from . import conv2d_gradfix
 from .modulated_conv import modulated_conv2d, modulated_conv2d_act, demod_coefficients
+from .warp import affine_warp_bilinear, reflect_pad
 
 __all__ = ['FusedLeakyReLU', 'fused_leaky_relu', 'fused_noise_bias_act', 'upfirdn2d', 'upfirdn2d_bias_act', 'conv2d_gradfix',
-           'modulated_conv2d', 'modulated_conv2d_act', 'demod_coefficients']
+           'modulated_conv2d', 'modulated_conv2d_act', 'demod_coefficients', 'affine_warp_bilinear', 'reflect_pad']

@@ -279,6 +279,45 @@ class HipBackend:
         _lib.check(rc, 'gc_channel_sum_f32')
         return out
 
+    def affine_warp(self, x, mat, in_h, in_w, out_h, out_w, adjoint):
+        """Bilinear affine resampling (adjoint=False: [B,C,in_h,in_w] -> [B,C,out_h,out_w]) or its transpose; see gc_affine_warp_bilinear_f32."""
+        dev = _lib.require_cuda_f32(x, mat)
+        b, c = x.shape[0], x.shape[1]
+        if tuple(mat.shape) != (b, 6):
+            raise RuntimeError('affine_warp: mat must be [batch, 6], got %s' % (tuple(mat.shape),))
+        want = (out_h, out_w) if adjoint else (in_h, in_w)
+        if tuple(x.shape[2:]) != want:
+            raise RuntimeError('affine_warp: input plane %s, expected %s' % (tuple(x.shape[2:]), want))
+        y = torch.empty((b, c) + ((in_h, in_w) if adjoint else (out_h, out_w)), dtype=x.dtype, device=dev)
+        if y.numel() == 0:
+            return y
+        lib = _lib.load()
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_affine_warp_bilinear_f32(_lib.ptr(x), _lib.ptr(mat), _lib.ptr(y), b, c, in_h, in_w, out_h, out_w, int(bool(adjoint)), _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_affine_warp_bilinear_f32')
+        return y
+
+    def reflect_pad(self, x, pads, adjoint, in_hw):
+        """F.pad(mode='reflect') of [B,C,in_h,in_w] by (left, right, top, bottom), or its adjoint (input: the padded-size gradient)."""
+        dev = _lib.require_cuda_f32(x)
+        left, right, top, bottom = pads
+        h, w = in_hw
+        b, c = x.shape[0], x.shape[1]
+        y = torch.empty((b, c, h, w) if adjoint else (b, c, h + top + bottom, w + left + right), dtype=x.dtype, device=dev)
+        lib = _lib.load()
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_reflect_pad_f32(_lib.ptr(x), _lib.ptr(y), b * c, h, w, left, right, top, bottom, int(bool(adjoint)), _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_reflect_pad_f32')
+        return y
+
     @staticmethod
     def _desc(x, n_out, geom):
         b, k, h, w = x.shape

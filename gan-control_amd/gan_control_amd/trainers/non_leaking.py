@@ -6,18 +6,19 @@ Mirrors the call surface of the reference's src/gan_control/trainers/non_leaking
 calls when ``training_config.augment.enabled`` (generator_trainer.py:421-424, 651-653).  The reference file
 imports ``upfirdn2d`` from a package it does not ship (non_leaking.py:6); here the two 12x12 sym6
 anti-aliasing passes (x2 up-sampling before, x2 down-sampling after the warp) run on the HIP upfirdn2d
-kernel (generic path), with first- and second-order gradients.
+kernel (LDS-tiled 12 x 12 variant), with first- and second-order gradients.
 
 Transform matrices are sampled on the host with the SAME order of random draws as the reference, so a
-given torch seed yields the same augmentation (pinned by tests/golden/augment.npz).  The bilinear warp
-itself is still ATen's grid_sample (plumbing for this round).
+given torch seed yields the same augmentation (pinned by tests/golden/augment.npz).  The reflect padding and the
+bilinear warp run on HIP kernels too (models/op/warp.py): the reference's sampling grid is an affine function of the
+output pixel index, folded on the host into one 2 x 3 matrix per sample (``warp_matrix``).
 """
 import math
 
 import torch
 from torch.nn import functional as F
 
-from ..models.op import upfirdn2d
+from ..models.op import upfirdn2d, affine_warp_bilinear, reflect_pad
 
 # Daubechies least-asymmetric ("symlet") 6 low-pass filter, 12 taps -- the ADA paper's anti-aliasing kernel
 SYM6 = (
@@ -158,6 +159,24 @@ def affine_grid(grid, mat):
     return (grid.reshape(n, h * w, 3) @ mat.transpose(1, 2)).reshape(n, h, w, 2)
 
 
+def warp_matrix(g_inv, h2, w2, x_range, y_range, scale, shift):
+    """The reference's sampling grid (make_grid -> affine_grid -> scale / shift, then grid_sample's un-normalisation with
+    align_corners=False; non_leaking.py:244-263, 338-357) is an affine function of the output pixel index (ox, oy).  Returns it as
+    [B, 6] rows (m0, m1, m2, m3, m4, m5): sx = m0*ox + m1*oy + m2, sy = m3*ox + m4*oy + m5 in input pixel units, in float64 on the host."""
+    a = g_inv[:, :2, :].double()
+    (x0, x1), (y0, y1) = x_range, y_range
+    dx, dy = (x1 - x0) / (w2 - 1), (y1 - y0) / (h2 - 1)
+    half = torch.tensor([w2 / 2.0, h2 / 2.0], dtype=torch.float64)
+    k = torch.tensor(scale, dtype=torch.float64) * half                       # normalised grid -> pixels, per axis
+    off = (torch.tensor(shift, dtype=torch.float64)) * half + torch.tensor([(w2 - 1) / 2.0, (h2 - 1) / 2.0], dtype=torch.float64)
+    m = torch.empty(a.shape[0], 6, dtype=torch.float64)
+    for r in range(2):                                                         # r = 0: sx from row 0 of inverse(G); r = 1: sy
+        m[:, 3 * r + 0] = k[r] * a[:, r, 0] * dx
+        m[:, 3 * r + 1] = k[r] * a[:, r, 1] * dy
+        m[:, 3 * r + 2] = k[r] * (a[:, r, 0] * x0 + a[:, r, 1] * y0 + a[:, r, 2]) + off[r]
+    return m.float()
+
+
 def get_padding(G, height, width):
     """Reflect-padding (in pixels) needed so that the warped image never samples outside; reference :266-285."""
     corners = torch.tensor([(-1.0, -1, 1), (-1, 1, 1), (1, -1, 1), (1, 1, 1)]).t()
@@ -174,10 +193,10 @@ def try_sample_affine_and_pad(img, p, pad_k, G=None):
         G_try = sample_affine(p, batch, height, width) if G is None else G
         pad_x1, pad_x2, pad_y1, pad_y2 = get_padding(torch.inverse(G_try), height, width)
         try:
-            img_pad = F.pad(img, (pad_x1 + pad_k, pad_x2 + pad_k, pad_y1 + pad_k, pad_y2 + pad_k), mode='reflect')
-        except RuntimeError:
+            img_pad = reflect_pad(img, (pad_x1 + pad_k, pad_x2 + pad_k, pad_y1 + pad_k, pad_y2 + pad_k))
+        except ValueError as e:
             if G is not None:
-                raise
+                raise RuntimeError(str(e)) from e
             continue            # padding larger than the image: draw again (reference :288-313)
         return img_pad, G_try, (pad_x1, pad_x2, pad_y1, pad_y2)
 
@@ -194,12 +213,10 @@ def random_apply_affine(img, p, G=None, antialiasing_kernel=SYM6):
     h_p, w_p = img_pad.shape[2] - len_k + 1, img_pad.shape[3] - len_k + 1
 
     img_2x = upfirdn2d(img_pad, kernel_flip, up=2)
-    grid = make_grid(img_2x.shape, -2 * pad_x1 / w_o - 1, 2 * (w_p - pad_x1) / w_o - 1,
-                     -2 * pad_y1 / h_o - 1, 2 * (h_p - pad_y1) / h_o - 1, device=img_2x.device).to(img_2x)
-    grid = affine_grid(grid, torch.inverse(G)[:, :2, :].to(img_2x))
-    grid = grid * torch.tensor([w_o / w_p, h_o / h_p], device=grid.device) + \
-        torch.tensor([(w_o + 2 * pad_x1) / w_p - 1, (h_o + 2 * pad_y1) / h_p - 1], device=grid.device)
-    img_affine = F.grid_sample(img_2x, grid, mode='bilinear', align_corners=False, padding_mode='zeros')
+    mat = warp_matrix(torch.inverse(G), img_2x.shape[2], img_2x.shape[3], (-2 * pad_x1 / w_o - 1, 2 * (w_p - pad_x1) / w_o - 1),
+                      (-2 * pad_y1 / h_o - 1, 2 * (h_p - pad_y1) / h_o - 1), (w_o / w_p, h_o / h_p),
+                      ((w_o + 2 * pad_x1) / w_p - 1, (h_o + 2 * pad_y1) / h_p - 1))
+    img_affine = affine_warp_bilinear(img_2x, mat.to(img_2x), img_2x.shape[2], img_2x.shape[3])
     img_down = upfirdn2d(img_affine, kernel, down=2)
     end_y = img_down.shape[2] if pad_y2 + 1 == 0 else -pad_y2 - 1
     end_x = img_down.shape[3] if pad_x2 + 1 == 0 else -pad_x2 - 1

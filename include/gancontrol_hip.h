@@ -266,6 +266,25 @@ int gc_weight_layout_f32(const float* src, float* dst, int taps, int k, int n,
                          const int64_t src_stride[3], const int64_t dst_stride[3],
                          int flip_taps, float scale, gc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Image-space pieces of the ADA augmentation (random_apply_affine, non_leaking.py:316-371) besides its two FIR passes.
+ *
+ * gc_affine_warp_bilinear_f32: bilinear resampling of x [batch, channels, in_h, in_w] into y [batch, channels, out_h, out_w]
+ * under a per-sample affine map mat [batch, 6]: output pixel (ox, oy) reads the input at
+ *     sx = m0*ox + m1*oy + m2,  sy = m3*ox + m4*oy + m5        (input PIXEL coordinates, pixel centres at integers)
+ * with zeros outside -- what F.grid_sample(mode='bilinear', padding_mode='zeros', align_corners=False) computes for the grid the
+ * reference builds with make_grid / affine_grid (non_leaking.py:244-263, 338-357: an affine function of the output pixel index,
+ * which the host folds into mat).  adjoint != 0: the transposed map -- x is then the gradient of the OUTPUT
+ * [batch, channels, out_h, out_w] and y receives the gradient of the input [batch, channels, in_h, in_w] (scatter-add).
+ *
+ * gc_reflect_pad_f32: y = F.pad(x, (left, right, top, bottom), mode='reflect') on `planes` planes of in_h x in_w
+ * (non_leaking.py:288-313); adjoint != 0: x is the gradient of the padded tensor, y receives the folded-back gradient.
+ */
+int gc_affine_warp_bilinear_f32(const float* x, const float* mat, float* y, int batch, int channels,
+                                int in_h, int in_w, int out_h, int out_w, int adjoint, gc_stream_t stream);
+int gc_reflect_pad_f32(const float* x, float* y, int planes, int in_h, int in_w, int left, int right, int top, int bottom,
+                       int adjoint, gc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

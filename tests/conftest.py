@@ -163,6 +163,30 @@ class EmulatedBackend:
         torch.as_strided(dst.reshape(-1), (taps, k, n), tuple(dst_stride)).copy_(view * scale)
         return dst
 
+    def affine_warp(self, x, mat, in_h, in_w, out_h, out_w, adjoint):
+        def fwd(img):
+            ox = torch.arange(out_w, dtype=img.dtype).view(1, 1, out_w)
+            oy = torch.arange(out_h, dtype=img.dtype).view(1, out_h, 1)
+            m = mat.to(img.dtype)
+            sx = m[:, 0].view(-1, 1, 1) * ox + m[:, 1].view(-1, 1, 1) * oy + m[:, 2].view(-1, 1, 1)
+            sy = m[:, 3].view(-1, 1, 1) * ox + m[:, 4].view(-1, 1, 1) * oy + m[:, 5].view(-1, 1, 1)
+            grid = torch.stack([(2 * sx + 1) / in_w - 1, (2 * sy + 1) / in_h - 1], dim=-1)       # pixel -> normalised, align_corners=False
+            return F.grid_sample(img, grid, mode='bilinear', padding_mode='zeros', align_corners=False)
+        if not adjoint:
+            return fwd(x)
+        probe = torch.zeros(x.shape[0], x.shape[1], in_h, in_w, dtype=x.dtype, requires_grad=True)
+        with torch.enable_grad():
+            g, = torch.autograd.grad(fwd(probe), probe, x.detach())
+        return g
+
+    def reflect_pad(self, x, pads, adjoint, in_hw):
+        if not adjoint:
+            return F.pad(x, tuple(pads), mode='reflect')
+        probe = torch.zeros(x.shape[0], x.shape[1], in_hw[0], in_hw[1], dtype=x.dtype, requires_grad=True)
+        with torch.enable_grad():
+            g, = torch.autograd.grad(F.pad(probe, tuple(pads), mode='reflect'), probe, x.detach())
+        return g
+
     def conv2d(self, x, w_t, in_scale, out_scale, geom, epilogue=None):
         if in_scale is not None:
             x = x * in_scale[:, :, None, None]

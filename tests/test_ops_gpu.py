@@ -731,3 +731,74 @@ def test_bias_act_bwd_reduce_adjoint(shape, noise, self_dot):
         assert (r is None) == (o is None), name
         if r is not None:
             assert rel_err(o, r.detach()) < 1e-5, name
+
+
+@pytest.mark.parametrize('up,down', [(2, 1), (1, 2), (1, 1)])
+@pytest.mark.parametrize('shape', [(2, 3, 70, 131), (1, 3, 16, 40), (1, 2, 129, 65)])
+def test_upfirdn2d_12x12_tile_kernel(up, down, shape):
+    """The LDS-tiled 12 x 12 kernel (firK_tile_kernel: the sym6 x sym6 anti-aliasing passes of ADA and their adjoints) across tile
+    edges, pads of both signs and both tap orders, against the emulated formula in fp64."""
+    hip, emu = _be()
+    gen = torch.Generator().manual_seed(sum(shape) + 10 * up + down)
+    x = torch.randn(*shape, generator=gen)
+    k = torch.randn(12, 12, generator=gen)
+    for p0, p1 in [(0, 0), (6, 5), (7, 6), (11, 1), (-3, -3), (2, 9)]:
+        oh, ow = (shape[2] * up + p0 + p1 - 12) // down + 1, (shape[3] * up + p0 + p1 - 12) // down + 1
+        if oh < 8 or ow < 32:
+            continue
+        for flip in (True, False):
+            ref = emu.upfirdn2d(x.double(), k.double(), up, down, p0, p0, oh, ow, flip)
+            out = hip.upfirdn2d(x.to(DEV), k.to(DEV), up, down, p0, p0, oh, ow, flip)
+            assert out.shape == ref.shape
+            assert rel_err(out, ref) < 2e-6, (p0, p1, flip)
+
+
+@pytest.mark.parametrize('shape,out_hw', [((2, 3, 40, 56), (40, 56)), ((3, 3, 64, 64), (50, 70)), ((1, 1, 7, 9), (20, 5))])
+def test_affine_warp_kernel(shape, out_hw):
+    """gc_affine_warp_bilinear_f32 and its adjoint against F.grid_sample(bilinear, zeros, align_corners=False) (fp64): rotations,
+    scales and shifts that send part of the output outside the image."""
+    import math
+    hip, emu = _be()
+    gen = torch.Generator().manual_seed(sum(shape))
+    b, c, h, w = shape
+    x = torch.randn(*shape, generator=gen)
+    th = torch.rand(b, generator=gen) * 2 * math.pi
+    sc = torch.rand(b, generator=gen) + 0.5
+    mat = torch.stack([sc * torch.cos(th), -sc * torch.sin(th), torch.rand(b, generator=gen) * w * 0.5,
+                       sc * torch.sin(th), sc * torch.cos(th), torch.rand(b, generator=gen) * h * 0.5 - 3], dim=1).float()
+    ref = emu.affine_warp(x.double(), mat.double(), h, w, out_hw[0], out_hw[1], False)
+    out = hip.affine_warp(x.to(DEV), mat.to(DEV), h, w, out_hw[0], out_hw[1], False)
+    assert rel_err(out, ref) < 1e-5
+    g = torch.randn(b, c, *out_hw, generator=gen)
+    ref = emu.affine_warp(g.double(), mat.double(), h, w, out_hw[0], out_hw[1], True)
+    out = hip.affine_warp(g.to(DEV), mat.to(DEV), h, w, out_hw[0], out_hw[1], True)
+    assert rel_err(out, ref) < 1e-5
+    # autograd: the adjoint is the gradient, the forward is the gradient of the adjoint
+    from gan_control_amd.models.op import affine_warp_bilinear
+    xp = x.to(DEV).requires_grad_(True)
+    y = affine_warp_bilinear(xp, mat.to(DEV), *out_hw)
+    gp = g.to(DEV).requires_grad_(True)
+    gx, = torch.autograd.grad(y, xp, gp, create_graph=True)
+    assert rel_err(gx, ref) < 1e-5
+    v = torch.randn(*shape, generator=gen).to(DEV)
+    gg, = torch.autograd.grad((gx * v).sum(), gp)
+    assert rel_err(gg, emu.affine_warp(v.cpu().double(), mat.double(), h, w, out_hw[0], out_hw[1], False)) < 1e-5
+
+
+@pytest.mark.parametrize('shape,pads', [((2, 3, 20, 30), (5, 7, 3, 9)), ((1, 2, 8, 8), (7, 7, 7, 7)), ((3, 1, 33, 17), (0, 4, 2, 0)), ((1, 1, 5, 6), (0, 0, 0, 0))])
+def test_reflect_pad_kernel(shape, pads):
+    import torch.nn.functional as F
+    from gan_control_amd.models.op import reflect_pad
+    gen = torch.Generator().manual_seed(sum(shape) + sum(pads))
+    x = torch.randn(*shape, generator=gen)
+    xr = x.double().requires_grad_(True)
+    xp = x.to(DEV).requires_grad_(True)
+    ref = F.pad(xr, pads, mode='reflect')
+    out = reflect_pad(xp, pads)
+    assert torch.equal(out.cpu().double(), ref.detach())
+    g = torch.randn(ref.shape, generator=gen)
+    gr, = torch.autograd.grad(ref, xr, g.double())
+    gp, = torch.autograd.grad(out, xp, g.to(DEV))
+    assert rel_err(gp, gr) < 1e-6
+    with pytest.raises(ValueError):
+        reflect_pad(xp, (shape[3], 0, 0, 0))
