@@ -645,8 +645,11 @@ int gcconv::conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w,
     }
     if (rc || !split) return rc;
     fin.part = static_cast<float*>(workspace);
-    const long long per_slice = (long long)d->batch * d->out_ch * d->out_h * d->out_w;
-    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)std::min<long long>((per_slice + 255) / 256, 2048)), dim3(256), 0, s, fin, sp.slices, per_slice);
+    return launch_splitk_finish(fin, sp.slices, (long long)d->batch * d->out_ch * d->out_h * d->out_w, s);
+}
+
+int gcconv::launch_splitk_finish(const ConvArgs& fin, int slices, long long per_slice, hipStream_t s) {
+    hipLaunchKernelGGL(splitk_finish_kernel, dim3((unsigned)std::min<long long>((per_slice + 255) / 256, 2048)), dim3(256), 0, s, fin, slices, per_slice);
     return gc::check_launch("gc_conv2d_f32(split-K finish)");
 }
 

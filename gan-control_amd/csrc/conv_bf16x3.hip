@@ -39,6 +39,9 @@ struct Bf16Args {
     const uint4* wh; const uint4* wl;   // packed weights [tap][ceil(K/8)][N] units of 8 bf16 (hi / lo parts)
     int kgroups;                        // ceil(K / 8)
     int tpb, groups;                    // conv_bf16x3_kernel: pixel tiles per workgroup, workgroups per (sample, phase)
+    // grid-level split over the input channels (small planes): slice blockIdx.z covers channels [z * k_per_split, (z + 1) * k_per_split)
+    // and writes RAW partial sums to part + z * per_slice; splitk_finish_kernel (conv.hip) adds the slices and applies the epilogue
+    int k_per_split; float* part; long long per_slice;
 };
 
 // wp[t][kg][n] = 8 x bf16 of w[t][kg*8 + q][n], q = 0..7 (zero beyond K); hi and lo parts
@@ -142,6 +145,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     const int n0 = blockIdx.y * OCT, n0_blk = n0;
     const int qh = (p.out_h - phy + UP - 1) / UP, qw = (p.out_w - phx + UP - 1) / UP;
     const int tile_begin = grp * a.tpb, tile_end = min(p.tiles_x * p.tiles_y, tile_begin + a.tpb);
+    const int kz0 = a.k_per_split ? (int)blockIdx.z * a.k_per_split : 0;
+    const int kz1 = a.k_per_split ? min(p.K, kz0 + a.k_per_split) : p.K;
     if (UP > 1) {      // tpb == 1; phases other than 0 have a smaller sub-grid
         if ((tile_begin / p.tiles_x) * TPH >= qh || (tile_begin % p.tiles_x) * 32 >= qw) return;
     }
@@ -271,6 +276,22 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
                     bh[j] = *reinterpret_cast<const bf16x8*>(&uh);
                     bl[j] = *reinterpret_cast<const bf16x8*>(&ul);
                 }
+#if defined(GC_EXP) && GC_EXP == 1      // experiment: the three terms as three sweeps over the accumulators (dependent MFMAs WOC * WPX apart)
+#pragma unroll
+                for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                    for (int j = 0; j < WPX; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                    for (int j = 0; j < WPX; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                    for (int j = 0; j < WPX; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+#else
 #pragma unroll
                 for (int i = 0; i < WOC; ++i)
 #pragma unroll
@@ -279,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
                     }
+#endif
             }
         }
     };
@@ -286,7 +308,8 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     // Output through a buffer descriptor as well: lane offset = pixel (+ the hi half's 4 channels), scalar offset = channel
     // plane; channels >= N and pixels outside the plane fall beyond num_records and are dropped by the hardware.
     const unsigned oplane = (unsigned)(p.out_h * p.out_w) * 4u;
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + (size_t)b * p.N * p.out_h * p.out_w, (unsigned)p.N * oplane);
+    float* const ybase = a.k_per_split ? a.part + (size_t)blockIdx.z * a.per_slice : p.y;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(ybase + (size_t)b * p.N * p.out_h * p.out_w, (unsigned)p.N * oplane);
     // store one finished tile (demodulation + fused epilogue) and clear the accumulators for the next
     const EpilogueConsts ec = epilogue_consts(p);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + (size_t)b * p.N * p.out_h * p.out_w : p.y, p.residual ? (unsigned)p.N * oplane : 0u);
@@ -328,10 +351,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
         for (int tile = tile_begin; tile < tile_end; ++tile) finish_tile(tile);
         return;
     }
-    const int nchunks = (p.K + KCB - 1) / KCB;
+    const int nchunks = (kz1 - kz0 + KCB - 1) / KCB;
     const int items = (tile_end - tile_begin) * nchunks;
-    int tile_n = tile_begin, k0_n = 0;        // cursor of the staging side (prefetch / commit)
-    int tile_c = tile_begin, k0_c = 0;        // cursor of the compute side (MFMA / stores)
+    int tile_n = tile_begin, k0_n = kz0;      // cursor of the staging side (prefetch / commit)
+    int tile_c = tile_begin, k0_c = kz0;      // cursor of the compute side (MFMA / stores)
     prefetch(tile_n, k0_n);
     for (int k = tid; k < ((p.K + KCB - 1) / KCB) * KCB; k += 256) s_si[k] = k < p.K ? (sib ? sib[k] : 1.f) : 0.f;
     if (tid < OCT) {
@@ -341,7 +364,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
     }
     __syncthreads();
     commit(tile_n, k0_n);
-    k0_n += KCB; if (k0_n >= p.K) { k0_n = 0; ++tile_n; }
+    k0_n += KCB; if (k0_n >= kz1) { k0_n = kz0; ++tile_n; }
     __syncthreads();
     // Steady state.  Every step is unconditional, so no control-flow path reaches the loop header with staged loads
     // in flight and the compiler plants no wait inside the next prefetch; the last item is peeled below.
@@ -354,9 +377,9 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         commit(tile_n, k0_n);                               // retires the loads first: no store is outstanding yet
-        k0_n += KCB; if (k0_n >= p.K) { k0_n = 0; ++tile_n; }
-        if (k0_c + KCB >= p.K) finish_tile(tile_c);         // stores drain while the next MFMA phase runs
-        k0_c += KCB; if (k0_c >= p.K) { k0_c = 0; ++tile_c; }
+        k0_n += KCB; if (k0_n >= kz1) { k0_n = kz0; ++tile_n; }
+        if (k0_c + KCB >= kz1) finish_tile(tile_c);         // stores drain while the next MFMA phase runs
+        k0_c += KCB; if (k0_c >= kz1) { k0_c = kz0; ++tile_c; }
         __syncthreads();
     }
     mfma_phase();
@@ -1220,10 +1243,11 @@ int launch(Bf16Args a, hipStream_t s) {
         while (want > 1 && wgs / want < 2048) want >>= 1;
         a.tpb = want;
     }
+    if (a.k_per_split) a.tpb = 1;
     a.groups = gc::ceil_div(tiles, a.tpb);
     const long long gx = (long long)a.groups * UP * UP * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
-    dim3 grid((unsigned)gx, ocb);
+    dim3 grid((unsigned)gx, ocb, a.k_per_split ? gc::ceil_div(a.c.K, a.k_per_split) : 1);
     hipLaunchKernelGGL((conv_bf16x3_kernel<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>), grid, dim3(256), 0, s, a);
     return gc::check_launch("gc_conv2d_bf16x3_f32");
 }
@@ -1258,13 +1282,40 @@ bool eligible(const gc_conv_desc* d) {
     return d->pad_x >= 1 && d->pad_x <= 2;      // up = 2: phase rows start 0 or 1 floats before the boundary only for these
 }
 
+// Planes of 9 .. 32 pixels (the 16^2 / 32^2 layers, 512 channels) give the launch only B * tiles * N / 64 = 64 .. 256 workgroups, each
+// walking all 32 channel chunks one after the other with nothing to hide the load latency behind (512 -> 512 @16^2, B = 4: 88 us for
+// 4.8 GFLOP).  Splitting K over blockIdx.z fills the chip and shortens the dependent chain; slices of >= 4 chunks.
+struct SplitPlan { int slices, k_per_split; };
+SplitPlan plan_splitk_bf16(const gc_conv_desc* d) {
+    SplitPlan sp{1, 0};
+    if (d->up != 1 || d->in_ch < 128) return sp;
+    const int rows = d->down == 2 ? 4 : 8;          // tile rows the dispatcher picks (4-row tiles when the launch is small: assume the larger tile here)
+    const long long wgs = (long long)gc::ceil_div(d->out_w, 32) * gc::ceil_div(d->out_h, rows) * d->batch * gc::ceil_div(d->out_ch, 64);
+    const int want = (int)std::min<long long>(512 / std::max<long long>(wgs, 1), d->in_ch / 64);
+    if (want <= 1) return sp;
+    sp.k_per_split = gc::ceil_div(gc::ceil_div(d->in_ch, want), KCB) * KCB;
+    sp.slices = gc::ceil_div(d->in_ch, sp.k_per_split);
+    if (sp.slices <= 1) { sp.slices = 1; sp.k_per_split = 0; }
+    return sp;
+}
+
+size_t splitk_bytes(const gc_conv_desc* d) {
+    const SplitPlan sp = plan_splitk_bf16(d);
+    return sp.slices > 1 ? (size_t)sp.slices * d->batch * d->out_ch * d->out_h * d->out_w * sizeof(float) : 0;
+}
+
 }  // namespace
 
 extern "C" size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d) {
     if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
     if (!eligible(d)) return conv2d_f32_workspace(d);        // runs on the fp32 kernel: split-K partial sums (small planes) or nothing
     const size_t units = (size_t)d->kh * d->kw * ((d->in_ch + 7) / 8) * d->out_ch;
-    return 2 * units * sizeof(uint4);
+    return 2 * units * sizeof(uint4) + splitk_bytes(d);      // the split weights (gc_conv2d_fused_bf16x3_f32 packs them here), then the K slices
+}
+
+extern "C" size_t gc_conv2d_bf16x3_splitk_bytes(const gc_conv_desc* d) {
+    if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !eligible(d)) return 0;
+    return splitk_bytes(d);
 }
 
 extern "C" size_t gc_conv2d_bf16x3_packed_bytes(const gc_conv_desc* d) {
@@ -1305,15 +1356,31 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
     const uint4* wh = static_cast<const uint4*>(packed);
     const uint4* wl = wh + units;
     Bf16Args a{{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
-                d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups, 1, 1};
+                d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups, 1, 1, 0, nullptr, 0};
     set_epilogue(a.c, ep);
+    // small planes: split over K when the caller brought room for the slices (gc_conv2d_bf16x3_splitk_bytes)
+    const SplitPlan sp = plan_splitk_bf16(d);
+    const size_t slice_bytes = splitk_bytes(d);
+    const bool split = sp.slices > 1 && workspace && workspace_bytes >= slice_bytes && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0;
+    ConvArgs fin = a.c;
+    if (split) {
+        a.c.so = nullptr;
+        set_epilogue(a.c, nullptr);
+        a.k_per_split = sp.k_per_split;
+        a.part = static_cast<float*>(workspace);
+        a.per_slice = (long long)d->batch * d->out_ch * d->out_h * d->out_w;
+    }
     if (d->kh == 3) {
         if (d->up == 2 && d->pad_y == 2 && d->pad_x == 2) return dispatch_t(a, s);
         if (d->up == 2) return dispatch<2, 1, 3>(a, s);
-        return d->down == 2 ? dispatch<1, 2, 3>(a, s) : dispatch<1, 1, 3>(a, s);
+        rc = d->down == 2 ? dispatch<1, 2, 3>(a, s) : dispatch<1, 1, 3>(a, s);
+    } else {
+        if (d->up == 2) return dispatch<2, 1, 1>(a, s);
+        rc = d->down == 2 ? dispatch<1, 2, 1>(a, s) : dispatch<1, 1, 1>(a, s);
     }
-    if (d->up == 2) return dispatch<2, 1, 1>(a, s);
-    return d->down == 2 ? dispatch<1, 2, 1>(a, s) : dispatch<1, 1, 1>(a, s);
+    if (rc || !split) return rc;
+    fin.part = a.part;
+    return launch_splitk_finish(fin, sp.slices, a.per_slice, s);
 }
 
 extern "C" int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
@@ -1328,7 +1395,9 @@ extern "C" int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x,
         return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_bf16x3_f32: workspace %zu < %zu bytes (or not 16-byte aligned)", workspace_bytes, need);
     if (!w) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_bf16x3_f32: null pointer");
     if ((rc = gc_conv2d_pack_weights_bf16x3(d, w, workspace, workspace_bytes, stream))) return rc;
-    return gc_conv2d_fused_bf16x3_packed_f32(d, x, w, workspace, workspace_bytes, in_scale, out_scale, ep, y, nullptr, 0, stream);
+    char* tail = static_cast<char*>(workspace) + need;
+    return gc_conv2d_fused_bf16x3_packed_f32(d, x, w, workspace, need, in_scale, out_scale, ep, y, workspace_bytes > need ? tail : nullptr,
+                                             workspace_bytes > need ? workspace_bytes - need : 0, stream);
 }
 
 extern "C" int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,

@@ -153,6 +153,9 @@ size_t conv2d_f32_workspace(const gc_conv_desc* d);
 int conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w, const float* in_scale, const float* out_scale,
                   const gc_conv_epilogue* ep, float* y, void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
+// defined in conv.hip: y = epilogue(sum over the K slices fin.part[z * per_slice + i]) in fixed order (split-K finish pass)
+int launch_splitk_finish(const ConvArgs& fin, int slices, long long per_slice, hipStream_t s);
+
 // defined in conv.hip: dw[i] = sum_s ws[s][i] in fixed order (deterministic split reduction)
 int launch_wgrad_reduce(const float* ws, float* dw, size_t count, int parts, hipStream_t s);
 

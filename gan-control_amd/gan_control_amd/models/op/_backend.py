@@ -358,7 +358,8 @@ class HipBackend:
                         _lib.check(lib.gc_conv2d_pack_weights_bf16x3(desc, _lib.ptr(w_t), _lib.ptr(buf), pbytes, _lib.stream_of(w_t)), 'gc_conv2d_pack_weights_bf16x3')
                     return buf
                 packed = weight_cache.derive(w_t, ('pack_bf16x3',), pack)
-                ws = packed          # not used as a workspace; keeps the call below uniform
+                sbytes = lib.gc_conv2d_bf16x3_splitk_bytes(desc)          # K slices of a small-plane launch
+                ws = torch.empty(sbytes // 4, dtype=torch.float32, device=dev) if sbytes else None
             else:
                 nbytes = lib.gc_conv2d_bf16x3_workspace(desc)
                 ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
@@ -372,11 +373,11 @@ class HipBackend:
             t0 = self.timer.start('conv', tname)
         if g: g.__enter__()
         try:
-            if ws is None:
+            if self.conv_mode == 'f32':
                 rc = lib.gc_conv2d_fused_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y), _lib.stream_of(x))
             elif packed is not None:
                 rc = lib.gc_conv2d_fused_bf16x3_packed_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(packed), packed.numel() * 4, _lib.ptr(in_scale),
-                                                           _lib.ptr(out_scale), ep, _lib.ptr(y), None, 0, _lib.stream_of(x))
+                                                           _lib.ptr(out_scale), ep, _lib.ptr(y), _lib.ptr(ws), ws.numel() * 4 if ws is not None else 0, _lib.stream_of(x))
             else:
                 rc = lib.gc_conv2d_fused_bf16x3_packed_f32(desc, _lib.ptr(x), _lib.ptr(w_t), None, 0, _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y),
                                                            _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))

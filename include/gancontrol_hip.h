@@ -222,6 +222,10 @@ int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x, const floa
  * gc_conv2d_bf16x3_workspace(d) bytes then.  Same results as gc_conv2d_fused_bf16x3_f32, bit for bit.
  */
 size_t gc_conv2d_bf16x3_packed_bytes(const gc_conv_desc* d);
+/* Small planes (9 .. 32 pixels wide, >= 128 input channels) are split over the input channels to fill the chip; the slices are summed in
+ * a fixed order by a finish pass that applies out_scale and the epilogue.  gc_conv2d_bf16x3_splitk_bytes(d) is the workspace that takes
+ * (0 when the shape is not split); without it the launch runs unsplit -- same result up to fp32 summation order. */
+size_t gc_conv2d_bf16x3_splitk_bytes(const gc_conv_desc* d);
 int gc_conv2d_pack_weights_bf16x3(const gc_conv_desc* d, const float* w, void* packed, size_t packed_bytes, gc_stream_t stream);
 int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const float* x, const float* w, const void* packed, size_t packed_bytes,
                                       const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
