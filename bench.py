@@ -45,7 +45,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=16)
     ap.add_argument('--size', type=int, default=1024)
     ap.add_argument('--batch-per-gpu', type=int, default=4)
-    ap.add_argument('--precision', default=os.environ.get('GANCONTROL_CONV_PRECISION', 'bf16x3'), choices=['f32', 'bf16x3'],
+    ap.add_argument('--precision', default=os.environ.get('GANCONTROL_CONV_PRECISION', 'bf16x3'), choices=['f32', 'bf16x3', 'bf16'],
                     help='conv arithmetic: bf16x3 = split-bf16 MFMA (fp32 storage, ~5e-6 relative error per layer), f32 = exact fp32 MFMA')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-fp32-leg', action='store_true', help='skip the second timed region in exact fp32 arithmetic ("fp32_exact" in the JSON line)')

@@ -17,6 +17,21 @@
 // Register-prefetch pipeline over chunks, compile-time geometry, phase decomposition for up = 2.
 #include "conv_common.h"
 
+// The same source builds a second time with -DGC_SINGLE (object conv_bf16.o): plain bf16 arithmetic -- ONE MFMA per product on the
+// hi parts only (bf16 operands, fp32 accumulate, fp32 in HBM; ~3e-3 relative error per layer, the precision of BASELINE.json's
+// config[1] "bf16").  The lo parts are then neither converted, stored to LDS nor read; entry points gc_conv2d_fused_bf16_packed_f32 /
+// gc_conv2d_wgrad_bf16_f32.  It is never the default nor the parity mode.
+#ifdef GC_SINGLE
+#define GC_LO(...)
+#define GC_MFMA3(c, ah, al, bh, bl) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0)
+#else
+#define GC_LO(...) __VA_ARGS__
+#define GC_MFMA3(c, ah, al, bh, bl)                                        \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);       \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);       \
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0)
+#endif
+
 // Wave priority during the MFMA phases: the co-resident workgroup is staging (vector ALU, LDS, loads) meanwhile; letting the
 // multiplying wave issue first keeps the matrix pipe fed (same-box A/B: -2 % forward, -1..3 % weight gradients).
 #ifndef GC_MFMA_PRIO
@@ -219,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
             const int u = t_ + 256 * j;
-            if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; wl_l[u] = wreg_l[j]; }
+            if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; GC_LO(wl_l[u] = wreg_l[j];) }
         }
         const int kgl = __builtin_amdgcn_readfirstlane(t_ >> 7), tb = t_ & 127;
         const int ix0 = (tile % p.tiles_x) * 32 * DOWN + ax.d0;
@@ -250,7 +265,7 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
                     if (i < tk.used) {
                         const int u = rbase + C::ucol(tk.col + i);
                         p_h[u] = *reinterpret_cast<uint4*>(&h);
-                        p_l[u] = *reinterpret_cast<uint4*>(&l);
+                        GC_LO(p_l[u] = *reinterpret_cast<uint4*>(&l);)
                     }
                 }
             }
@@ -276,31 +291,10 @@ __global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
                     bh[j] = *reinterpret_cast<const bf16x8*>(&uh);
                     bl[j] = *reinterpret_cast<const bf16x8*>(&ul);
                 }
-#if defined(GC_EXP) && GC_EXP == 1      // experiment: the three terms as three sweeps over the accumulators (dependent MFMAs WOC * WPX apart)
 #pragma unroll
                 for (int i = 0; i < WOC; ++i)
 #pragma unroll
-                    for (int j = 0; j < WPX; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < WOC; ++i)
-#pragma unroll
-                    for (int j = 0; j < WPX; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < WOC; ++i)
-#pragma unroll
-                    for (int j = 0; j < WPX; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-#else
-#pragma unroll
-                for (int i = 0; i < WOC; ++i)
-#pragma unroll
-                    for (int j = 0; j < WPX; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                    }
-#endif
+                    for (int j = 0; j < WPX; ++j) { GC_MFMA3(acc[i][j], ah[i], al[i], bh[j], bl[j]); }
             }
         }
     };
@@ -561,7 +555,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
                 const float sc = SC ? s_scale[(d >> 24) & 63u] : 1.f;
                 uint4 h, l;
                 unit8(scaled_t, xreg[j], ox0 - p.pad_x + 8 * (int)((d >> 16) & 15u), p.in_w, sc, &h, &l);      // rows / channels outside the image were loaded as zeros
-                if (256 * (j + 1) <= C::NXU || tid + 256 * j < C::NXU) { xh[d & 0xffffu] = h; xl[d & 0xffffu] = l; }
+                if (256 * (j + 1) <= C::NXU || tid + 256 * j < C::NXU) { xh[d & 0xffffu] = h; GC_LO(xl[d & 0xffffu] = l;) }
             }
 #pragma unroll
             for (int j = 0; j < C::NPY; ++j) {
@@ -569,7 +563,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
                 const float sc = SC ? s_scale[KT + ((d >> 24) & 63u)] : 1.f;
                 uint4 h, l;
                 unit8(scaled_t, yreg[j], ox0 + 8 * (int)((d >> 16) & 15u), p.out_w, sc, &h, &l);
-                if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; yl[d & 0xffffu] = l; }
+                if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; GC_LO(yl[d & 0xffffu] = l;) }
             }
         };
         if (scaled) items(std::true_type{}); else items(std::false_type{});
@@ -584,7 +578,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
                 for (int q = 0; q < 8; ++q) { const int c = q - p.pad_x; v[q] = (c >= 0 && c < p.in_w) ? row0[c] : 0.f; }
                 uint4 h, l;
                 split8(v, scaled ? s_scale[0] : 1.f, &h, &l);
-                xh[r * XU] = h; xl[r * XU] = l;
+                xh[r * XU] = h; GC_LO(xl[r * XU] = l;)
             }
         }
     };
@@ -617,13 +611,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
                             const uint4 uh = shift_px(a0h, a1h, tx), ul = shift_px(a0l, a1l, tx);
                             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh), al = *reinterpret_cast<const bf16x8*>(&ul);
                             f32x16 c = acc[ty * KS + tx];
-#if defined(GC_ABL) && GC_ABL == 1      // dev ablation: one MFMA instead of three
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-#else
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-#endif
+                            GC_MFMA3(c, ah, al, bh, bl);
                             acc[ty * KS + tx] = c;
                         }
                         if (KS == 3) __builtin_amdgcn_sched_barrier(0x100);
@@ -818,10 +806,10 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
                 uint4 eh, el, oh, ol;
                 split8<SC>(ev, sc, &eh, &el);
                 if (256 * (j + 1) <= C::NXI || tid + 256 * j < C::NXI) {
-                    xh[o] = eh; xl[o] = el;
+                    xh[o] = eh; GC_LO(xl[o] = el;)
                     if (KS == 3 && it < C::XO) {
                         split8<SC>(od, sc, &oh, &ol);
-                        xh[o + XE] = oh; xl[o + XE] = ol;
+                        xh[o + XE] = oh; GC_LO(xl[o + XE] = ol;)
                     }
                 }
                 __builtin_amdgcn_sched_barrier(0);      // one item at a time: interleaving the conversions of several items costs more registers than there are
@@ -837,7 +825,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
                 for (int q = 0; q < 8; ++q) v[q] = q < room ? v[q] : 0.f;
                 uint4 h, l;
                 split8<SC>(v, sc, &h, &l);
-                if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; yl[d & 0xffffu] = l; }
+                if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; GC_LO(yl[d & 0xffffu] = l;) }
             }
         };
         if (scaled) items(std::true_type{}); else items(std::false_type{});
@@ -866,13 +854,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
                         auto tap = [&](int tx, const uint4 uh, const uint4 ul) {
                             const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh), al = *reinterpret_cast<const bf16x8*>(&ul);
                             f32x16 c = acc[ty * KS + tx];
-#if defined(GC_ABL) && GC_ABL == 1      // dev ablation: one MFMA instead of three
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-#else
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, c, 0, 0, 0);
-#endif
+                            GC_MFMA3(c, ah, al, bh, bl);
                             acc[ty * KS + tx] = c;
                         };
                         // tap order 0, 2, 1: the even units (and their one-pixel shift) retire before the odd unit is live --
@@ -1077,7 +1059,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
 #pragma unroll
         for (int j = 0; j < C::NWU; ++j) {
             const int u = t_ + 256 * j;
-            if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; wl_l[u] = wreg_l[j]; }
+            if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; GC_LO(wl_l[u] = wreg_l[j];) }
         }
         const float4 sa = *reinterpret_cast<const float4*>(&s_si[k0 + kgl_p * 8]), sb = *reinterpret_cast<const float4*>(&s_si[k0 + kgl_p * 8 + 4]);
         const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
@@ -1096,7 +1078,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
             }
             if (i < t_used) {
                 p_h[ubase + i] = *reinterpret_cast<uint4*>(&h);
-                p_l[ubase + i] = *reinterpret_cast<uint4*>(&l);
+                GC_LO(p_l[ubase + i] = *reinterpret_cast<uint4*>(&l);)
             }
         }
     };
@@ -1134,9 +1116,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
 #pragma unroll
                         for (int j = 0; j < WPX; ++j) {
                             f32x16 c = acc[py * 2 + px][j];
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[j], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[j], c, 0, 0, 0);
-                            c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[j], c, 0, 0, 0);
+                            GC_MFMA3(c, ah, al, bh[j], bl[j]);
                             acc[py * 2 + px][j] = c;
                         }
                     }
@@ -1306,6 +1286,11 @@ size_t splitk_bytes(const gc_conv_desc* d) {
 
 }  // namespace
 
+#ifdef GC_SINGLE
+// the plain-bf16 build shares the queries, the weight pack (its lo half is simply not read) and the workspace layout of the split build
+#define gc_conv2d_fused_bf16x3_packed_f32 gc_conv2d_fused_bf16_packed_f32
+#define gc_conv2d_wgrad_bf16x3_f32 gc_conv2d_wgrad_bf16_f32
+#else
 extern "C" size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d) {
     if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
     if (!eligible(d)) return conv2d_f32_workspace(d);        // runs on the fp32 kernel: split-K partial sums (small planes) or nothing
@@ -1317,7 +1302,9 @@ extern "C" size_t gc_conv2d_bf16x3_splitk_bytes(const gc_conv_desc* d) {
     if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !eligible(d)) return 0;
     return splitk_bytes(d);
 }
+#endif
 
+#ifndef GC_SINGLE
 extern "C" size_t gc_conv2d_bf16x3_packed_bytes(const gc_conv_desc* d) {
     if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !eligible(d)) return 0;
     return 2 * (size_t)d->kh * d->kw * ((d->in_ch + 7) / 8) * d->out_ch * sizeof(uint4);
@@ -1337,6 +1324,7 @@ extern "C" int gc_conv2d_pack_weights_bf16x3(const gc_conv_desc* d, const float*
                        w, wh, wh + units, taps, d->in_ch, d->out_ch, kgroups);
     return gc::check_launch("gc_conv2d_pack_weights_bf16x3");
 }
+#endif
 
 extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const float* x, const float* w, const void* packed, size_t packed_bytes,
                                                  const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
@@ -1383,6 +1371,7 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
     return launch_splitk_finish(fin, sp.slices, a.per_slice, s);
 }
 
+#ifndef GC_SINGLE
 extern "C" int gc_conv2d_fused_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
                                           const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
                                           void* workspace, size_t workspace_bytes, gc_stream_t stream) {
@@ -1415,6 +1404,7 @@ extern "C" size_t gc_conv2d_wgrad_bf16x3_workspace(const gc_conv_desc* d) {
     }
     return need;
 }
+#endif
 
 extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* dy,
                                           const float* in_scale, const float* out_scale, float* dw,

@@ -52,6 +52,8 @@ SIGNATURES = {
     'gc_conv2d_bf16x3_splitk_bytes': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_pack_weights_bf16x3': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _sz, _vp]),
     'gc_conv2d_fused_bf16x3_packed_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _sz, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
+    'gc_conv2d_fused_bf16_packed_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _sz, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
+    'gc_conv2d_wgrad_bf16_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_wgrad_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

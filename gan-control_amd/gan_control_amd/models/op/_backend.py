@@ -64,7 +64,8 @@ ConvGeom = namedtuple('ConvGeom', 'kh kw up down pad_y pad_x out_h out_w')
 class HipBackend:
     name = 'hip'
     timer = None          # optional utils.profiling.KernelTimer (bench.py); None in normal operation
-    # 'f32': exact fp32 MFMA (the parity mode); 'bf16x3': split-bf16 MFMA, ~5e-6 relative error per layer
+    # 'f32': exact fp32 MFMA (the parity mode); 'bf16x3': split-bf16 MFMA, ~5e-6 relative error per layer;
+    # 'bf16': one bf16 MFMA per product, fp32 accumulate and storage, ~3e-3 per layer (BASELINE config[1]; never the default)
     conv_mode = os.environ.get('GANCONTROL_CONV_PRECISION', 'f32')
 
     @staticmethod
@@ -348,7 +349,7 @@ class HipBackend:
                 raise RuntimeError('conv2d epilogue: noise has %d elements, expected %d' % (noise.numel(), x.shape[0] * geom.out_h * geom.out_w))
             ep = ctypes.byref(_lib.ConvEpilogue(_lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), float(slope), float(gain), int(bool(activate)), _lib.ptr(residual)))
         ws = packed = None
-        if self.conv_mode == 'bf16x3':
+        if self.conv_mode in ('bf16x3', 'bf16'):
             pbytes = lib.gc_conv2d_bf16x3_packed_bytes(desc)
             if pbytes:
                 # hi / lo split of the weights: once per (weight, optimiser step) when w_t derives from a parameter (weight_cache.py)
@@ -364,7 +365,7 @@ class HipBackend:
                 nbytes = lib.gc_conv2d_bf16x3_workspace(desc)
                 ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
         elif self.conv_mode != 'f32':
-            raise RuntimeError('GANCONTROL_CONV_PRECISION must be f32 or bf16x3, got %r' % self.conv_mode)
+            raise RuntimeError('GANCONTROL_CONV_PRECISION must be f32, bf16x3 or bf16, got %r' % self.conv_mode)
         g = self._guard(dev)
         t0 = None
         if self.timer:
@@ -376,7 +377,8 @@ class HipBackend:
             if self.conv_mode == 'f32':
                 rc = lib.gc_conv2d_fused_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y), _lib.stream_of(x))
             elif packed is not None:
-                rc = lib.gc_conv2d_fused_bf16x3_packed_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(packed), packed.numel() * 4, _lib.ptr(in_scale),
+                fn = lib.gc_conv2d_fused_bf16_packed_f32 if self.conv_mode == 'bf16' else lib.gc_conv2d_fused_bf16x3_packed_f32
+                rc = fn(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(packed), packed.numel() * 4, _lib.ptr(in_scale),
                                                            _lib.ptr(out_scale), ep, _lib.ptr(y), _lib.ptr(ws), ws.numel() * 4 if ws is not None else 0, _lib.stream_of(x))
             else:
                 rc = lib.gc_conv2d_fused_bf16x3_packed_f32(desc, _lib.ptr(x), _lib.ptr(w_t), None, 0, _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y),
@@ -395,14 +397,14 @@ class HipBackend:
         dw = torch.empty((geom.kh, geom.kw, x.shape[1], n_out), dtype=x.dtype, device=dev)
         desc = self._desc(x, n_out, geom)
         lib = _lib.load()
-        fast = self.conv_mode == 'bf16x3'
+        fast = self.conv_mode in ('bf16x3', 'bf16')
         nbytes = (lib.gc_conv2d_wgrad_bf16x3_workspace if fast else lib.gc_conv2d_wgrad_workspace)(desc)
         ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
         g = self._guard(dev)
         t0 = self.timer.start('wgrad') if self.timer else None
         if g: g.__enter__()
         try:
-            fn = lib.gc_conv2d_wgrad_bf16x3_f32 if fast else lib.gc_conv2d_wgrad_f32
+            fn = (lib.gc_conv2d_wgrad_bf16_f32 if self.conv_mode == 'bf16' else lib.gc_conv2d_wgrad_bf16x3_f32) if fast else lib.gc_conv2d_wgrad_f32
             rc = fn(desc, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(dw),
                     _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
         finally:

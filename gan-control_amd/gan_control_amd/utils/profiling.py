@@ -24,7 +24,7 @@ def conv_variant(geom, n_out, batch=1, k_in=64, mode='f32'):
     if geom.kh == 1 and geom.up == 1 and geom.down == 1 and geom.pad_y == 0 and geom.pad_x == 0 and (k_in <= 4 or n_out <= 4) \
             and geom.out_h * geom.out_w * batch >= 1 << 18:
         return ('pw_narrow_kernel' if n_out <= 4 else 'pw_widen_kernel') + geo      # csrc/pointwise.hip
-    if mode == 'bf16x3' and 16 <= k_in <= 1024 and qw > 8:
+    if mode in ('bf16x3', 'bf16') and 16 <= k_in <= 1024 and qw > 8:
         if geom.up == 2 and geom.kh == 3 and geom.pad_y == 2 and geom.pad_x == 2:
             # convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, EPI> (dispatch_t): the four output phases in one workgroup
             tq = -(-geom.out_w // 2)

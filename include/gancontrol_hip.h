@@ -231,6 +231,13 @@ int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const float* x, con
                                       const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
                                       void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
+/* Plain bf16 arithmetic: the kernels of the split-bf16 path with ONE MFMA per product on the bf16-rounded operands (fp32 accumulate,
+ * fp32 in HBM on both sides; ~3e-3 relative error per layer) -- the precision BASELINE.json's config[1] names.  Same arguments,
+ * packed weights (gc_conv2d_pack_weights_bf16x3; the lo half is not read) and workspaces as the split-bf16 entry points. */
+int gc_conv2d_fused_bf16_packed_f32(const gc_conv_desc* d, const float* x, const float* w, const void* packed, size_t packed_bytes,
+                                    const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
+                                    void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
 /* Weight gradient of the same contraction (up must be 1):
  *
  *   dw[ty,tx,k,n] = sum_{b,oy,ox} in_scale[b,k] * x[b,k, oy*down + ty - pad_y, ox*down + tx - pad_x]
@@ -251,6 +258,11 @@ size_t gc_conv2d_wgrad_bf16x3_workspace(const gc_conv_desc* d);
 int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* dy,
                                const float* in_scale, const float* out_scale, float* dw,
                                void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
+/* Plain-bf16 variant (see gc_conv2d_fused_bf16_packed_f32); workspace as for the split-bf16 weight gradient. */
+int gc_conv2d_wgrad_bf16_f32(const gc_conv_desc* d, const float* x, const float* dy,
+                             const float* in_scale, const float* out_scale, float* dw,
+                             void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Weight re-layout: scale + permute + optional tap mirror in one pass.

@@ -802,3 +802,62 @@ def test_reflect_pad_kernel(shape, pads):
     assert rel_err(gp, gr) < 1e-6
     with pytest.raises(ValueError):
         reflect_pad(xp, (shape[3], 0, 0, 0))
+
+
+@pytest.mark.parametrize('case', BF16_CASES[::3])
+def test_conv2d_bf16_kernel(case):
+    """Plain bf16 arithmetic (one MFMA per product on bf16-rounded operands, fp32 accumulate / storage): ~3e-3 relative error per layer by
+    construction; asserted at 2e-2.  Not a parity mode: BASELINE config[1]'s precision."""
+    from gan_control_amd.models.op._backend import ConvGeom
+    hip, emu = _be()
+    prev, hip.conv_mode = hip.conv_mode, 'bf16'
+    try:
+        b, K, N, h, w, k, up, down, pad = case
+        gen = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+        x = torch.randn(b, K, h, w, generator=gen)
+        wt = torch.randn(k, k, K, N, generator=gen)
+        si = torch.randn(b, K, generator=gen)
+        so = torch.rand(b, N, generator=gen) + 0.5
+        oh, ow = _out_size(h, k, up, down, pad, up > 1), _out_size(w, k, up, down, pad, up > 1)
+        geom = ConvGeom(k, k, up, down, pad, pad, oh, ow)
+        ref = emu.conv2d(x.double(), wt.double(), si.double(), so.double(), geom)
+        out = hip.conv2d(x.to(DEV), wt.to(DEV), si.to(DEV), so.to(DEV), geom)
+        assert rel_err(out, ref) < 2e-2
+        # the split-bf16 mode on the same call is three orders closer: the two builds really are different kernels
+        hip.conv_mode = 'bf16x3'
+        fine = hip.conv2d(x.to(DEV), wt.to(DEV), si.to(DEV), so.to(DEV), geom)
+        hip.conv_mode = 'bf16'
+        if K >= 16 and -(-ow // up) > 8 and not (k == 1 and (K <= 4 or N <= 4)):
+            assert rel_err(fine, ref) < 5e-5 < rel_err(out, ref)
+        if up == 1:
+            dy = torch.randn(b, N, oh, ow, generator=gen)
+            ref = emu.conv2d_wgrad(x.double(), dy.double(), si.double(), so.double(), geom)
+            out = hip.conv2d_wgrad(x.to(DEV), dy.to(DEV), si.to(DEV), so.to(DEV), geom)
+            assert rel_err(out, ref) < 2e-2
+    finally:
+        hip.conv_mode = prev
+
+
+def test_bf16_mode_network_and_iteration():
+    """--precision bf16: G / D forward within 5e-2 of the reference image at 64x64 (looser check of its own) and one
+    full training iteration with finite losses that stay near the exact-fp32 iteration's."""
+    import step_checks
+    from gan_control_amd.trainers.utils import requires_grad
+    hip, _ = _be()
+    prev, hip.conv_mode = hip.conv_mode, 'bf16'
+    try:
+        oc.check_network(64, DEV, tol=5e-2)
+        stats = {}
+        for mode in ('f32', 'bf16'):
+            hip.conv_mode = mode
+            tr = step_checks.make_trainer(DEV, size=64, batch=4)
+            torch.manual_seed(1)
+            real = tr.synthetic_batch()
+            tr.gen.manual_seed(5)
+            tr.train_iteration(0, real)
+            stats[mode] = {k: float(v) for k, v in tr.stats.items() if torch.is_tensor(v) and v.numel() == 1}
+        for k in ('d_loss', 'g_adv_loss', 'g_path_loss'):
+            a, b = stats['bf16'][k], stats['f32'][k]
+            assert a == a and abs(a - b) <= 0.1 * max(1.0, abs(b)), (k, a, b)
+    finally:
+        hip.conv_mode = prev

@@ -22,6 +22,15 @@ for e in prof.key_averages(group_by_input_shape=True):
     dt = getattr(e, 'self_device_time_total', None)
     if dt is None: dt = e.self_cuda_time_total
     if dt > 0 and e.key.startswith('aten::'): rows.append((dt, e.count, e.key + ' ' + str(e.input_shapes)[:90]))
+import time
+t0 = time.perf_counter()
+for _ in range(3):
+    tr.generator_regularize_step()
+torch.cuda.synchronize()
+wall = (time.perf_counter() - t0) / 3 * 1e3
+all_dev = sum((getattr(e, 'self_device_time_total', None) or 0) for e in prof.key_averages())
+n_all = sum(e.count for e in prof.key_averages() if (getattr(e, 'self_device_time_total', None) or 0) > 0)
+print(f'wall {wall:.1f} ms per step; device time of ALL kernels {all_dev / 1e3:.1f} ms over {n_all} launching ops (device-bound if the two agree)')
 rows.sort(reverse=True)
 tot = sum(r[0] for r in rows)
 print(f'total {tot/1e3:.1f} ms, {sum(r[1] for r in rows)} launches')

@@ -1,40 +1,41 @@
 #!/usr/bin/env python3
-"""Device time of the four phases of a training iteration (dev tool, GPU only): D step, R1 step, G step, path-length step."""
-import argparse, os, sys
+"""Wall time of the four phases of an iteration (D step, R1, G step, path length) with the GPU drained in between (dev tool)."""
+import os, sys, time
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(REPO, 'gan-control_amd'))
 import torch
 from gan_control_amd.models.op import _backend
 from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
-
-ap = argparse.ArgumentParser()
-ap.add_argument('--size', type=int, default=1024); ap.add_argument('--batch', type=int, default=4)
-ap.add_argument('--precision', default='bf16x3'); ap.add_argument('--reps', type=int, default=5)
-a = ap.parse_args()
-_backend.get().conv_mode = a.precision
-tr = GeneratorTrainer(default_config(a.size, a.batch), device='cuda', seed=0)
-real = torch.randn(a.batch, 3, a.size, a.size, device='cuda').clamp(-1, 1)
+from gan_control_amd.trainers.utils import requires_grad, make_mini_batch_from_noise
+_backend.get().conv_mode = os.environ.get('GANCONTROL_CONV_PRECISION', 'bf16x3')
+size, batch = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, int(sys.argv[2]) if len(sys.argv) > 2 else 4
+tr = GeneratorTrainer(default_config(size, batch), device='cuda', seed=0)
+real = tr.synthetic_batch()
 for i in range(2):
-    tr.train_iteration(i, real)
-
-
-def timed(fn):
+    tr.train_iteration(i * 16, real)
+def timed(fn, n=5):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(n): fn()
+    torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
+def dstep():
+    requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
+    tr.discriminator_step(make_mini_batch_from_noise(tr.sample_z(batch), batch, batch), [real])
+def r1():
+    requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
+    tr.discriminator_regularize_step([real])
+def gstep():
+    requires_grad(tr.generator, True); requires_grad(tr.discriminator, False)
+    tr.generator_step(make_mini_batch_from_noise(tr.sample_z(batch), batch, batch))
+def pl():
+    requires_grad(tr.generator, True); requires_grad(tr.discriminator, False)
+    tr.generator_regularize_step()
+t = {'d_step': timed(dstep), 'r1': timed(r1), 'g_step': timed(gstep), 'pl': timed(pl)}
+print({k: round(v, 2) for k, v in t.items()}, 'ms; per iteration = d + g + r1/16 + pl/4 = %.2f ms' % (t['d_step'] + t['g_step'] + t['r1'] / 16 + t['pl'] / 4))
+# CPU issue time (no synchronisation inside the timed region): a phase is launch-bound when this approaches its wall time
+def issue(fn, n=5):
+    out = []
+    for _ in range(n):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); fn(); out.append((time.perf_counter() - t0) * 1e3)
     torch.cuda.synchronize()
-    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    s.record()
-    for _ in range(a.reps):
-        fn()
-    e.record(); torch.cuda.synchronize()
-    return s.elapsed_time(e) / a.reps
-
-
-tc = tr.config['training_config']
-z = lambda: tr.sample_z(a.batch)
-rows = [('D step (G fwd no-grad, D fwd+bwd on fake|real, Adam)', timed(lambda: tr.discriminator_step([z()], [real])), 1.0),
-        ('R1 step (D fwd + double backward on real, Adam)', timed(lambda: tr.discriminator_regularize_step([real])), 1.0 / tc['d_reg_every']),
-        ('G step (G fwd, D fwd, bwd through both, Adam)', timed(lambda: tr.generator_step([z()])), 1.0),
-        ('path-length step (G fwd + double backward, Adam)', timed(lambda: tr.generator_regularize_step()), 1.0 / tc['g_reg_every'])]
-tot = sum(t * w for _, t, w in rows)
-for name, t, w in rows:
-    print(f'{name:58s} {t:8.2f} ms  x{w:6.4f} = {t * w:7.2f} ms/iter ({t * w / tot * 100:4.1f}%)')
-print(f'{"sum":58s} {tot:8.2f} ms/iter  -> {a.batch / tot * 1e3:.1f} img/s')
+    return min(out)
+print('CPU issue time (ms):', {k: round(issue(f), 2) for k, f in (('d_step', dstep), ('r1', r1), ('g_step', gstep), ('pl', pl))})
