@@ -12,6 +12,13 @@ namespace gc {
 char* err_buf();
 int fail(int code, const char* fmt, ...);
 
+// Dispatch probe (gc_conv2d_variant_name): while probe_buf() is non-null the convolution launchers write the name of the kernel
+// variant they WOULD launch into it and return without launching -- the name comes from the dispatch code itself, so a host-side
+// profiler cannot drift from it.
+char*& probe_buf();
+inline bool probing() { return probe_buf() != nullptr; }
+int probe_name(const char* fmt, ...);
+
 inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(GC_ERR_HIP, "%s: %s", what, hipGetErrorString(e));

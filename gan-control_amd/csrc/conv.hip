@@ -511,6 +511,7 @@ int launch_conv(ConvArgs a, hipStream_t s) {
     const long long gx = (long long)a.tiles_x * a.tiles_y * UP * UP * a.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_f32: grid too large");
     const int slices = a.k_per_split ? gc::ceil_div(a.K, a.k_per_split) : 1;
+    if (gc::probing()) return gc::probe_name("conv_mfma_kernel<%d,%d,%d,%d,%d,%d,%d>|up%d,down%d,k%d", WG_OC, WG_PX, KSPLIT, KCT, WOC, WPX, TPW, UP, DOWN, KS);
     dim3 grid((unsigned)gx, gc::ceil_div(a.N, C::OCT), slices);
     hipLaunchKernelGGL((conv_mfma_kernel<WG_OC, WG_PX, KSPLIT, KCT, WOC, WPX, TPW, UP, DOWN, KS>), grid, dim3(256), 0, s, a);
     return gc::check_launch("gc_conv2d_f32");

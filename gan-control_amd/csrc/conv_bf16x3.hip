@@ -1190,6 +1190,7 @@ int launch_t(Bf16Args a, hipStream_t s) {
     a.c.tiles_x = gc::ceil_div(qw, TPW);
     const long long gx = (long long)a.c.tiles_x * a.c.tiles_y * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
+    if (gc::probing()) return gc::probe_name("convt_fused_bf16x3_kernel<%d,%d,%d,%d>|up2,down1,k3", WG_OC, WG_PX, WPX, TPW);
     dim3 grid((unsigned)gx, gc::ceil_div(a.c.N, C::OCT));
     const int epi = (a.c.bias || a.c.noise || a.c.act || a.c.residual) ? 2 : (a.c.so ? 1 : 0);
     if (epi == 2)      hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 2>), grid, dim3(256), 0, s, a);
@@ -1227,6 +1228,7 @@ int launch(Bf16Args a, hipStream_t s) {
     a.groups = gc::ceil_div(tiles, a.tpb);
     const long long gx = (long long)a.groups * UP * UP * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
+    if (gc::probing()) return gc::probe_name("conv_bf16x3_kernel<%d,%d,%d,%d>|up%d,down%d,k%d", WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS);
     dim3 grid((unsigned)gx, ocb, a.k_per_split ? gc::ceil_div(a.c.K, a.k_per_split) : 1);
     hipLaunchKernelGGL((conv_bf16x3_kernel<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>), grid, dim3(256), 0, s, a);
     return gc::check_launch("gc_conv2d_bf16x3_f32");

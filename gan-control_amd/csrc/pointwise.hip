@@ -239,6 +239,7 @@ int gcconv::pointwise_conv(const gc_conv_desc* d, const float* x, const float* w
     const long long groups = (a.plane + 3) / 4;
     dim3 grid((unsigned)((groups + 255) / 256), d->batch);
     hipStream_t s = (hipStream_t)stream;
+    if (gc::probing()) return gc::probe_name("%s|up1,down1,k1", d->out_ch <= MAXS ? "pw_narrow_kernel" : "pw_widen_kernel");
     if (d->out_ch <= MAXS) {
         if (a.vec) hipLaunchKernelGGL(pw_narrow_kernel<true>, grid, dim3(256), 0, s, a);
         else       hipLaunchKernelGGL(pw_narrow_kernel<false>, grid, dim3(256), 0, s, a);

@@ -54,6 +54,7 @@ SIGNATURES = {
     'gc_conv2d_fused_bf16x3_packed_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _sz, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
     'gc_conv2d_fused_bf16_packed_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _sz, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_bf16_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'gc_conv2d_variant_name': (_i32, [ctypes.POINTER(ConvDesc), _i32, ctypes.c_char_p, _i32]),
     'gc_conv2d_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_wgrad_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

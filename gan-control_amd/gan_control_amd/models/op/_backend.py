@@ -370,7 +370,7 @@ class HipBackend:
         t0 = None
         if self.timer:
             from ...utils.profiling import conv_variant, conv_flops
-            tname = conv_variant(geom, n_out, x.shape[0], x.shape[1], self.conv_mode)
+            tname = conv_variant(geom, n_out, x.shape[0], x.shape[1], self.conv_mode, in_hw=(x.shape[2], x.shape[3]))
             t0 = self.timer.start('conv', tname)
         if g: g.__enter__()
         try:

@@ -13,45 +13,26 @@ import collections
 import torch
 
 
-def conv_variant(geom, n_out, batch=1, k_in=64, mode='f32'):
-    """Name of the conv_mfma_kernel tile configuration gc_conv2d_f32 selects (csrc/conv.hip, dispatch_conv).
+_VARIANTS = {}
+_MODES = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
 
-    Template arguments: <WG_OC, WG_PX, KSPLIT, WOC, WPX, TPW>; the (up, down, taps) triple follows.  In bf16x3 mode
-    the same shapes run on conv_bf16x3_kernel (planes wider than 8 px and >= 16 input channels).
-    """
-    qw, qh = -(-geom.out_w // geom.up), -(-geom.out_h // geom.up)
-    geo = '|up%d,down%d,k%d' % (geom.up, geom.down, geom.kh)
-    if geom.kh == 1 and geom.up == 1 and geom.down == 1 and geom.pad_y == 0 and geom.pad_x == 0 and (k_in <= 4 or n_out <= 4) \
-            and geom.out_h * geom.out_w * batch >= 1 << 18:
-        return ('pw_narrow_kernel' if n_out <= 4 else 'pw_widen_kernel') + geo      # csrc/pointwise.hip
-    if mode in ('bf16x3', 'bf16') and 16 <= k_in <= 1024 and qw > 8:
-        if geom.up == 2 and geom.kh == 3 and geom.pad_y == 2 and geom.pad_x == 2:
-            # convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, EPI> (dispatch_t): the four output phases in one workgroup
-            tq = -(-geom.out_w // 2)
-            tpw = 16 if -(-tq // 16) * 16 < -(-tq // 32) * 32 else 32
-            return ('convt_fused_bf16x3_kernel<1,4,2,%d>' % tpw if n_out <= 32 else 'convt_fused_bf16x3_kernel<2,2,2,%d>' % tpw) + geo
-        # conv_bf16x3_kernel<WG_OC, WG_PX, WOC, WPX> (csrc/conv_bf16x3.hip, dispatch)
-        if geom.down == 2:
-            return ('conv_bf16x3_kernel<1,4,1,1>' if n_out <= 32 else 'conv_bf16x3_kernel<1,4,2,1>') + geo
-        if n_out <= 32:
-            return 'conv_bf16x3_kernel<1,4,1,2>' + geo
-        big = -(-qw // 32) * -(-qh // 8) * geom.up * geom.up * batch * -(-n_out // 64)
-        return ('conv_bf16x3_kernel<1,4,2,1>' if big < 512 else 'conv_bf16x3_kernel<1,4,2,2>') + geo
-    if qw <= 16:
-        tpw = 4 if qw <= 4 else (8 if qw <= 8 else 16)
-        return 'conv_mfma_kernel<1,1,4,32,1,1,%d>' % tpw + geo
-    if geom.down == 2:
-        if n_out <= 64:
-            return 'conv_mfma_kernel<2,2,1,1,1,32>' + geo
-    else:
-        if n_out <= 32:
-            return 'conv_mfma_kernel<1,4,1,1,4,32>' + geo
-        if n_out <= 64:
-            return 'conv_mfma_kernel<1,4,1,2,2,32>' + geo
-    big = -(-qw // 32) * -(-qh // 4) * geom.up * geom.up * batch * -(-n_out // 128)
-    if big < 512:
-        return 'conv_mfma_kernel<2,2,1,1,1,32>' + geo
-    return 'conv_mfma_kernel<2,2,1,2,2,32>' + geo
+
+def conv_variant(geom, n_out, batch=1, k_in=64, mode='f32', in_hw=None):
+    """Name of the kernel variant the library's dispatcher selects for this shape, asked of the dispatch code itself
+    (gc_conv2d_variant_name: the launchers run in a no-launch probe mode), so the name cannot drift from the C++ side."""
+    import ctypes
+    from .. import _lib
+    if in_hw is None:       # input extent from the output extent (any consistent value: the dispatch looks at the output side)
+        in_hw = ((geom.out_h - 1) * geom.down + geom.kh - 2 * geom.pad_y, (geom.out_w - 1) * geom.down + geom.kw - 2 * geom.pad_x) if geom.up == 1 \
+            else (-(-geom.out_h // geom.up), -(-geom.out_w // geom.up))
+    key = (tuple(geom), n_out, batch, k_in, mode, tuple(in_hw))
+    name = _VARIANTS.get(key)
+    if name is None:
+        desc = _lib.ConvDesc(batch, k_in, n_out, max(in_hw[0], 1), max(in_hw[1], 1), geom.out_h, geom.out_w, geom.kh, geom.kw, geom.up, geom.down, geom.pad_y, geom.pad_x)
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().gc_conv2d_variant_name(desc, _MODES[mode], buf, 128), 'gc_conv2d_variant_name')
+        name = _VARIANTS[key] = buf.value.decode()
+    return name
 
 
 def conv_flops(batch, k_in, n_out, in_h, in_w, geom):

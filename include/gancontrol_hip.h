@@ -238,6 +238,11 @@ int gc_conv2d_fused_bf16_packed_f32(const gc_conv_desc* d, const float* x, const
                                     const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep, float* y,
                                     void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
+/* Name of the kernel variant the dispatcher picks for a shape ("conv_bf16x3_kernel<1,4,2,2>|up1,down1,k3", ...), written by the
+ * dispatch code itself (the launchers run in a no-launch probe mode): what a host-side profiler keys its per-kernel statistics on.
+ * mode: 0 = exact fp32, 1 = split-bf16, 2 = plain bf16.  name must hold >= 128 bytes. */
+int gc_conv2d_variant_name(const gc_conv_desc* d, int mode, char* name, int name_bytes);
+
 /* Weight gradient of the same contraction (up must be 1):
  *
  *   dw[ty,tx,k,n] = sum_{b,oy,ox} in_scale[b,k] * x[b,k, oy*down + ty - pad_y, ox*down + tx - pad_x]

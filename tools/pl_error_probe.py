@@ -1,5 +1,19 @@
-import sys, os, torch, math
-sys.path[:0]=['/root/repo','/root/repo/gan-control_amd','/root/repo/tests']
+#!/usr/bin/env python3
+"""Where does the fp32 error of the path-length double-backward come from?  (dev tool, CPU, emulated C ABI)
+
+Runs the generator forward and the first-order path-length gradient (create_graph) of the PRODUCT's autograd layer twice -- in fp64
+and in fp32 -- over the emulated backend, records the output of every primitive call (conv2d, plane_dot, bias_act_bwd_reduce,
+conv2d_wgrad) in order and prints the relative error of each fp32 result against its fp64 twin.  Result that tests/step_checks.py
+cites: every primitive is at ~5e-7 until the first activation backward whose mask differs in ONE element (a leaky-ReLU whose
+pre-activation is within rounding of zero takes the other slope); from there a ~5e-4 error travels down the layers.  In fp64 the
+product reproduces the oracle's double-backward gradients to 1e-15.
+"""
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [REPO, os.path.join(REPO, 'gan-control_amd'), os.path.join(REPO, 'tests')]
+import torch
 import conftest, step_checks, op_checks as oc
 from conftest import load_golden, EmulatedBackend
 from gan_control_amd.models.op import _backend, modulated_conv as mc
