@@ -127,8 +127,13 @@ struct BCfg {
     }
 };
 
+#if defined(GC_EXP) && GC_EXP == 2      // experiment: three workgroups per CU for the 32-channel tiles (more loads in flight on the HBM-bound layers)
+#define GC_CONV_OCC(WOC, WPX, DOWN) ((WOC) * (WPX) <= 2 && (DOWN) == 1 ? 3 : 2)
+#else
+#define GC_CONV_OCC(WOC, WPX, DOWN) 2
+#endif
 template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
-__global__ __launch_bounds__(256, 2) void conv_bf16x3_kernel(Bf16Args a) {
+__global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_kernel(Bf16Args a) {
     using C = BCfg<WG_OC, WG_PX, WOC, WPX, UP, DOWN, KS>;
     static_assert(WG_OC * WG_PX == 4, "4 waves per workgroup");
     constexpr int OCT = C::OCT, TPH = C::TPH, PWD = C::PWD, PLANE = C::PLANE;
