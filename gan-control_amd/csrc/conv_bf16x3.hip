@@ -37,6 +37,18 @@
 #ifndef GC_MFMA_PRIO
 #define GC_MFMA_PRIO 2
 #endif
+#ifndef GC_WS_MIN_K
+#define GC_WS_MIN_K 64      // input channels from which the wave-specialised forward kernel takes over
+#endif
+#ifndef GC_WS_SLOTS
+#define GC_WS_SLOTS 256     // workgroups the wave-specialised kernel keeps resident: one per CU
+#endif
+#ifndef GC_WS_STAGER_PRIO
+#define GC_WS_STAGER_PRIO 0
+#endif
+#ifndef GC_WS_ABL
+#define GC_WS_ABL 0         // dev ablations of conv_bf16x3_ws_kernel (wrong results): 1 no patch staging, 2 no weight DMA, 4 fragments read once, 8 no stores
+#endif
 #include <type_traits>
 
 namespace {
@@ -383,6 +395,291 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
     }
     mfma_phase();
     finish_tile(tile_c);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Wave-specialised variant of conv_bf16x3_kernel for the wide layers (up = down = 1, K a multiple of 16, N a multiple of 64):
+// ONE workgroup of 12 waves per CU -- eight MULTIPLYING waves (two per SIMD; each owns 64 oc x 2 rows x 32 px of a
+// 64 oc x 16 rows x 32 px tile and issues nothing but LDS fragment reads and MFMAs) and four STAGING waves (one per SIMD:
+// global loads, the per-sample scale, the hi / lo split and the LDS writes of the NEXT 16-channel chunk) -- over two LDS stages
+// with one barrier per chunk.  In conv_bf16x3_kernel every wave alternates between the two jobs and the matrix pipes only stay
+// busy while the co-resident workgroup happens to be in the other phase (matrix pipes busy 51 %, 21 % of the wave time at the two
+// barriers per chunk, profiles/pmc_r01.md); here the multiplying waves never convert and never wait for a load.
+//  * The pre-split weight slab goes HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: a [tap][kg] row of 64 oc units is 1 KiB,
+//    contiguous on both sides = one wave-level instruction): no registers, no ds_write, no vector ALU work for 63 % of the staged bytes.
+//  * A 16-row tile halves the weight staging and the halo rows (18 / 16 instead of 10 / 8) per MFMA.
+//  * Ordering of the LDS-DMA data: the staging wave waits vmcnt(0) before the barrier, the multiplying waves read the stage after it;
+//    a stage is rewritten one full item after its last read (the barrier in between retires the reads).
+// Eight values with one scale EACH (a channel-last patch unit: eight channels of one pixel) -> hi / lo bf16 units.  Plain v_mul_f32 /
+// v_sub_f32 by asm: left to itself the compiler pairs neighbouring channels into v_pk_mul_f32 / v_pk_add_f32, and packed fp32 does not
+// run under another wave's MFMA (profiles/pmc_r01.md, co-issue table) -- in the wave-specialised kernel the staging wave shares its SIMD
+// with two multiplying waves, so every packed instruction is time taken from the matrix pipe.
+template <bool SCALED>
+__device__ __forceinline__ void split8s(const float (&v)[8], const float (&sc)[8], uint4* h, uint4* l) {
+    bf16x8 hh, ll;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float f = v[q];
+        if (SCALED) asm("v_mul_f32 %0, %1, %2" : "=v"(f) : "v"(v[q]), "v"(sc[q]));
+        const __bf16 t = (__bf16)f;
+        hh[q] = t;
+        const float tf = (float)t;
+        float dlo;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(dlo) : "v"(f), "v"(tf));
+        ll[q] = (__bf16)dlo;
+    }
+    *h = *reinterpret_cast<uint4*>(&hh);
+    *l = *reinterpret_cast<uint4*>(&ll);
+}
+
+// LDS-DMA of one 1 KiB row: lane l copies 16 bytes from its own global address to (wave-uniform LDS address) + 16 l.  M0 carries the LDS
+// address and is compiler-reserved: saved and restored inside the statement (cdna guide, "M0 ... write it in the same statement").
+__device__ __forceinline__ void glds16(const void* gsrc, const void* lds_row) {
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds_row);
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+template <int KS>
+__global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
+    using C = BCfg<1, 8, 2, 2, 1, 1, KS>;
+    constexpr int OCT = 64, TPH = C::TPH, PLANE = C::PLANE, WOC = 2, WPX = 2, NTAP = KS * KS;
+    constexpr int STAGE = C::SMEM_UNITS;                 // one stage: [weights hi | weights lo | patch hi | patch lo]
+    static_assert(C::OCT == OCT && C::TPH == 16, "64 oc x 16 rows x 32 px tiles");
+    static_assert(2 * STAGE * 16 + (MAX_K_BF16X3 + KCB + 2 * OCT) * 4 <= 160 * 1024, "two stages fit the 160 KiB of LDS");
+    const ConvArgs& p = a.c;
+    __shared__ uint4 smem[2 * STAGE];
+    __shared__ __attribute__((aligned(16))) float s_si[MAX_K_BF16X3 + KCB];
+    __shared__ __attribute__((aligned(16))) float s_so[OCT], s_bias[OCT];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int grp = bid % a.groups;
+    const int b = bid / a.groups;
+    const int n0 = blockIdx.y * OCT;
+    const int tile_begin = grp * a.tpb, tile_end = min(p.tiles_x * p.tiles_y, tile_begin + a.tpb);
+    const int nchunks = p.K / KCB;
+    const int items = (tile_end - tile_begin) * nchunks;
+    const int chan = p.in_h * p.in_w;
+
+    for (int k = tid; k < p.K; k += 768) s_si[k] = p.si ? p.si[(size_t)b * p.K + k] : 1.f;
+    if (tid < OCT) {
+        const int oc = n0 + tid;
+        s_so[tid] = p.so ? p.so[(size_t)b * p.N + oc] : 1.f;
+        s_bias[tid] = p.bias ? p.bias[oc] : 0.f;
+    }
+    __syncthreads();
+
+    if (wave >= 8) {
+        // ---------------- staging waves ----------------
+        if (GC_WS_STAGER_PRIO) __builtin_amdgcn_s_setprio(GC_WS_STAGER_PRIO);
+        const int st = tid - 512;
+        const int kgl = __builtin_amdgcn_readfirstlane(st >> 7), tb = st & 127;     // waves 8, 9: channel group 0; waves 10, 11: group 1
+        const float* xb = p.x + (size_t)b * p.K * chan;
+        const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)p.K * chan * 4u);
+        const int lead = gc::pos_mod(p.pad_x, 32);           // patch rows start `lead` floats before a 128-byte boundary
+        // Two register sets: the loads of item i + 2 are in flight while item i + 1 is converted and written, so the load latency
+        // is never on this wave's critical path (which is then ~300 vector instructions + 16 ds_write_b128 per item).
+        uint4 pa[C::NT][8], pb[C::NT][8];
+        auto loads = [&](uint4 (&preg)[C::NT][8], int tile, int k0) {
+            const int iy0 = (tile / p.tiles_x) * TPH - p.pad_y, ix0 = (tile % p.tiles_x) * 32 - p.pad_x;
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j) {
+                const typename C::Task tk = C::task_of(tb + 128 * j, lead);
+                const int iy = iy0 + tk.row, ix = ix0 + tk.col;
+                const bool ok = tk.used > 0 && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;      // rows past the last tile: zeros
+                const unsigned boff = ok ? (unsigned)(iy * p.in_w + ix) * 4u : OOB;
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    preg[j][q] = buf_load_u128(rx, boff, (unsigned)(k0 + kgl * 8 + q) * chan * 4u);     // channels past K: beyond the descriptor, zeros
+            }
+        };
+        auto convert = [&](uint4 (&preg)[C::NT][8], int tile, int k0, int buf) {
+            uint4* const p_h = smem + buf * STAGE + 2 * C::WUNITS;
+            uint4* const p_l = p_h + C::PUNITS;
+            const int kk = min(k0, p.K - KCB);          // the item past the last one is converted into a stage nobody reads
+            const float4 sa = *reinterpret_cast<const float4*>(&s_si[kk + kgl * 8]), sb = *reinterpret_cast<const float4*>(&s_si[kk + kgl * 8 + 4]);
+            const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+            const int ix0 = (tile % p.tiles_x) * 32 - p.pad_x;
+            const bool ragged_rows = (p.in_w & 3) != 0 && ix0 + lead + 32 * C::SEG_M + 4 > p.in_w;
+            auto body = [&](auto masked, auto scaled) {
+#pragma unroll
+                for (int j = 0; j < C::NT; ++j) {
+                    const typename C::Task tk = C::task_of(tb + 128 * j, lead);
+                    const int inrow = p.in_w - (ix0 + tk.col);
+                    const int rbase = kgl * PLANE + tk.row * C::RP;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float v[8];
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) {
+                            const unsigned raw = i == 0 ? preg[j][q].x : (i == 1 ? preg[j][q].y : (i == 2 ? preg[j][q].z : preg[j][q].w));
+                            v[q] = (!decltype(masked)::value || i < inrow) ? __uint_as_float(raw) : 0.f;
+                        }
+                        uint4 h, l;
+                        split8s<decltype(scaled)::value>(v, sc, &h, &l);
+                        if (i < tk.used) {
+                            const int u = rbase + C::ucol(tk.col + i);
+                            p_h[u] = h;
+                            GC_LO(p_l[u] = l;)
+                        }
+                    }
+                }
+            };
+            // without modulation (every layer of D) the multiply by one is not issued
+            if (p.si) { if (ragged_rows) body(std::true_type{}, std::true_type{}); else body(std::false_type{}, std::true_type{}); }
+            else      { if (ragged_rows) body(std::true_type{}, std::false_type{}); else body(std::false_type{}, std::false_type{}); }
+        };
+        auto advance = [&](int& tile, int& k0) { k0 += KCB; if (k0 >= p.K) { k0 = 0; ++tile; } };
+        int t0 = tile_begin, k0 = 0;                    // item 0 -> set A
+        loads(pa, t0, k0);
+        int t1 = t0, k1 = k0; advance(t1, k1);          // item 1 -> set B
+        loads(pb, t1, k1);
+        convert(pa, t0, k0, 0);
+        __syncthreads();
+        // interval `it`: the multiplying waves work on item it; item it + 1 is converted here, item it + 2 is fetched
+        for (int it = 0; it < items; it += 2) {
+            int t2 = t1, k2 = k1; advance(t2, k2);
+            if (!(GC_WS_ABL & 1)) { loads(pa, t2, k2); convert(pb, t1, k1, 1); }
+            __syncthreads();
+            if (it + 1 >= items) break;
+            t1 = t2; k1 = k2; advance(t1, k1);
+            if (!(GC_WS_ABL & 1)) { loads(pb, t1, k1); convert(pa, t2, k2, 0); }
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------- multiplying waves ----------------
+    const int wave_px = wave;        // rows 2 wave, 2 wave + 1 of the tile
+    f32x16 acc[WOC][WPX];
+#pragma unroll
+    for (int i = 0; i < WOC; ++i)
+#pragma unroll
+        for (int j = 0; j < WPX; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int boff[WPX];
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) boff[j] = hi * PLANE + (wave_px * WPX + j) * C::RP;
+    const int aoff = hi * OCT + l31;
+
+    const unsigned oplane = (unsigned)(p.out_h * p.out_w) * 4u;
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y + (size_t)b * p.N * p.out_h * p.out_w, (unsigned)p.N * oplane);
+    const EpilogueConsts ec = epilogue_consts(p);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + (size_t)b * p.N * p.out_h * p.out_w : p.y, p.residual ? (unsigned)p.N * oplane : 0u);
+    auto finish_tile = [&](int tile) {
+        const int qy0 = (tile / p.tiles_x) * TPH, qx0 = (tile % p.tiles_x) * 32;
+        const int nb = opaque_s(n0);
+        // every load of the epilogue (noise, residual) is issued before the first store: a load between two stores waits for the stores
+        unsigned voff[WPX];
+        float nz[WPX];
+#pragma unroll
+        for (int j = 0; j < WPX; ++j) {
+            const int qy = qy0 + wave_px * WPX + j, qx = qx0 + l31;
+            const bool inside = qy < p.out_h && qx < p.out_w;
+            voff[j] = inside ? (unsigned)(qy * p.out_w + qx) * 4u + (unsigned)(4 * hi) * oplane : OOB;
+            nz[j] = (p.noise && inside) ? p.noise[((size_t)b * p.out_h + qy) * p.out_w + qx] : 0.f;
+        }
+        if (p.residual) {
+#pragma unroll
+            for (int j = 0; j < WPX; ++j)
+#pragma unroll
+                for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        acc[i][j][r] = conv_epilogue(ec, acc[i][j][r], s_so[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi], s_bias[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi], nz[j])
+                                       + buf_load_f32(rres, voff[j], (unsigned)(nb + i * 32 + (r & 3) + 8 * (r >> 2)) * oplane);
+        }
+#pragma unroll
+        for (int j = 0; j < WPX; ++j) {
+#pragma unroll
+            for (int i = 0; i < WOC; ++i) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int ocl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const int ocs = nb + i * 32 + (r & 3) + 8 * (r >> 2);
+                    const float v = p.residual ? acc[i][j][r] : conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz[j]);
+                    if (!(GC_WS_ABL & 8) || v == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff[j], (int)((unsigned)ocs * oplane), 0);
+                    acc[i][j][r] = 0.f;
+                }
+            }
+        }
+    };
+    // The weight slab of the NEXT item: rows (half, tap, kg) of 64 units, one LDS-DMA instruction each, dealt round-robin to the eight
+    // multiplying waves (4 or 5 each) at the start of their MFMA phase.  The instruction is issued from an asm statement: the
+    // compiler-tracked builtin makes every later LDS read of the wave (the fragment reads of THIS item) wait for the DMA first, which
+    // puts its latency at the head of each MFMA phase.  Untracked, its completion is counted by hand: vmcnt(0) before the barrier.
+#ifdef GC_SINGLE
+    constexpr int ROWS = NTAP * KG;
+#else
+    constexpr int ROWS = 2 * NTAP * KG;
+#endif
+    auto weights = [&](int k0, int buf) {
+        uint4* const base = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < (ROWS + 7) / 8; ++j) {
+            const int r = wave + 8 * j;
+            if (8 * j + 7 < ROWS || r < ROWS) {
+                const int half = r / (NTAP * KG), rr = r % (NTAP * KG);
+                const int t = rr / KG, kg = rr % KG;
+                const uint4* src = (half ? a.wl : a.wh) + ((size_t)(t * a.kgroups + k0 / 8 + kg) * p.N + n0 + lane);
+                glds16(src, base + half * C::WUNITS + rr * OCT);
+            }
+        }
+    };
+    int tile_c = tile_begin, k0_c = 0;
+    weights(0, 0);
+    wait_staged_loads();
+    __syncthreads();                 // stage 0 is staged
+    for (int it = 0; it < items; ++it) {
+        if (!(GC_WS_ABL & 2)) weights(k0_c + KCB < p.K ? k0_c + KCB : 0, (it + 1) & 1);          // after the last item: a valid slab into a stage nobody reads
+        const uint4* const wl_h = smem + (it & 1) * STAGE;
+        const uint4* const wl_l = wl_h + C::WUNITS;
+        const uint4* const p_h = wl_l + C::WUNITS;
+        const uint4* const p_l = p_h + C::PUNITS;
+        __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
+        // Fragment double buffer: the eight ds_read_b128 of tap t + 1 are issued BEFORE the twelve MFMAs of tap t (the scheduling
+        // barriers pin that order; left alone the compiler sinks every read to 1-3 MFMAs before its use, far less than the LDS latency).
+        bf16x8 fa[2][2 * WOC], fb[2][2 * WPX];          // [set][hi 0..1, lo 0..1]
+        auto load_tap = [&](int t, int set) {
+            const int jy = t / KS, jx = t % KS;
+            const int wbase = t * KG * OCT + aoff;
+            const int pbase = jy * C::RP + l31 + jx;
+#pragma unroll
+            for (int i = 0; i < WOC; ++i) {
+                const uint4 uh = wl_h[wbase + i * 32];
+                fa[set][i] = *reinterpret_cast<const bf16x8*>(&uh);
+                GC_LO(const uint4 ul = wl_l[wbase + i * 32]; fa[set][WOC + i] = *reinterpret_cast<const bf16x8*>(&ul);)
+            }
+#pragma unroll
+            for (int j = 0; j < WPX; ++j) {
+                const uint4 uh = p_h[pbase + boff[j]];
+                fb[set][j] = *reinterpret_cast<const bf16x8*>(&uh);
+                GC_LO(const uint4 ul = p_l[pbase + boff[j]]; fb[set][WPX + j] = *reinterpret_cast<const bf16x8*>(&ul);)
+            }
+        };
+        load_tap(0, 0);
+#pragma unroll
+        for (int t = 0; t < NTAP; ++t) {
+            if (t + 1 < NTAP && !(GC_WS_ABL & 4)) load_tap(t + 1, (t + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) { constexpr int fs = (GC_WS_ABL & 4) ? 0 : 1; GC_MFMA3(acc[i][j], fa[t & fs][i], fa[t & fs][WOC + i], fb[t & fs][j], fb[t & fs][WPX + j]); }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        wait_staged_loads();         // the LDS-DMA rows of this wave have landed (they were issued a whole MFMA phase ago)
+        __syncthreads();             // this stage may be rewritten from the next item on; the other one is staged
+        k0_c += KCB;
+        if (k0_c >= p.K) { finish_tile(tile_c); k0_c = 0; ++tile_c; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1239,8 +1536,42 @@ int launch(Bf16Args a, hipStream_t s) {
     return gc::check_launch("gc_conv2d_bf16x3_f32");
 }
 
+// wave-specialised kernel (conv_bf16x3_ws_kernel): 64 oc x 16 rows x 32 px tiles, one 12-wave workgroup per CU
+template <int KS>
+int launch_ws(Bf16Args a, hipStream_t s) {
+    a.c.tiles_y = gc::ceil_div(a.c.out_h, 16);
+    a.c.tiles_x = gc::ceil_div(a.c.out_w, 32);
+    const int tiles = a.c.tiles_x * a.c.tiles_y, ocb = a.c.N / 64;
+    const long long wgs = (long long)tiles * a.c.B * ocb;
+    // One workgroup per CU is resident, so nothing overlaps a workgroup's start-up (two exposed load latencies) and its store drain:
+    // give every workgroup ALL the consecutive tiles its CU would get over the rounds of the launch (the staging waves then run ahead
+    // into the next tile while the multiplying waves store the current one).
+    a.tpb = (int)std::min<long long>(std::max<long long>((wgs + GC_WS_SLOTS - 1) / GC_WS_SLOTS, 1), tiles);
+    a.groups = gc::ceil_div(tiles, a.tpb);
+    const long long gx = (long long)a.groups * a.c.B;
+    if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
+    if (gc::probing()) return gc::probe_name("conv_bf16x3_ws_kernel<%d>|up1,down1,k%d", KS, KS);
+    hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    return gc::check_launch("gc_conv2d_bf16x3_f32(ws)");
+}
+
+// the layers the wave-specialised kernel takes: whole 16-channel chunks and 64-channel output blocks, enough chunks per tile to
+// amortise its two-stage start-up, and enough tiles to give every CU a workgroup
+inline bool ws_eligible(const Bf16Args& a) {
+#ifdef GC_NO_WS
+    return false;
+#endif
+    const ConvArgs& c = a.c;
+    if (a.k_per_split || c.K % KCB != 0 || c.N % 64 != 0 || c.K < GC_WS_MIN_K || c.out_w < 32 || c.out_h < 16) return false;
+    const long long wgs = (long long)gc::ceil_div(c.out_w, 32) * gc::ceil_div(c.out_h, 16) * c.B * (c.N / 64);
+    return wgs >= 192;
+}
+
 template <int UP, int DOWN, int KS>
 int dispatch(const Bf16Args& a, hipStream_t s) {
+    if constexpr (UP == 1 && DOWN == 1) {
+        if (ws_eligible(a)) return launch_ws<KS>(a, s);
+    }
     if constexpr (DOWN == 2) {
         // patch extents double: 4-row tiles only
         if (a.c.N <= 32) return launch<1, 4, 1, 1, UP, DOWN, KS>(a, s);

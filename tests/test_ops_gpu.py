@@ -441,6 +441,12 @@ BF16_CASES = CONV_CASES + [
 ]
 
 
+# shapes the wave-specialised kernel takes (conv_bf16x3_ws_kernel: K % 16 == 0, K >= 64, N % 64 == 0, >= 192 tiles x samples x oc blocks):
+# several tiles per workgroup, odd chunk counts, ragged rows (width % 4 != 0), heights that end inside a 16-row tile, 1x1 taps
+WS_CASES = [(3, 64, 128, 130, 190, 3, 1, 1, 1), (2, 80, 64, 257, 259, 3, 1, 1, 1), (2, 128, 192, 100, 132, 1, 1, 1, 0), (4, 256, 256, 64, 96, 3, 1, 1, 1)]
+BF16_CASES = BF16_CASES + WS_CASES
+
+
 @pytest.mark.parametrize('case', BF16_CASES)
 def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
     """Split-bf16 MFMA path: ~5e-6 relative error per layer by construction; assert 5e-5 (parity bound is 1e-3)."""
@@ -454,6 +460,9 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
     so = torch.rand(b, N, generator=gen) + 0.5
     oh, ow = _out_size(h, k, up, down, pad, up > 1), _out_size(w, k, up, down, pad, up > 1)
     geom = ConvGeom(k, k, up, down, pad, pad, oh, ow)
+    if case in WS_CASES:
+        from gan_control_amd.utils.profiling import conv_variant
+        assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_bf16x3_ws_kernel'), 'this shape is meant to reach the wave-specialised kernel'
     for use_scales in (False, True):
         a = (si, so) if use_scales else (None, None)
         ref = emu.conv2d(x.double(), wt.double(), *[None if t is None else t.double() for t in a], geom)
@@ -468,7 +477,7 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
             assert rel_err(out, ref) < 5e-5, ('wgrad', use_scales)
 
 
-EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3][::2]
+EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3 and c not in WS_CASES][::2] + WS_CASES
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
