@@ -37,6 +37,9 @@
 #ifndef GC_MFMA_PRIO
 #define GC_MFMA_PRIO 2
 #endif
+#ifndef GC_PLAIN_SPLIT
+#define GC_PLAIN_SPLIT 1      // dev knob: 0 = leave the scale-and-split arithmetic to the compiler (it forms packed fp32 instructions)
+#endif
 #ifndef GC_WS_MIN_K
 #define GC_WS_MIN_K 64      // input channels from which the wave-specialised forward kernel takes over
 #endif
@@ -91,6 +94,39 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
         wh[u] = *reinterpret_cast<uint4*>(&h);
         wl[u] = *reinterpret_cast<uint4*>(&l);
     }
+}
+
+// Eight values with one scale EACH (a channel-last patch unit: eight channels of one pixel) -> hi / lo bf16 units.  Plain v_mul_f32 /
+// v_sub_f32 by asm: left to itself the compiler pairs neighbouring channels into v_pk_mul_f32 / v_pk_add_f32, and packed fp32 does not
+// run under another wave's MFMA (profiles/pmc_r01.md, co-issue table) -- in the wave-specialised kernel the staging wave shares its SIMD
+// with two multiplying waves, so every packed instruction is time taken from the matrix pipe.
+template <bool SCALED>
+__device__ __forceinline__ void split8s(const float (&v)[8], const float (&sc)[8], uint4* h, uint4* l) {
+    bf16x8 hh, ll;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        float f = v[q];
+#if GC_PLAIN_SPLIT
+        if (SCALED) asm("v_mul_f32 %0, %1, %2" : "=v"(f) : "v"(v[q]), "v"(sc[q]));
+#else
+        if (SCALED) f = v[q] * sc[q];
+#endif
+        const __bf16 t = (__bf16)f;
+        hh[q] = t;
+        const float tf = (float)t;
+        float dlo;
+#if GC_PLAIN_SPLIT
+        // the low part of a scaled value is taken from the EXACT product (one fused multiply-subtract), so the rounding of v * sc to fp32
+        // is captured as well -- what the compiler's own contraction of `v * sc - hi` does
+        if (SCALED) asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(dlo) : "v"(v[q]), "v"(sc[q]), "v"(tf));
+        else        asm("v_sub_f32 %0, %1, %2" : "=v"(dlo) : "v"(f), "v"(tf));
+#else
+        dlo = f - tf;
+#endif
+        ll[q] = (__bf16)dlo;
+    }
+    *h = *reinterpret_cast<uint4*>(&hh);
+    *l = *reinterpret_cast<uint4*>(&ll);
 }
 
 template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
@@ -270,19 +306,18 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
                 const int rbase = kgl * PLANE + tk.row * C::RP;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    bf16x8 h, l;
+                    float v[8];
 #pragma unroll
                     for (int q = 0; q < 8; ++q) {
                         const unsigned raw = i == 0 ? preg[j][q].x : (i == 1 ? preg[j][q].y : (i == 2 ? preg[j][q].z : preg[j][q].w));
-                        const float v = (!decltype(masked)::value || i < inrow) ? __uint_as_float(raw) * sc[q] : 0.f;
-                        const __bf16 hh = (__bf16)v;
-                        h[q] = hh;
-                        l[q] = (__bf16)(v - (float)hh);
+                        v[q] = (!decltype(masked)::value || i < inrow) ? __uint_as_float(raw) : 0.f;
                     }
+                    uint4 h, l;
+                    split8s<true>(v, sc, &h, &l);        // plain (un-packed) multiplies and subtractions: see split8s
                     if (i < tk.used) {
                         const int u = rbase + C::ucol(tk.col + i);
-                        p_h[u] = *reinterpret_cast<uint4*>(&h);
-                        GC_LO(p_l[u] = *reinterpret_cast<uint4*>(&l);)
+                        p_h[u] = h;
+                        GC_LO(p_l[u] = l;)
                     }
                 }
             }
@@ -410,28 +445,6 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
 //  * A 16-row tile halves the weight staging and the halo rows (18 / 16 instead of 10 / 8) per MFMA.
 //  * Ordering of the LDS-DMA data: the staging wave waits vmcnt(0) before the barrier, the multiplying waves read the stage after it;
 //    a stage is rewritten one full item after its last read (the barrier in between retires the reads).
-// Eight values with one scale EACH (a channel-last patch unit: eight channels of one pixel) -> hi / lo bf16 units.  Plain v_mul_f32 /
-// v_sub_f32 by asm: left to itself the compiler pairs neighbouring channels into v_pk_mul_f32 / v_pk_add_f32, and packed fp32 does not
-// run under another wave's MFMA (profiles/pmc_r01.md, co-issue table) -- in the wave-specialised kernel the staging wave shares its SIMD
-// with two multiplying waves, so every packed instruction is time taken from the matrix pipe.
-template <bool SCALED>
-__device__ __forceinline__ void split8s(const float (&v)[8], const float (&sc)[8], uint4* h, uint4* l) {
-    bf16x8 hh, ll;
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        float f = v[q];
-        if (SCALED) asm("v_mul_f32 %0, %1, %2" : "=v"(f) : "v"(v[q]), "v"(sc[q]));
-        const __bf16 t = (__bf16)f;
-        hh[q] = t;
-        const float tf = (float)t;
-        float dlo;
-        asm("v_sub_f32 %0, %1, %2" : "=v"(dlo) : "v"(f), "v"(tf));
-        ll[q] = (__bf16)dlo;
-    }
-    *h = *reinterpret_cast<uint4*>(&hh);
-    *l = *reinterpret_cast<uint4*>(&ll);
-}
-
 // LDS-DMA of one 1 KiB row: lane l copies 16 bytes from its own global address to (wave-uniform LDS address) + 16 l.  M0 carries the LDS
 // address and is compiler-reserved: saved and restored inside the statement (cdna guide, "M0 ... write it in the same statement").
 __device__ __forceinline__ void glds16(const void* gsrc, const void* lds_row) {
@@ -1369,18 +1382,17 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
         const int ubase = kgl_p * PLANE + t_row * PWD + t_col;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            bf16x8 h, l;
+            float v[8];
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const unsigned raw = i == 0 ? preg[q].x : (i == 1 ? preg[q].y : (i == 2 ? preg[q].z : preg[q].w));
-                const float v = i < inrow ? __uint_as_float(raw) * sc[q] : 0.f;
-                const __bf16 hh = (__bf16)v;
-                h[q] = hh;
-                l[q] = (__bf16)(v - (float)hh);
+                v[q] = i < inrow ? __uint_as_float(raw) : 0.f;
             }
+            uint4 h, l;
+            split8s<true>(v, sc, &h, &l);        // plain (un-packed) multiplies and subtractions: see split8s
             if (i < t_used) {
-                p_h[ubase + i] = *reinterpret_cast<uint4*>(&h);
-                GC_LO(p_l[ubase + i] = *reinterpret_cast<uint4*>(&l);)
+                p_h[ubase + i] = h;
+                GC_LO(p_l[ubase + i] = l;)
             }
         }
     };
