@@ -246,17 +246,18 @@ def main():
                 out['roofline'] = roofline_of(summ, elapsed)
                 name = out['roofline']['kernel']
                 ach, peak, split = out['roofline']['achieved'], out['roofline']['peak'], name.startswith('conv_bf16x3')
-                traffic_file = os.path.join(REPO, 'profiles', 'pmc_r01_traffic.json')
-                if os.path.exists(traffic_file):      # separate rocprofv3 --pmc passes (tools/pmc_mix.py), launch-weighted over this kernel's shape mix
-                    pmc = json.load(open(traffic_file))
+                # separate rocprofv3 --pmc passes (tools/pmc_mix.py), launch-weighted over this kernel's shape mix; newest round first
+                for traffic_file in sorted((f for f in os.listdir(os.path.join(REPO, 'profiles')) if f.startswith('pmc_r') and f.endswith('_traffic.json')), reverse=True):
+                    pmc = json.load(open(os.path.join(REPO, 'profiles', traffic_file)))
                     if pmc.get('kernel') == name:
                         out['roofline']['traffic'] = pmc['traffic_bytes_per_launch']
                         out['roofline']['traffic_unit'] = 'bytes/launch'
-                        out['roofline']['traffic_source'] = pmc['source']
+                        out['roofline']['traffic_source'] = pmc['source'] + ' (profiles/%s)' % traffic_file
+                        break
                 if split:
                     out['roofline']['note'] = ('achieved = ALGORITHMIC flops/s; the split-bf16 kernel issues 3 bf16 MFMAs per product, '
                                                'so the matrix pipes do 3x this (frac of bf16 peak spent = %.3f) and frac <= 1/3 by construction; '
-                                               'per-shape PMC traffic: profiles/pmc_r01_traffic.json, profiles/pmc_r01.md' % (3 * ach / peak))
+                                               'per-shape PMC traffic: profiles/pmc_r*_traffic.json, profiles/pmc_r01.md' % (3 * ach / peak))
             fir = summ.get('fir44_tile_kernel')
             if fir:
                 ach = fir['work'] / (fir['total_ms'] * 1e-3) / 1e9

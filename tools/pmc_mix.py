@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Launch the shape mix of the bench's dominant convolution kernel (conv_bf16x3_kernel<1,4,2,2>, 3x3 stride 1), two launches per
-shape in a fixed order -- the target of the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes.  `--parse <fetch dir> <write dir> <out.json>`
+"""Launch the shape mix of the bench's dominant convolution kernel (round 2: conv_bf16x3_ws_kernel<3>; round 1: conv_bf16x3_kernel<1,4,2,2>,
+3x3 stride 1), two launches per shape in a fixed order -- the target of the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes.  `--parse <fetch dir> <write dir> <out.json>`
 pairs the kernel's dispatches with MIX in order, keeps the second launch of each shape and writes the launch-weighted traffic.
 
 MIX = (batch, channels, resolution, launches per 16 training iterations), from tools/shape_profile.py on the FFHQ-1024 step.
@@ -8,7 +8,8 @@ MIX = (batch, channels, resolution, launches per 16 training iterations), from t
 import csv, glob, json, os, sys
 MIX = [(4, 64, 512, 84), (4, 128, 256, 84), (4, 256, 128, 84), (4, 512, 64, 84), (8, 64, 512, 32), (8, 128, 256, 32), (8, 256, 128, 32), (8, 512, 64, 32),
        (2, 64, 512, 16), (2, 128, 256, 16), (2, 256, 128, 16)]
-KERNEL = 'conv_bf16x3_kernel<1, 4, 2, 2, 1, 1, 3>'
+KERNEL = os.environ.get('PMC_KERNEL', 'conv_bf16x3_ws_kernel<3>')                 # substring of the rocprofv3 kernel name
+KERNEL_LABEL = os.environ.get('PMC_KERNEL_LABEL', 'conv_bf16x3_ws_kernel<3>|up1,down1,k3')     # the name bench.py reports
 
 
 def run():
@@ -50,7 +51,7 @@ def parse(fdir, wdir, out):
                      'algorithmic_bytes': algo, 'traffic_over_algorithmic': (read_b + write_b) / algo})
         tot += launches * (read_b + write_b); n += launches
         print(f'B{b} {c:4d}ch @{res:4d}: read {read_b / 2**20:8.1f} MiB  write {write_b / 2**20:8.1f} MiB  algorithmic {algo / 2**20:8.1f} MiB  x{(read_b + write_b) / algo:5.2f}')
-    json.dump({'kernel': 'conv_bf16x3_kernel<1,4,2,2>|up1,down1,k3', 'traffic_bytes_per_launch': tot / n,
+    json.dump({'kernel': KERNEL_LABEL, 'traffic_bytes_per_launch': tot / n,
                'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/pmc_mix.py; FETCH_SIZE doubled (16-byte-per-lane loads); '
                          'fabric-side bytes (Infinity-Cache hits included), launch-weighted over the shape mix of the FFHQ-1024 step', 'shapes': rows}, open(out, 'w'), indent=1)
     print('launch-weighted traffic per launch: %.1f MiB' % (tot / n / 2**20))
