@@ -22,6 +22,21 @@ _FORK_TORGB = os.environ.get('GANCONTROL_FORK_TORGB', '0') == '1'         # off 
 from .op import _backend
 from .op import (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, upfirdn2d_bias_act, conv2d_gradfix, modulated_conv2d,
                  modulated_conv2d_act)
+from .op.modulated_conv import demod_coefficients
+# The style path (26 modulation GEMMs, 18 demodulation GEMMs and the elementwise algebra around them: ~150 launches of a few
+# microseconds on [B, 512] tensors per generator pass, three times that in its backward and second-order passes) on a SIDE STREAM:
+# it depends on the latents and the weights only, so it runs next to the convolutions instead of between them.  Autograd runs
+# every backward node on the stream of its forward, so the backward and double-backward of the path overlap in the same way.
+_STYLE_STREAM = os.environ.get('GANCONTROL_STYLE_STREAM', '0') == '1'     # measured: no gain while the launch path is the bottleneck
+_side_streams = {}
+
+
+def style_stream(device):
+    """The side stream of the style path on ``device`` (one per device, created on first use)."""
+    st = _side_streams.get(device)
+    if st is None:
+        st = _side_streams[device] = torch.cuda.Stream(device=device)
+    return st
 
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
 
@@ -153,6 +168,12 @@ class ModulatedConv2d(nn.Module):
         return (f'{self.__class__.__name__}({self.in_channel}, {self.out_channel}, {self.kernel_size}, '
                 f'upsample={self.upsample}, downsample={self.downsample})')
 
+    def styles(self, style):
+        """(s, d): the modulation factors and the demodulation coefficients of this layer for the latent ``style``."""
+        s = self.modulation(style)
+        d = demod_coefficients(self.weight, s, self.scale) if self.demodulate else None
+        return s, d
+
     def forward(self, input, style):
         s = self.modulation(style)
         if self.upsample:
@@ -199,8 +220,10 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, input, style, noise=None):
+    def forward(self, input, style, noise=None, mod=None):
+        """mod: (s, d) computed ahead of time by ``conv.styles(style)`` (Generator.forward's style path)."""
         conv = self.conv
+        s_pre, d_pre = mod if mod is not None else (None, None)
         if noise is not None and noise.shape[0] == 1 and input.shape[0] > 1:
             # the registered [1, 1, h, w] buffers of randomize_noise=False broadcast over the batch (gan_model.py:343-345)
             noise = noise.expand(input.shape[0], -1, -1, -1)
@@ -211,12 +234,13 @@ class StyledConv(nn.Module):
                 pad = conv.padding
                 noise = input.new_empty(b, 1, h + 2 * pad - conv.kernel_size + 1, w + 2 * pad - conv.kernel_size + 1).normal_()
             act = self.activate
-            return modulated_conv2d_act(input, conv.weight, conv.modulation(style), act.bias, noise, self.noise.weight,
+            return modulated_conv2d_act(input, conv.weight, s_pre if mod is not None else conv.modulation(style), act.bias, noise, self.noise.weight,
                                         demodulate=conv.demodulate, padding=conv.padding,
-                                        negative_slope=act.negative_slope, act_scale=act.scale)
+                                        negative_slope=act.negative_slope, act_scale=act.scale, demod=d_pre)
         if _FUSE_EPILOGUE and conv.upsample:
             # transposed conv, then Blur -> noise -> bias + leaky-ReLU in one launch (the activation runs in the FIR's epilogue)
-            out = modulated_conv2d(input, conv.weight, conv.modulation(style), demodulate=conv.demodulate, upsample=True, apply_blur=False)
+            out = modulated_conv2d(input, conv.weight, s_pre if mod is not None else conv.modulation(style), demodulate=conv.demodulate, upsample=True,
+                                   apply_blur=False, demod=d_pre)
             if noise is None:
                 b, _, h, w = out.shape
                 p0, p1 = conv.blur.pad
@@ -244,7 +268,7 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, out_channels, 1, style_dim, demodulate=False, conv_transpose=conv_transpose)
         self.bias = nn.Parameter(torch.zeros(1, out_channels, 1, 1))
 
-    def forward(self, input, style, skip=None, fork=False):
+    def forward(self, input, style, skip=None, fork=False, mod=None):
         """fork=True returns (rgb, input') where input' is `input` for its second consumer (the next up-sampling layer): that
         consumer's gradient is then added inside this layer's input-gradient kernel instead of by a separate pass."""
         conv = self.conv
@@ -255,7 +279,7 @@ class ToRGB(nn.Module):
             return (out, input) if fork else out
         # 1x1 modulated conv + bias + up-sampled skip in ONE launch: the two adds run in the convolution's epilogue
         up = self.upsample(skip) if skip is not None else None
-        return modulated_conv2d(input, conv.weight, conv.modulation(style), demodulate=conv.demodulate, padding=conv.padding,
+        return modulated_conv2d(input, conv.weight, mod[0] if mod is not None else conv.modulation(style), demodulate=conv.demodulate, padding=conv.padding,
                                 bias=self.bias, residual=up, fork=fork)
 
 
@@ -378,20 +402,56 @@ class Generator(nn.Module):
         out = self.input(latent)
         # one unbind instead of 26 slices: its backward is a single stack, a slice's backward is a zero-fill + add of the whole latent
         lat = latent.unbind(1)
-        out = self.conv1(out, lat[0], noise=noise[0])
+        mods = self._style_path(lat)
+        out = self.conv1(out, lat[0], noise=noise[0], mod=mods(0))
         # every StyledConv output feeds ToRGB and the next up-sampling layer: ToRGB forks it (see ToRGB.forward)
-        rgb = (lambda m, x, w, sk: m(x, w, sk, fork=True)) if _FORK_TORGB else (lambda m, x, w, sk: (m(x, w, sk), x))
-        skip, out = rgb(self.to_rgb1, out, lat[1], None)
-        i = 1
+        rgb = (lambda m, x, w, sk, md: m(x, w, sk, fork=True, mod=md)) if _FORK_TORGB else (lambda m, x, w, sk, md: (m(x, w, sk, mod=md), x))
+        skip, out = rgb(self.to_rgb1, out, lat[1], None, mods(1))
+        i, j = 1, 2
         for up_conv, conv, n1, n2, to_rgb in zip(self.convs[::2], self.convs[1::2], noise[1::2], noise[2::2], self.to_rgbs):
-            out = up_conv(out, lat[i], noise=n1)
-            out = conv(out, lat[i + 1], noise=n2)
-            skip, out = rgb(to_rgb, out, lat[i + 2], skip)
+            out = up_conv(out, lat[i], noise=n1, mod=mods(j))
+            out = conv(out, lat[i + 1], noise=n2, mod=mods(j + 1))
+            skip, out = rgb(to_rgb, out, lat[i + 2], skip, mods(j + 2))
             i += 2
+            j += 3
         image = skip
         if return_grad:
             return image, self.g_path_regularize_grad(image, latent)
         return image, (latent if return_latents else None)
+
+    def _style_path(self, lat):
+        """(s, d) of every modulated convolution in execution order -- conv1, to_rgb1, then (up-sampling conv, conv, to_rgb) per
+        resolution -- computed ahead of the image path on the side stream.  Returns ``mods(j)``: the pair of layer j, after making the
+        current stream wait for it."""
+        layers, idx = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)], 1
+        for up_conv, conv, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
+            layers += [(up_conv.conv, idx), (conv.conv, idx + 1), (to_rgb.conv, idx + 2)]
+            idx += 2
+        dev = lat[0].device
+        if not (_STYLE_STREAM and dev.type == 'cuda'):
+            pairs = [m.styles(lat[i]) for m, i in layers]
+            return lambda j: pairs[j]
+        main, side = torch.cuda.current_stream(dev), style_stream(dev)
+        if side == main:
+            pairs = [m.styles(lat[i]) for m, i in layers]
+            return lambda j: pairs[j]
+        side.wait_stream(main)                       # the latents (and the last weight update) are ready
+        pairs, events = [], []
+        with torch.cuda.stream(side):
+            for m, i in layers:
+                s, d = m.styles(lat[i])
+                for t in (s, d):
+                    if t is not None:
+                        t.record_stream(main)        # consumed by convolution launches on the main stream
+                ev = torch.cuda.Event()
+                ev.record(side)
+                pairs.append((s, d))
+                events.append(ev)
+
+        def mods(j):
+            torch.cuda.current_stream(dev).wait_event(events[j])
+            return pairs[j]
+        return mods
 
     @staticmethod
     def g_path_regularize_grad(fake_img, latents, dim_1_shape=1, pl_noise=None):

@@ -232,7 +232,7 @@ class _ModWGrad(Function):
 
 
 def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=None, blur_pad=None, padding=None, apply_blur=True,
-                     bias=None, residual=None, fork=False):
+                     bias=None, residual=None, fork=False, demod=None):
     """x [B,IC,H,W]; weight [1,OC,IC,k,k] (the reference parameter layout); s [B,IC] = modulation(style).
 
     plain:    conv2d(padding = k // 2)                                    gan_model.py:325-329
@@ -240,7 +240,8 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
     """
     _, oc, ic, k, _ = weight.shape
     scale = 1.0 / math.sqrt(ic * k * k)
-    d = demod_coefficients(weight, s, scale) if demodulate else None
+    # demod: the coefficients computed by the caller ahead of time (Generator.forward's style path on its side stream)
+    d = (demod if demod is not None else demod_coefficients(weight, s, scale)) if demodulate else None
     if upsample:
         if bias is not None or residual is not None or fork:
             raise NotImplementedError('modulated_conv2d: bias / residual / fork are built for the plain branch only')
@@ -257,11 +258,11 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
     return _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow), None if bias is None else bias.reshape(-1).contiguous(), residual, bool(fork))
 
 
-def modulated_conv2d_act(x, weight, s, bias, noise, noise_weight, demodulate=True, padding=None, negative_slope=0.2, act_scale=2 ** 0.5):
+def modulated_conv2d_act(x, weight, s, bias, noise, noise_weight, demodulate=True, padding=None, negative_slope=0.2, act_scale=2 ** 0.5, demod=None):
     """modulated_conv2d (plain branch) -> + noise_weight * noise -> FusedLeakyReLU(bias), in one kernel launch."""
     _, oc, ic, k, _ = weight.shape
     scale = 1.0 / math.sqrt(ic * k * k)
-    d = demod_coefficients(weight, s, scale) if demodulate else None
+    d = (demod if demod is not None else demod_coefficients(weight, s, scale)) if demodulate else None
     pad = k // 2 if padding is None else padding
     w_t = kernel_layout(weight.view(oc, ic, k, k), scale)
     oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1

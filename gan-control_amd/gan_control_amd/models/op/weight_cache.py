@@ -7,7 +7,11 @@ however, only changes when the optimiser steps, while one training iteration use
 input gradient over the interleaved fake / real batch; R1; the G forward of the D step and of the G step, ...).
 
 The cache is keyed on the ROOT tensor (the parameter, or the leaf a test passes in) and its autograd version counter
-(every in-place update -- Adam, ``load_state_dict``, EMA -- bumps it), so an entry can never be stale.  Derived tensors
+(in-place updates through the dispatcher -- ``copy_``, ``load_state_dict``, foreach / single-tensor optimisers -- bump it).
+The version counter alone is NOT enough: the FUSED optimisers (``Adam(fused=True)``, the default on the device) update parameters
+without bumping it, and so does anything that writes through ``.data`` (the EMA of trainers/utils.py, the reference's own
+``accumulate``).  Every ``Optimizer.step`` therefore drops the whole cache (a global post-step hook registered below), and
+``invalidate()`` is what code that writes through ``.data`` must call (``accumulate`` does).  Derived tensors
 register their storage address, which lets a derivation of a derivation (``adj(w_t)``, ``pack(adj(w_t))``) find its
 root without any attribute travelling through ``save_for_backward``.  The cache owns the derived tensors while they
 are valid, so a registered address cannot be re-used by another live tensor.  Results are bit-identical to
@@ -83,3 +87,15 @@ def derive(src, op, make):
 def clear():
     for rid in list(_roots):
         _drop(rid)
+
+
+invalidate = clear      # the name for callers that changed a weight behind the version counter's back (``.data`` writes)
+
+
+def _after_optimizer_step(optimizer, args, kwargs):
+    clear()
+
+
+# every torch optimiser, whichever implementation (fused kernels do not touch the version counters)
+from torch.optim.optimizer import register_optimizer_step_post_hook as _register      # noqa: E402
+_register(_after_optimizer_step)

@@ -16,6 +16,7 @@ nn.DataParallel; the config dictionary keeps the reference's JSON schema (config
 """
 import copy
 import math
+import os
 
 import torch
 from torch import autograd, optim
@@ -126,7 +127,7 @@ class GeneratorTrainer:
         # now that the replicas are identical.  Python's ``random`` (style-mixing coin, inject index) stays in lock-step:
         # those are one draw per step for the whole global batch in the reference too.
         torch.manual_seed(seed * 1000 + self.rank + 1)
-        self.mean_path_length = 0
+        self.mean_path_length = torch.zeros((), device=self.device)       # a persistent device scalar, updated in place
         self.ada = AdaptiveAugmentState(tc['augment'], self.device)        # generator_trainer.py:333-339
         self.accum = 0.5 ** (tc['batch'] / tc['g_moving_average'])
         self.stats = {}
@@ -178,7 +179,7 @@ class GeneratorTrainer:
         self.g_optim.load_state_dict(ckpt['g_optim'])
         self.d_optim.load_state_dict(ckpt['d_optim'])
         if 'mean_path_length' in ckpt:
-            self.mean_path_length = torch.tensor(ckpt['mean_path_length'], device=self.device)
+            self._mean_path_length_tensor().fill_(float(ckpt['mean_path_length']))
 
     # -- losses (names and maths of the reference's static methods) ------------------------------
     @staticmethod
@@ -229,6 +230,10 @@ class GeneratorTrainer:
 
     # -- discriminator ----------------------------------------------------------------------------
     def discriminator_step(self, mini_noise_inputs, mini_real_inputs, noise=None):
+        self._discriminator_step(mini_noise_inputs, mini_real_inputs, noise=noise)
+        self._ada_update()
+
+    def _discriminator_step(self, mini_noise_inputs, mini_real_inputs, noise=None):
         self.stats['d_loss'] = 0
         self.discriminator.zero_grad(set_to_none=True)
         n = len(mini_real_inputs)
@@ -248,6 +253,8 @@ class GeneratorTrainer:
         self._fill_missing_grads(self.discriminator, ())          # zeros are the same on every rank: nothing to reduce
         self.d_optim.step()
         self.last_real_pred = real_pred.detach()
+
+    def _ada_update(self):
         # ADA statistic on the last mini-batch's real predictions (generator_trainer.py:669-688), summed over ranks; tracked
         # on every D step like the reference, p only moves when augmentation is enabled
         reduce_sum = (lambda t: ddp.all_reduce_mean_(t).mul_(ddp.world_size())) if ddp.is_dist() else None
@@ -353,7 +360,9 @@ class GeneratorTrainer:
             self.g_reducer.begin(sync=(k == n - 1), phase='pl')
             fake_img, latent = self.generator(zk, noise=noise, return_latents=True)
             grad = Generator.g_path_regularize_grad(fake_img, latent, pl_noise=pl_noise)
-            path_loss, self.mean_path_length, path_lengths = self.g_path_regularize_grad(grad, self.mean_path_length, reduce_mean=reduce_mean)
+            mpl = self._mean_path_length_tensor()
+            path_loss, new_mean, path_lengths = self.g_path_regularize_grad(grad, mpl, reduce_mean=reduce_mean)
+            mpl.copy_(new_mean)
             path_loss = path_loss / n
             weighted = tc['path_regularize'] * tc['g_reg_every'] * path_loss
             if tc['path_batch_shrink']:
@@ -378,6 +387,11 @@ class GeneratorTrainer:
         if i % tc['g_reg_every'] == 0:
             self.generator_regularize_step(noise=noise)
         accumulate(self.g_ema_module, self.g_module, self.accum)
+
+    def _mean_path_length_tensor(self):
+        if not torch.is_tensor(self.mean_path_length):          # callers may reset it with a plain number
+            self.mean_path_length = torch.full((), float(self.mean_path_length), device=self.device)
+        return self.mean_path_length
 
     # -- one iteration ------------------------------------------------------------------------------
     def train_iteration(self, i, real_img):

@@ -19,6 +19,8 @@ def accumulate(model1, model2, decay=0.999):
     src = [source[n].data for n in names]
     torch._foreach_mul_(dst, decay)
     torch._foreach_add_(dst, src, alpha=1 - decay)
+    from ..models.op import weight_cache
+    weight_cache.invalidate()       # ``.data`` writes do not bump the version counters the cache of derived weight forms is keyed on
 
 
 def requires_grad(model, flag=True):

@@ -68,6 +68,68 @@ def test_misc_modules(emu_backend):
     oc.check_misc('cpu')
 
 
+def _fused_step_conv_check(device):
+    """A FUSED optimiser step and a ``.data`` write do not bump the autograd version counter the cache of derived weight forms is keyed
+    on: the next forward must still see the new weights (regression: the cache served the weights of the first iteration for ever)."""
+    from gan_control_amd.models.op import conv2d_gradfix, weight_cache
+    from gan_control_amd.trainers.utils import accumulate
+    weight_cache.clear()
+    gen = torch.Generator().manual_seed(3)
+    conv = torch.nn.Conv2d(5, 6, 3, bias=False).to(device)                  # only a holder of a [6, 5, 3, 3] parameter
+    with torch.no_grad():
+        conv.weight.copy_(torch.randn(6, 5, 3, 3, generator=gen))
+    x = torch.randn(2, 5, 8, 8, generator=gen).to(device)
+    fwd = lambda w: conv2d_gradfix.conv2d(x, w, padding=1, weight_scale=0.5)
+    opt = torch.optim.Adam(conv.parameters(), lr=0.1, fused=True)
+    fwd(conv.weight).square().sum().backward()
+    version = conv.weight._version
+    opt.step()
+    y_cached = fwd(conv.weight).detach()
+    weight_cache.ENABLED, prev = False, weight_cache.ENABLED
+    try:
+        y_fresh = fwd(conv.weight).detach()
+    finally:
+        weight_cache.ENABLED = prev
+    assert torch.equal(y_cached, y_fresh), 'stale derived weights after a fused optimiser step (version counter %d -> %d)' % (version, conv.weight._version)
+    # the EMA writes through .data (trainers/utils.py::accumulate, like the reference's): same requirement
+    ema = torch.nn.Conv2d(5, 6, 3, bias=False).to(device)
+    before = fwd(ema.weight).detach()
+    accumulate(ema, conv, 0.5)
+    after = fwd(ema.weight).detach()
+    weight_cache.ENABLED, prev = False, weight_cache.ENABLED
+    try:
+        fresh = fwd(ema.weight).detach()
+    finally:
+        weight_cache.ENABLED = prev
+    assert torch.equal(after, fresh) and not torch.equal(after, before)
+    weight_cache.clear()
+
+
+def test_weight_cache_survives_fused_optimizer_and_data_writes(emu_backend):
+    _fused_step_conv_check('cpu')
+
+
+def test_training_with_and_without_weight_cache(emu_backend):
+    """Three full iterations (fused Adam, EMA) with the cache of derived weight forms on and off: the same parameters, bit for bit."""
+    from gan_control_amd.models.op import weight_cache
+    out = []
+    for enabled in (True, False):
+        weight_cache.clear()
+        weight_cache.ENABLED, prev = enabled, weight_cache.ENABLED
+        try:
+            from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
+            tr = GeneratorTrainer(default_config(16, 4), device='cpu', seed=0, fused_adam=True)
+            real = tr.synthetic_batch()
+            for i in range(3):
+                tr.train_iteration(i, real)
+            out.append({k: v.clone() for k, v in list(tr.generator.state_dict().items()) + list(tr.discriminator.state_dict().items())})
+        finally:
+            weight_cache.ENABLED = prev
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]), k
+    weight_cache.clear()
+
+
 @pytest.mark.parametrize('name', ['ffhq', 'metfaces', 'afhq'])
 def test_trainer_from_shipped_config(name, emu_backend):
     oc.check_config_ingestion('cpu', name, size=16, batch=4)

@@ -627,6 +627,13 @@ def test_headline_iteration_bf16x3_vs_f32():
             assert abs(float(a[phase][n]) - ref) <= tol * max(ref, 1e-3 * total), (phase, n, float(a[phase][n]), ref)
 
 
+def test_weight_cache_survives_fused_optimizer_and_data_writes_gpu():
+    """Fused Adam (the device default) and the EMA's ``.data`` writes do not bump version counters: the cache of derived weight forms
+    must be dropped by the optimiser hook / accumulate (regression: training ran on the first iteration's convolution weights)."""
+    from test_ops_emulated import _fused_step_conv_check
+    _fused_step_conv_check(DEV)
+
+
 def test_split_fc_gpu():
     oc.check_split_fc(DEV)
 
