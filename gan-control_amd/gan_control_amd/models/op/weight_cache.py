@@ -10,7 +10,7 @@ The cache is keyed on the ROOT tensor (the parameter, or the leaf a test passes 
 (in-place updates through the dispatcher -- ``copy_``, ``load_state_dict``, foreach / single-tensor optimisers -- bump it).
 The version counter alone is NOT enough: the FUSED optimisers (``Adam(fused=True)``, the default on the device) update parameters
 without bumping it, and so does anything that writes through ``.data`` (the EMA of trainers/utils.py, the reference's own
-``accumulate``).  Every ``Optimizer.step`` therefore drops the whole cache (a global post-step hook registered below), and
+``accumulate``).  Every ``Optimizer.step`` therefore drops what was derived from that optimiser's parameters (a global post-step hook registered below), and
 ``invalidate()`` is what code that writes through ``.data`` must call (``accumulate`` does).  Derived tensors
 register their storage address, which lets a derivation of a derivation (``adj(w_t)``, ``pack(adj(w_t))``) find its
 root without any attribute travelling through ``save_for_backward``.  The cache owns the derived tensors while they
@@ -89,11 +89,19 @@ def clear():
         _drop(rid)
 
 
-invalidate = clear      # the name for callers that changed a weight behind the version counter's back (``.data`` writes)
+def invalidate(tensors=None):
+    """Drop what was derived from ``tensors`` (parameters whose storage was written behind the version counter's back: ``.data`` writes,
+    fused optimiser kernels); everything when called without arguments."""
+    if tensors is None:
+        return clear()
+    for t in tensors:
+        _drop(id(t))
 
 
 def _after_optimizer_step(optimizer, args, kwargs):
-    clear()
+    # only the parameters this optimiser owns: the other network's derived forms stay valid across this step
+    for group in optimizer.param_groups:
+        invalidate(group['params'])
 
 
 # every torch optimiser, whichever implementation (fused kernels do not touch the version counters)

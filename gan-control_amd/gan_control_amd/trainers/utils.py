@@ -20,7 +20,7 @@ def accumulate(model1, model2, decay=0.999):
     torch._foreach_mul_(dst, decay)
     torch._foreach_add_(dst, src, alpha=1 - decay)
     from ..models.op import weight_cache
-    weight_cache.invalidate()       # ``.data`` writes do not bump the version counters the cache of derived weight forms is keyed on
+    weight_cache.invalidate(target.values())       # ``.data`` writes do not bump the version counters the cache of derived weight forms is keyed on
 
 
 def requires_grad(model, flag=True):
