@@ -225,6 +225,19 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
     if (threadIdx.x == 0) partial[(size_t)plane * chunks + j] = r;
 }
 
+// out[r] = (sum_j partial[r][j]) / den[r], a zero denominator counting as one (a measure-zero modulation factor: the gradient it
+// scales is zero as well).  Second stage of the plane reductions and the division by the modulation / demodulation factor in ONE launch
+// (it was a reduction + compare + select + divide, four launches of a few microseconds each, per factor per layer per backward pass).
+__global__ __launch_bounds__(256) void rows_sum_div_kernel(const float* __restrict__ partial, const float* __restrict__ den, float* __restrict__ out,
+                                                           int rows, int chunks) {
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    if (r >= rows) return;
+    float acc = 0.f;
+    for (int j = 0; j < chunks; ++j) acc += partial[(size_t)r * chunks + j];      // fixed order: deterministic
+    if (den) { const float d = den[r]; acc = acc / (d == 0.f ? 1.f : d); }
+    out[r] = acc;
+}
+
 // stage 1: partial[c][b * chunks + j] = sum over chunk j of plane (b, c); fixed summation order
 __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ x, float* __restrict__ partial,
                                                           int batch, int channels, int64_t inner, int chunks, int64_t chunk_len) {
@@ -380,6 +393,13 @@ extern "C" int gc_bias_act_bwd_reduce_f32(const float* dy, const float* y_ref, c
                                           float* psum, float* pdot, int batch, int channels, int64_t inner,
                                           float slope, float gain, gc_stream_t stream) {
     return gc_bias_act_bwd_reduce_self_f32(dy, y_ref, noise, nullptr, nullptr, dx, psum, pdot, nullptr, batch, channels, inner, slope, gain, stream);
+}
+
+extern "C" int gc_rows_sum_div_f32(const float* partial, const float* den, float* out, int rows, int chunks, gc_stream_t stream) {
+    if (!partial || !out) return gc::fail(GC_ERR_BAD_ARG, "gc_rows_sum_div_f32: null pointer");
+    if (rows <= 0 || chunks <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_rows_sum_div_f32: bad extents");
+    hipLaunchKernelGGL(rows_sum_div_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, partial, den, out, rows, chunks);
+    return gc::check_launch("gc_rows_sum_div_f32");
 }
 
 extern "C" int gc_plane_dot_f32(const float* a, const float* b, float* partial, int planes, int64_t inner, gc_stream_t stream) {

@@ -23,6 +23,7 @@ from .op import _backend
 from .op import (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, upfirdn2d_bias_act, conv2d_gradfix, modulated_conv2d,
                  modulated_conv2d_act)
 from .op.modulated_conv import demod_coefficients
+from .op.linear import scaled_mm, equal_linear
 # The style path (26 modulation GEMMs, 18 demodulation GEMMs and the elementwise algebra around them: ~150 launches of a few
 # microseconds on [B, 512] tensors per generator pass, three times that in its backward and second-order passes) on a SIDE STREAM:
 # it depends on the latents and the weights only, so it runs next to the convolutions instead of between them.  Autograd runs
@@ -127,9 +128,9 @@ class EqualLinear(nn.Module):
         # the mapping network and the 26 style modulations are ~400 tiny launches per iteration otherwise
         x = input.reshape(-1, input.shape[-1])
         if self.bias is None:
-            out = torch.mm(x, self.weight.t()) * self.scale
+            out = scaled_mm(x, self.weight.t(), self.scale)
         else:
-            out = torch.addmm(self.bias, x, self.weight.t(), beta=self.lr_mul, alpha=self.scale)
+            out = equal_linear(x, self.weight, self.bias, self.scale, self.lr_mul)
         out = out.reshape(*input.shape[:-1], self.weight.shape[0])
         if self.activation:
             if self.bias is None:
@@ -387,7 +388,7 @@ class Generator(nn.Module):
         if not input_is_latent:
             styles = [self.style(s) for s in styles]
         if noise is None:
-            noise = [None] * self.num_layers if randomize_noise else \
+            noise = self._draw_noise(styles[0].shape[0], styles[0].device) if randomize_noise else \
                 [getattr(self.noises, f'noise_{i}') for i in range(self.num_layers)]
         if truncation < 1:
             styles = [truncation_latent + truncation * (s - truncation_latent) for s in styles]
@@ -418,6 +419,18 @@ class Generator(nn.Module):
         if return_grad:
             return image, self.g_path_regularize_grad(image, latent)
         return image, (latent if return_latents else None)
+
+    def _draw_noise(self, batch, device):
+        """The per-layer noise maps of one forward pass (NoiseInjection draws `image.new_empty(b, 1, h, w).normal_()` per layer,
+        gan_model.py:340-345) as ONE normal_() over a flat buffer and 17 views of it: one launch instead of one per layer."""
+        sizes = [4 * 4] + [(2 ** res) ** 2 for res in range(3, self.log_size + 1) for _ in range(2)]
+        flat = torch.empty(batch * sum(sizes), device=device, dtype=self.input.input.dtype).normal_()
+        out, o = [], 0
+        for n in sizes:
+            side = int(math.isqrt(n))
+            out.append(flat[o:o + batch * n].view(batch, 1, side, side))
+            o += batch * n
+        return out
 
     def _style_path(self, lat):
         """(s, d) of every modulated convolution in execution order -- conv1, to_rgb1, then (up-sampling conv, conv, to_rgb) per

@@ -7,6 +7,7 @@ the product never does.
 """
 import contextlib
 import ctypes
+import math
 import os
 from collections import namedtuple
 
@@ -225,8 +226,25 @@ class HipBackend:
         _lib.check(rc, 'gc_bias_act_bwd_reduce_adjoint_f32')
         return g_dy, g_yref, pgb, pgn
 
-    def plane_dot(self, a, b):
-        """[B, C, *] x [B, C, *] -> [B, C]: sum over the trailing dims of a * b."""
+    def rows_sum_div(self, partial, den=None):
+        """[..., J] -> [...]: sum over the last dim, divided by ``den`` (same leading shape; a zero divisor counts as one)."""
+        dev = _lib.require_cuda_f32(partial, den)
+        lead = partial.shape[:-1]
+        rows, chunks = int(math.prod(lead)), int(partial.shape[-1])
+        out = torch.empty(lead, dtype=partial.dtype, device=dev)
+        if rows == 0:
+            return out
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = _lib.load().gc_rows_sum_div_f32(_lib.ptr(partial), _lib.ptr(den), _lib.ptr(out), rows, chunks, _lib.stream_of(partial))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_rows_sum_div_f32')
+        return out
+
+    def plane_dot(self, a, b, den=None):
+        """[B, C, *] x [B, C, *] -> [B, C]: sum over the trailing dims of a * b (divided by den [B, C], a zero divisor counting as one)."""
         dev = _lib.require_cuda_f32(a, b)
         batch, ch = a.shape[0], a.shape[1]
         inner = a.numel() // (batch * ch)
@@ -240,7 +258,9 @@ class HipBackend:
         finally:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_plane_dot_f32')
-        return partial.sum(2) if chunks > 1 else partial.reshape(batch, ch)
+        if den is None and chunks == 1:
+            return partial.reshape(batch, ch)
+        return self.rows_sum_div(partial, None if den is None else den.contiguous())
 
     def weight_layout(self, src, taps, k, n, src_stride, dst_shape, dst_stride, flip, scale):
         """dst[t',k,n] = scale * src[t,k,n] between two strided weight layouts; see gc_weight_layout_f32."""

@@ -30,11 +30,28 @@ from .weight_layout import kernel_layout
 from .upfirdn2d import upfirdn2d
 
 
+class _WeightSq(Function):
+    """[OC, IC, k, k] -> sum over the taps of W^2, [OC, IC].  The value only changes with the weight, so it is computed once per weight
+    version (weight_cache) instead of in every forward pass of every iteration phase; the backward is the closed form 2 g W."""
+
+    @staticmethod
+    def forward(ctx, w):
+        from . import weight_cache
+        ctx.save_for_backward(w)
+        return weight_cache.derive(w, ('wsq',), lambda: w.detach().pow(2).sum([2, 3])).detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        w, = ctx.saved_tensors
+        return (2.0 * g)[:, :, None, None] * w
+
+
 def demod_coefficients(weight, s, scale, eps=1e-8):
     """d[b,oc] = rsqrt(sum_{ic,k} (scale * W[oc,ic,k] * s[b,ic])^2 + eps); weight is [1,OC,IC,k,k], s is [B,IC]."""
-    wsq = weight.view(weight.shape[1:]).pow(2).sum([2, 3])     # [OC, IC]  (view, not weight[0]: its backward is free)
-    # scale^2 * (s^2 @ wsq^T) + eps as ONE GEMM call (alpha, bias epilogue) instead of GEMM + two elementwise launches
-    return torch.rsqrt(torch.addmm(_eps_vector(s, wsq.shape[0], eps), s.pow(2), wsq.t(), alpha=scale * scale))
+    wsq = _WeightSq.apply(weight.view(weight.shape[1:]))       # [OC, IC]  (view, not weight[0]: its backward is free)
+    # scale^2 * (s^2 @ wsq^T) + eps as ONE GEMM call (alpha, bias epilogue) in every direction of differentiation (op/linear.py)
+    from .linear import equal_linear
+    return torch.rsqrt(equal_linear(s.pow(2), wsq, _eps_vector(s, wsq.shape[0], eps), scale * scale, 1.0))
 
 
 _EPS_VECTORS = {}
@@ -48,27 +65,67 @@ def _eps_vector(like, n, eps):
     return t
 
 
-def _safe(scale):
-    """Divisor for the scale gradients; an exactly-zero factor (measure zero) would otherwise give 0/0."""
-    return torch.where(scale == 0, 1.0, scale)
-
-
-class _PlaneDot(Function):
-    """[B,C,H,W] x [B,C,H,W] -> [B,C] on gc_plane_dot_f32."""
+class _SafeDiv(Function):
+    """num / den over [B, C] vectors, a zero ``den`` (measure zero: the gradient it scales is zero as well) counting as one.
+    One launch (gc_rows_sum_div_f32 with one chunk) instead of compare + select + divide; closed under differentiation."""
 
     @staticmethod
-    def forward(ctx, a, b):
-        ctx.save_for_backward(a, b)
+    def forward(ctx, num, den):
+        out = _backend.get().rows_sum_div(num.contiguous().unsqueeze(-1), den.contiguous())
+        ctx.save_for_backward(den, out)
         ctx.set_materialize_grads(False)
-        return _backend.get().plane_dot(a.contiguous(), b.contiguous())
+        return out
 
     @staticmethod
     def backward(ctx, g):
         if g is None:
             return None, None
-        a, b = ctx.saved_tensors
-        g4 = g[:, :, None, None]
-        return (g4 * b if ctx.needs_input_grad[0] else None), (g4 * a if ctx.needs_input_grad[1] else None)
+        den, out = ctx.saved_tensors
+        gq = _SafeDiv.apply(g, den)
+        return (gq if ctx.needs_input_grad[0] else None), (-(gq * out) if ctx.needs_input_grad[1] else None)
+
+
+class _SumDiv(Function):
+    """partial [B, C, J] -> sum_J partial / den [B, C] (zero-safe as _SafeDiv): the second stage of a plane reduction and the division
+    by the modulation / demodulation factor in one launch."""
+
+    @staticmethod
+    def forward(ctx, partial, den):
+        out = _backend.get().rows_sum_div(partial.contiguous(), den.contiguous())
+        ctx.save_for_backward(den, out)
+        ctx.chunks = partial.shape[-1]
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None
+        den, out = ctx.saved_tensors
+        gq = _SafeDiv.apply(g, den)
+        return (gq.unsqueeze(-1).expand(*gq.shape, ctx.chunks) if ctx.needs_input_grad[0] else None), (-(gq * out) if ctx.needs_input_grad[1] else None)
+
+
+class _PlaneDot(Function):
+    """[B,C,H,W] x [B,C,H,W] -> [B,C] on gc_plane_dot_f32, divided by ``den`` [B,C] when given (zero-safe, in the reduction's second stage)."""
+
+    @staticmethod
+    def forward(ctx, a, b, den=None):
+        out = _backend.get().plane_dot(a.contiguous(), b.contiguous(), den)
+        ctx.has_den = den is not None
+        ctx.save_for_backward(a, b, den if den is not None else a.new_empty(0), out if den is not None else a.new_empty(0))
+        ctx.set_materialize_grads(False)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None
+        a, b, den, out = ctx.saved_tensors
+        gq = _SafeDiv.apply(g, den) if ctx.has_den else g
+        g4 = gq[:, :, None, None]
+        return (g4 * b if ctx.needs_input_grad[0] else None), (g4 * a if ctx.needs_input_grad[1] else None), \
+            (-(gq * out) if ctx.has_den and ctx.needs_input_grad[2] else None)
 
 
 class _ModConv(Function):
@@ -115,14 +172,14 @@ class _ModConv(Function):
         if need_si:
             # d/dsi sees the convolution only, not the forked gradient that was added in the epilogue
             conv_part = gx if (gfork is None or not need[0]) else gx - gfork
-            gsi = _PlaneDot.apply(x, conv_part) / _safe(si)
+            gsi = _PlaneDot.apply(x, conv_part, si)
         if ctx.has_so and need[3]:
             conv_part = y
             if ctx.has_res:
                 conv_part = conv_part - res
             if ctx.has_bias:
                 conv_part = conv_part - bias.reshape(1, -1, 1, 1)
-            gso = _PlaneDot.apply(gy, conv_part) / _safe(so)
+            gso = _PlaneDot.apply(gy, conv_part, so)
         if ctx.has_bias and need[5] and _backend.want_param_grads():
             from .fused_act import _channel_sum
             gb = _channel_sum(gy)
@@ -175,7 +232,7 @@ class _ModConvAct(Function):
             if has_noise and need[6]:
                 gnw = pdot.sum().reshape(noise_w.shape)
             if want_so:
-                gso = pself.sum(2) / _safe(so)
+                gso = _SumDiv.apply(pself, so)
         else:
             g_pre = _BiasActGrad.apply(gy, out, slope, gain)
         need_si = has_si and need[2]
@@ -184,7 +241,7 @@ class _ModConvAct(Function):
         if need[1]:
             gw = _mod_weight_grad(x, g_pre, si, so, g)
         if need_si:
-            gsi = _PlaneDot.apply(x, gx) / _safe(si)
+            gsi = _PlaneDot.apply(x, gx, si)
         return (gx if need[0] else None), gw, gsi, gso, gb, None, gnw, None, None, None
 
 
@@ -225,9 +282,9 @@ class _ModWGrad(Function):
         if ctx.needs_input_grad[1] or need_so:
             ggy = _ModConv.apply(x, ggw.contiguous(), si, so, g)
         if need_si:
-            gsi = _PlaneDot.apply(x, gx) / _safe(si)
+            gsi = _PlaneDot.apply(x, gx, si)
         if need_so:
-            gso = _PlaneDot.apply(gy, ggy) / _safe(so)
+            gso = _PlaneDot.apply(gy, ggy, so)
         return (gx if ctx.needs_input_grad[0] else None), (ggy if ctx.needs_input_grad[1] else None), gsi, gso, None
 
 

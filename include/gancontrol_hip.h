@@ -136,6 +136,12 @@ int gc_bias_act_bwd_reduce_adjoint_f32(const float* ggx, const float* cs, const 
  * Gradients of the per-sample modulation / demodulation factors of K3 (sum_hw x * dx and sum_hw dy * y). */
 int gc_plane_dot_f32(const float* a, const float* b, float* partial, int planes, int64_t inner, gc_stream_t stream);
 
+/* out[r] = (sum_j partial[r*chunks + j]) / den[r]; den may be NULL (plain sum), a zero denominator counts as one.
+ * The second stage of gc_plane_dot_f32 / the pself sums of gc_bias_act_bwd_reduce_self_f32 fused with the division by the modulation
+ * (in_scale) / demodulation (out_scale) factor: `sum_hw x * dx / s` of ModulatedConv2d's weight algebra (gan_model.py:284-293) in one
+ * launch.  chunks = 1 is an element-wise safe division of two [rows] vectors. */
+int gc_rows_sum_div_f32(const float* partial, const float* den, float* out, int rows, int chunks, gc_stream_t stream);
+
 /* Per-channel sum over batch and inner dims: out[c] = sum_{b,i} x[b,c,i]  (bias gradient).
  * Deterministic two-stage reduction; workspace must hold gc_channel_sum_workspace() bytes. */
 size_t gc_channel_sum_workspace(int batch, int channels, int64_t inner);

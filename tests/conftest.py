@@ -149,8 +149,12 @@ class EmulatedBackend:
         g_dy = total * torch.where(y_ref > 0, torch.full_like(y_ref, gain), torch.full_like(y_ref, gain * slope))
         return g_dy, g_yref, pgb, pgn
 
-    def plane_dot(self, a, b):
-        return (a * b).reshape(a.shape[0], a.shape[1], -1).sum(2)
+    def rows_sum_div(self, partial, den=None):
+        out = partial.sum(-1)
+        return out if den is None else out / torch.where(den == 0, torch.ones_like(den), den)
+
+    def plane_dot(self, a, b, den=None):
+        return self.rows_sum_div((a * b).reshape(a.shape[0], a.shape[1], -1), den)
 
     def channel_sum(self, x):
         return x.sum([d for d in range(x.ndim) if d != 1])
