@@ -43,6 +43,9 @@
 #ifndef GC_WS_MIN_K
 #define GC_WS_MIN_K 64      // input channels from which the wave-specialised forward kernel takes over
 #endif
+#ifndef GC_WG_XCD
+#define GC_WG_XCD 1          // XCD-aware block order of the weight-gradient kernels (0: hardware order)
+#endif
 #ifndef GC_WS_SLOTS
 #define GC_WS_SLOTS 256     // workgroups the wave-specialised kernel keeps resident: one per CU
 #endif
@@ -706,6 +709,22 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
 #else
 #define WG_LOAD(r, off, imm) buf_load_u128(r, off, imm)
 #endif
+// XCD-aware block order for the weight-gradient grids (k blocks x n blocks x pixel splits).  Workgroups go to the eight XCDs round-robin
+// in linear block order, so the 8 x 8 (k, n) blocks of ONE pixel split -- which all stream the same X and dY tiles -- land on eight
+// different L2s and every tile crosses the fabric eight times.  Re-deal the linear ids so that each XCD gets a contiguous range of
+// (x fastest, then y, then z): the blocks that share operands then share one L2.
+struct WgBlock { int x, y, z; };
+template <bool XCD>
+__device__ __forceinline__ WgBlock wg_block() {
+  if (XCD) {
+    const unsigned gx = gridDim.x, gy = gridDim.y, total = gx * gy * gridDim.z;
+    unsigned l = blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z);
+    if (total % 8 == 0) l = (l % 8) * (total / 8) + l / 8;
+    return {(int)(l % gx), (int)((l / gx) % gy), (int)(l / (gx * gy))};
+  }
+    return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+}
+
 struct WgArgs {
     const float* x; const float* dy; const float* si; const float* so; float* ws;
     int B, K, N, in_h, in_w, out_h, out_w, pad_y, pad_x;
@@ -769,7 +788,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wp = wave % WP, wn = (wave / WP) % WN, wk = wave / (WP * WN);
-    const int k0 = blockIdx.x * KT, n0 = blockIdx.y * NTL, split = blockIdx.z;
+    const WgBlock blk = wg_block<false>();      // measured: no gain at stride 1 (same-box A/B within +-3 %)
+    const int k0 = blk.x * KT, n0 = blk.y * NTL, split = blk.z;
 
     f32x16 acc[NT];
 #pragma unroll
@@ -1016,7 +1036,8 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
     const int wn = wave & 1, wk = WK == 2 ? wave >> 1 : 0, wp = WK == 2 ? 0 : wave >> 1;
-    const int k0 = blockIdx.x * KT, n0 = blockIdx.y * NTL, split = blockIdx.z;
+    const WgBlock blk = wg_block<GC_WG_XCD != 0>();      // stride 2: +3..10 % (same-box A/B)
+    const int k0 = blk.x * KT, n0 = blk.y * NTL, split = blk.z;
 
     f32x16 acc[NT];
 #pragma unroll
