@@ -46,12 +46,6 @@
 #ifndef GC_WG_XCD
 #define GC_WG_XCD 1          // XCD-aware block order of the weight-gradient kernels (0: hardware order)
 #endif
-#ifndef GC_WGWS_ABL
-#define GC_WGWS_ABL 0        // dev ablations of wgrad_bf16x3_ws_kernel (wrong results): 1 no staging, 4 fragments read once
-#endif
-#ifndef GC_WG_WS_SLOTS
-#define GC_WG_WS_SLOTS 256    // workgroup slots the wave-specialised weight-gradient launch is split for (one per CU)
-#endif
 #ifndef GC_WS_SLOTS
 #define GC_WS_SLOTS 256     // workgroups the wave-specialised kernel keeps resident: one per CU
 #endif
@@ -1259,248 +1253,22 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Wave-specialised weight gradient (stride 1, 64 k x 64 n blocks): the structure of conv_bf16x3_ws_kernel applied to
-// wgrad_bf16x3_kernel<2,2,1,TR,KS>.  One workgroup of 8 waves per CU at 256 registers: four MULTIPLYING waves (one per SIMD, each a
-// 32 k x 32 n block for all taps = 144 accumulators, fragments of the next kernel row prefetched while the 27 MFMAs of the current one
-// issue) and four STAGING waves (loads of tile t + 2 in flight while tile t + 1 is split and written) over two LDS stages, one barrier
-// per tile.  In the one-role kernel a tile costs ~8900 cycles of which the MFMAs are 3456 (weight gradients).
-template <int TR, int KS>
-__global__ __launch_bounds__(512) void wgrad_bf16x3_ws_kernel(WgArgs p) {
-    using C = WgCfg<2, 2, 1, TR, KS>;
-    constexpr int KT = C::KT, NTL = C::NTL, PH = C::PH, XU = C::XU, YU = C::YU, NT = C::NT;
-    constexpr int STAGE = 2 * (KT * C::CSX + NTL * C::CSY);          // units: [x hi | x lo | dy hi | dy lo]
-    static_assert(2 * STAGE * 16 <= 158 * 1024, "two stages fit the LDS");
-    __shared__ uint4 smem[2 * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const WgBlock blk = wg_block<false>();
-    const int k0 = blk.x * KT, n0 = blk.y * NTL, split = blk.z;
-
-    const int tiles_per_sample = p.tiles_x * p.tiles_y;
-    const int total_tiles = tiles_per_sample * p.B;
-    const int t_begin = split * p.tiles_per_split;
-    const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
-    const int items = t_end - t_begin;
-    const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
-
-    if (wave >= 4) {
-        // ---------------- staging waves ----------------
-        const int st = tid - 256;
-        constexpr unsigned OUTSIDE = 0x80000000u;
-        unsigned xdesc[C::NPX], ydesc[C::NPY];       // LDS unit offset | unit column << 16 | patch row << 20 | channel << 24 | idle lane << 31
-#pragma unroll
-        for (int j = 0; j < C::NPX; ++j) {
-            const int u = st + 256 * j;
-            const int xu = u % XU, row = u / XU;
-            const int r = row % PH, kk = min(row / PH, KT - 1);
-            const bool live = u < C::NXU && k0 + kk < p.K;
-            xdesc[j] = (unsigned)(kk * C::CSX + r * XU + xu) | (unsigned)xu << 16 | (unsigned)r << 20 | (unsigned)kk << 24 | (live ? 0u : OUTSIDE);
-        }
-#pragma unroll
-        for (int j = 0; j < C::NPY; ++j) {
-            const int u = st + 256 * j;
-            const int yu = u % YU, row = u / YU;
-            const int r = row % TR, nn = min(row / TR, NTL - 1);
-            const bool live = u < C::NYU && n0 + nn < p.N;
-            ydesc[j] = (unsigned)(nn * C::CSY + r * YU + yu) | (unsigned)yu << 16 | (unsigned)r << 20 | (unsigned)nn << 24 | (live ? 0u : OUTSIDE);
-        }
-        const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
-        const bool scaled = p.si != nullptr || p.so != nullptr;
-        struct Regs { float4 x[C::NPX][2], y[C::NPY][2]; float sx[C::NPX], sy[C::NPY]; };
-        Regs ra, rb;
-        auto tile_origin = [&](int tile, int& b, int& oy0, int& ox0) {
-            b = tile / tiles_per_sample;
-            const int rem = tile - b * tiles_per_sample;
-            oy0 = (rem % p.tiles_y) * TR; ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows
-        };
-        auto loads = [&](Regs& rg, int tile) {
-            int b, oy0, ox0;
-            tile_origin(min(tile, total_tiles - 1), b, oy0, ox0);            // the tile past the last one: a valid address, converted into a stage nobody reads
-            const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
-            const int xoff = (k0 * xchan + iy0 * p.in_w + ix0) * 4, yoff = (n0 * ychan + oy0 * p.out_w + ox0) * 4;
-            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
-            const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
-#pragma unroll
-            for (int j = 0; j < C::NPX; ++j) {
-                const unsigned d = (unsigned)opaque((int)xdesc[j]);
-                const int r = (int)((d >> 20) & 15u), kk = (int)((d >> 24) & 63u);
-                const int lin = kk * (xchan * 4) + r * (p.in_w * 4) + (int)((d >> 16) & 15u) * 32 + xoff;
-                const unsigned off = ((int)d >= 0 && (unsigned)(iy0 + r) < (unsigned)p.in_h) ? (unsigned)max(lin, 0) : OUTSIDE;
-                rg.x[j][0] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 0));
-                rg.x[j][1] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 16));
-                rg.sx[j] = (scaled && p.si) ? p.si[(size_t)b * p.K + min(k0 + kk, p.K - 1)] : 1.f;
-            }
-#pragma unroll
-            for (int j = 0; j < C::NPY; ++j) {
-                const unsigned d = (unsigned)opaque((int)ydesc[j]);
-                const int r = (int)((d >> 20) & 15u), nn = (int)((d >> 24) & 63u);
-                const int lin = nn * (ychan * 4) + r * (p.out_w * 4) + (int)((d >> 16) & 15u) * 32 + yoff;
-                const unsigned off = ((int)d >= 0 && oy0 + r < p.out_h) ? (unsigned)lin : OUTSIDE;
-                rg.y[j][0] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 0));
-                rg.y[j][1] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 16));
-                rg.sy[j] = (scaled && p.so) ? p.so[(size_t)b * p.N + min(n0 + nn, p.N - 1)] : 1.f;
-            }
-        };
-        auto unit8 = [&](auto scaled_t, const float4 (&r)[2], int col0, int width, float scale, uint4* h, uint4* l) {
-            float v[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
-            if (col0 < 0 || col0 + 8 > width) {      // only lanes whose unit straddles an image border pay for the masks
-#pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = (col0 + q >= 0 && col0 + q < width) ? v[q] : 0.f;
-            }
-            split8<decltype(scaled_t)::value>(v, scale, h, l);
-        };
-        auto convert = [&](Regs& rg, int tile, int buf) {
-            int b, oy0, ox0;
-            tile_origin(min(tile, total_tiles - 1), b, oy0, ox0);
-            uint4* const xh = smem + buf * STAGE;
-            uint4* const xl = xh + KT * C::CSX;
-            uint4* const yh = xl + KT * C::CSX;
-            uint4* const yl = yh + NTL * C::CSY;
-            auto body = [&](auto scaled_t) {
-#pragma unroll
-                for (int j = 0; j < C::NPX; ++j) {
-                    const unsigned d = (unsigned)opaque((int)xdesc[j]);
-                    uint4 h, l;
-                    unit8(scaled_t, rg.x[j], ox0 - p.pad_x + 8 * (int)((d >> 16) & 15u), p.in_w, rg.sx[j], &h, &l);
-                    if (256 * (j + 1) <= C::NXU || st + 256 * j < C::NXU) { xh[d & 0xffffu] = h; GC_LO(xl[d & 0xffffu] = l;) }
-                }
-#pragma unroll
-                for (int j = 0; j < C::NPY; ++j) {
-                    const unsigned d = (unsigned)opaque((int)ydesc[j]);
-                    uint4 h, l;
-                    unit8(scaled_t, rg.y[j], ox0 + 8 * (int)((d >> 16) & 15u), p.out_w, rg.sy[j], &h, &l);
-                    if (256 * (j + 1) <= C::NYU || st + 256 * j < C::NYU) { yh[d & 0xffffu] = h; GC_LO(yl[d & 0xffffu] = l;) }
-                }
-            };
-            if (scaled) body(std::true_type{}); else body(std::false_type{});
-            // the one unit per sample that was fetched from offset 0 instead of -pad_x (channel 0, image row 0, left halo): its owner rebuilds it
-            if (k0 == 0 && ox0 == 0 && p.pad_x > 0 && oy0 - p.pad_y <= 0 && p.pad_y - oy0 < PH && st == (p.pad_y - oy0) * XU) {
-                const float* row0 = p.x + (size_t)b * p.K * xchan;
-                float v[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) { const int c = q - p.pad_x; v[q] = (c >= 0 && c < p.in_w) ? row0[c] : 0.f; }
-                uint4 h, l;
-                split8(v, (scaled && p.si) ? p.si[(size_t)b * p.K] : 1.f, &h, &l);
-                xh[(p.pad_y - oy0) * XU] = h; GC_LO(xl[(p.pad_y - oy0) * XU] = l;)
-            }
-        };
-        if (items > 0) {
-            loads(ra, t_begin);
-            loads(rb, t_begin + 1);
-            convert(ra, t_begin, 0);
-            __syncthreads();
-            for (int it = 0; it < items; it += 2) {
-                if (!(GC_WGWS_ABL & 1)) { loads(ra, t_begin + it + 2); convert(rb, t_begin + it + 1, 1); }
-                __syncthreads();
-                if (it + 1 >= items) break;
-                if (!(GC_WGWS_ABL & 1)) { loads(rb, t_begin + it + 3); convert(ra, t_begin + it + 2, 0); }
-                __syncthreads();
-            }
-        }
-        return;
-    }
-
-    // ---------------- multiplying waves ----------------
-    const int wn = wave & 1, wk = wave >> 1;
-    f32x16 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-    const int xa = (wk * 32 + l31) * C::CSX + hi, yb_ = (wn * 32 + l31) * C::CSY + hi;
-    if (items > 0) {
-        __syncthreads();                 // stage 0 is staged
-        for (int it = 0; it < items; ++it) {
-            const uint4* const xh = smem + (it & 1) * STAGE;
-            const uint4* const xl = xh + KT * C::CSX;
-            const uint4* const yh = xl + KT * C::CSX;
-            const uint4* const yl = yh + NTL * C::CSY;
-            __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
-            // one "row item" = (pixel step, kernel row): 2 A units (hi, lo) + the B fragment of the step; the next one is fetched before
-            // the 3 * KS MFMAs of the current one issue
-            constexpr int ROWS = 2 * TR * KS;
-            uint4 fa[2][4], fb[2][2];
-            auto fetch = [&](int ri, int set) {
-                const int step = ri / KS, ty = ri % KS;
-                const int r = step >> 1, sx = step & 1;
-                const int o = xa + (r + ty) * XU + 2 * sx;
-                fa[set][0] = xh[o]; GC_LO(fa[set][1] = xl[o];)
-                if (KS == 3) { fa[set][2] = xh[o + 1]; GC_LO(fa[set][3] = xl[o + 1];) }
-                if (ty == 0) { fb[(step & 1)][0] = yh[yb_ + r * YU + 2 * sx]; GC_LO(fb[(step & 1)][1] = yl[yb_ + r * YU + 2 * sx];) }
-            };
-            fetch(0, 0);
-#pragma unroll
-            for (int ri = 0; ri < ROWS; ++ri) {
-                if (ri + 1 < ROWS && !(GC_WGWS_ABL & 4)) fetch(ri + 1, (ri + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                const int step = (GC_WGWS_ABL & 4) ? 0 : ri / KS, ty = ri % KS, set = (GC_WGWS_ABL & 4) ? 0 : ri & 1;
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&fb[step & 1][0]);
-                GC_LO(const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&fb[step & 1][1]);)
-#ifdef GC_SINGLE
-                const bf16x8 bl = bh;
-#endif
-#pragma unroll
-                for (int tx = 0; tx < KS; ++tx) {
-                    const uint4 uh = shift_px(fa[set][0], KS == 3 ? fa[set][2] : fa[set][0], tx);
-                    const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh);
-#ifdef GC_SINGLE
-                    const bf16x8 al = ah;
-#else
-                    const uint4 ul = shift_px(fa[set][1], KS == 3 ? fa[set][3] : fa[set][1], tx);
-                    const bf16x8 al = *reinterpret_cast<const bf16x8*>(&ul);
-#endif
-                    f32x16 c = acc[ty * KS + tx];
-                    GC_MFMA3(c, ah, al, bh, bl);
-                    acc[ty * KS + tx] = c;
-                }
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_s_setprio(0);
-            __syncthreads();
-        }
-    }
-    float* out = p.ws + (size_t)split * NT * p.K * p.N;
-    const int n = n0 + wn * 32 + l31;
-    if (n < p.N) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = k0 + wk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (k < p.K) out[((size_t)t * p.K + k) * p.N + n] = acc[t][r];
-            }
-        }
-    }
-}
-
 struct WgPlan { int small, ct, kt, tr, splits, tiles_per_split, tiles_x, tiles_y; };
 
 // 64k x 64n tiles (2 rows per pixel tile) when both channel counts reach 64, else 32k x 32n tiles with the four
 // waves splitting the pixel steps of a 4-row tile
-// the layers the wave-specialised weight-gradient kernel takes: the 64 k x 64 n stride-1 plan
-inline bool wg_ws_eligible(const gc_conv_desc* d) {
-#ifdef GC_NO_WS_WG
-    return false;
-#endif
-    return d->down == 1 && d->in_ch >= 64 && d->out_ch >= 64;
-}
-
 WgPlan plan_wg(const gc_conv_desc* d) {
     WgPlan pl;
     pl.small = d->down == 1 && !(d->in_ch >= 64 && d->out_ch >= 64);
     pl.ct = pl.small ? 32 : 64;
     pl.kt = (d->down == 2 && d->in_ch < 64) ? 32 : pl.ct;      // stride 2 with 32..63 input channels: 32k x 64n tiles
     pl.tr = pl.small ? 6 : 2;          // 32 x 32 channel tiles: six rows (81 MFMAs per wave between barriers, 65 KB of LDS; four rows: 923 vs 880 us at 32 -> 32 @1024^2)
-    if (d->down == 2 && pl.kt == 64) pl.tr = 1;     // stride 2, 64k x 64n: one output row per tile keeps two workgroups per CU (two-row tiles need 110 KB of LDS: 130 vs 171 TFLOP/s)
+    if (d->down == 2 && pl.kt == 64) pl.tr = 1;     // stride 2, 64k x 64n: one output row per tile keeps two workgroups per CU (two-row tiles need 110 KB of LDS: 130 vs 171 TFLOP/s)     // stride 2, small planes: one output row per tile, two workgroups per CU
     pl.tiles_x = gc::ceil_div(d->out_w, 32);
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
     const int ctiles = gc::ceil_div(d->in_ch, pl.kt) * gc::ceil_div(d->out_ch, pl.ct);
-    // workgroup slots of the launch: two per CU for the one-role kernels (256 registers), one per CU for the wave-specialised kernel
-    int want = gc::ceil_div(wg_ws_eligible(d) ? GC_WG_WS_SLOTS : 512, ctiles);
+    int want = gc::ceil_div(512, ctiles);      // one workgroup per CU is resident (512 registers per lane): two rounds
     if (want > total) want = total;
     if (want < 1) want = 1;
     pl.tiles_per_split = gc::ceil_div(total, want);
@@ -2045,12 +1813,8 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
             hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 3>), grid, dim3(256), dyn, s, a);
         } else
 #endif
-        if (wg_ws_eligible(d)) {
-            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_ws_kernel<2, 3>), grid, dim3(512), 0, s, a);
-            else            hipLaunchKernelGGL((wgrad_bf16x3_ws_kernel<2, 1>), grid, dim3(512), 0, s, a);
-        }
-        else if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 3>), grid, dim3(256), 0, s, a);
-        else                 hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 1>), grid, dim3(256), 0, s, a);
+        if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 3>), grid, dim3(256), 0, s, a);
+        else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 1>), grid, dim3(256), 0, s, a);
     }
     rc = gc::check_launch("gc_conv2d_wgrad_bf16x3_f32");
     if (rc || pl.splits == 1) return rc;
