@@ -46,6 +46,15 @@
 #ifndef GC_WG_XCD
 #define GC_WG_XCD 1          // XCD-aware block order of the weight-gradient kernels (0: hardware order)
 #endif
+#ifndef GC_WS_MIN_K32
+#define GC_WS_MIN_K32 32    // ... and its 32-output-channel variant
+#endif
+#ifndef GC_WS_WIDE_MAX_K
+#define GC_WS_WIDE_MAX_K 64   // input channels up to which the wave-specialised kernel uses 8 x 64 tiles
+#endif
+#ifndef GC_WS_WIDE_CB32
+#define GC_WS_WIDE_CB32 2      // column blocks of the wide tiles of the 32-output-channel variant (4: 4 rows x 128 px)
+#endif
 #ifndef GC_WS_SLOTS
 #define GC_WS_SLOTS 256     // workgroups the wave-specialised kernel keeps resident: one per CU
 #endif
@@ -132,12 +141,12 @@ __device__ __forceinline__ void split8s(const float (&v)[8], const float (&sc)[8
     *l = *reinterpret_cast<uint4*>(&ll);
 }
 
-template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS>
+template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS, int CB = 1>
 struct BCfg {
     static constexpr int OCT = WG_OC * WOC * 32;
-    static constexpr int TPH = WG_PX * WPX;                 // tile rows (each 32-pixel MFMA column block is one row segment)
+    static constexpr int TPH = WG_PX * WPX / CB;            // tile rows (each 32-pixel MFMA column block is one row segment); CB column blocks side by side
     static constexpr int NT1 = UP == 1 ? KS : (KS + UP - 1) / UP;
-    static constexpr int PH = (TPH - 1) * DOWN + NT1, PWD = 31 * DOWN + NT1;
+    static constexpr int PH = (TPH - 1) * DOWN + NT1, PWD = (32 * CB - 1) * DOWN + NT1;
     // Column order of a patch row in LDS.  Stride 2: de-interleaved (even columns, then odd), so that lane l's fragment
     // read of column 2 l + tap is a run of consecutive 16-byte units -- row-major order spent 41 % of the LDS cycles in
     // bank conflicts there (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE), de-interleaved 15 %, kernel -3 %.  Stride 1 stays
@@ -457,12 +466,12 @@ __device__ __forceinline__ void glds16(const void* gsrc, const void* lds_row) {
                  : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
 
-template <int KS>
+template <int KS, int WOC, int CB>
 __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
-    using C = BCfg<1, 8, 2, 2, 1, 1, KS>;
-    constexpr int OCT = 64, TPH = C::TPH, PLANE = C::PLANE, WOC = 2, WPX = 2, NTAP = KS * KS;
+    using C = BCfg<1, 8, WOC, 2, 1, 1, KS, CB>;      // CB = 1: 16 rows x 32 px tiles; CB = 2: 8 rows x 64 px (longer contiguous runs per row: the HBM-bound layers)
+    constexpr int OCT = 32 * WOC, TPH = C::TPH, PLANE = C::PLANE, WPX = 2, NTAP = KS * KS;
     constexpr int STAGE = C::SMEM_UNITS;                 // one stage: [weights hi | weights lo | patch hi | patch lo]
-    static_assert(C::OCT == OCT && C::TPH == 16, "64 oc x 16 rows x 32 px tiles");
+    static_assert(C::OCT == OCT && C::TPH * CB == 16, "(32 | 64) oc x 512 px tiles");
     static_assert(2 * STAGE * 16 + (MAX_K_BF16X3 + KCB + 2 * OCT) * 4 <= 160 * 1024, "two stages fit the 160 KiB of LDS");
     const ConvArgs& p = a.c;
     __shared__ uint4 smem[2 * STAGE];
@@ -502,7 +511,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
         // is never on this wave's critical path (which is then ~300 vector instructions + 16 ds_write_b128 per item).
         uint4 pa[C::NT][8], pb[C::NT][8];
         auto loads = [&](uint4 (&preg)[C::NT][8], int tile, int k0) {
-            const int iy0 = (tile / p.tiles_x) * TPH - p.pad_y, ix0 = (tile % p.tiles_x) * 32 - p.pad_x;
+            const int iy0 = (tile / p.tiles_x) * TPH - p.pad_y, ix0 = (tile % p.tiles_x) * (32 * CB) - p.pad_x;
 #pragma unroll
             for (int j = 0; j < C::NT; ++j) {
                 const typename C::Task tk = C::task_of(tb + 128 * j, lead);
@@ -520,7 +529,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
             const int kk = min(k0, p.K - KCB);          // the item past the last one is converted into a stage nobody reads
             const float4 sa = *reinterpret_cast<const float4*>(&s_si[kk + kgl * 8]), sb = *reinterpret_cast<const float4*>(&s_si[kk + kgl * 8 + 4]);
             const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
-            const int ix0 = (tile % p.tiles_x) * 32 - p.pad_x;
+            const int ix0 = (tile % p.tiles_x) * (32 * CB) - p.pad_x;
             const bool ragged_rows = (p.in_w & 3) != 0 && ix0 + lead + 32 * C::SEG_M + 4 > p.in_w;
             auto body = [&](auto masked, auto scaled) {
 #pragma unroll
@@ -571,7 +580,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     }
 
     // ---------------- multiplying waves ----------------
-    const int wave_px = wave;        // rows 2 wave, 2 wave + 1 of the tile
+    const int wave_row = (wave / CB) * 2, wave_col = (wave % CB) * 32;        // this wave: rows wave_row, wave_row + 1 of column block wave % CB
     f32x16 acc[WOC][WPX];
 #pragma unroll
     for (int i = 0; i < WOC; ++i)
@@ -581,7 +590,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     int boff[WPX];
 #pragma unroll
-    for (int j = 0; j < WPX; ++j) boff[j] = hi * PLANE + (wave_px * WPX + j) * C::RP;
+    for (int j = 0; j < WPX; ++j) boff[j] = hi * PLANE + (wave_row + j) * C::RP + wave_col;
     const int aoff = hi * OCT + l31;
 
     const unsigned oplane = (unsigned)(p.out_h * p.out_w) * 4u;
@@ -589,14 +598,14 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     const EpilogueConsts ec = epilogue_consts(p);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.residual ? p.residual + (size_t)b * p.N * p.out_h * p.out_w : p.y, p.residual ? (unsigned)p.N * oplane : 0u);
     auto finish_tile = [&](int tile) {
-        const int qy0 = (tile / p.tiles_x) * TPH, qx0 = (tile % p.tiles_x) * 32;
+        const int qy0 = (tile / p.tiles_x) * TPH, qx0 = (tile % p.tiles_x) * (32 * CB);
         const int nb = opaque_s(n0);
         // every load of the epilogue (noise, residual) is issued before the first store: a load between two stores waits for the stores
         unsigned voff[WPX];
         float nz[WPX];
 #pragma unroll
         for (int j = 0; j < WPX; ++j) {
-            const int qy = qy0 + wave_px * WPX + j, qx = qx0 + l31;
+            const int qy = qy0 + wave_row + j, qx = qx0 + wave_col + l31;
             const bool inside = qy < p.out_h && qx < p.out_w;
             voff[j] = inside ? (unsigned)(qy * p.out_w + qx) * 4u + (unsigned)(4 * hi) * oplane : OOB;
             nz[j] = (p.noise && inside) ? p.noise[((size_t)b * p.out_h + qy) * p.out_w + qx] : 0.f;
@@ -635,16 +644,21 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
 #else
     constexpr int ROWS = 2 * NTAP * KG;
 #endif
+    // one instruction moves 64 units = 64 / OCT consecutive rows (rows are adjacent in LDS; the halves hold an even number of rows)
+    constexpr int RPI = 64 / OCT, INSTR = ROWS / RPI;
+    static_assert(ROWS % RPI == 0 && (NTAP * KG) % RPI == 0, "row groups do not straddle the hi / lo halves");
     auto weights = [&](int k0, int buf) {
         uint4* const base = smem + buf * STAGE;
 #pragma unroll
-        for (int j = 0; j < (ROWS + 7) / 8; ++j) {
-            const int r = wave + 8 * j;
-            if (8 * j + 7 < ROWS || r < ROWS) {
-                const int half = r / (NTAP * KG), rr = r % (NTAP * KG);
+        for (int j = 0; j < (INSTR + 7) / 8; ++j) {
+            const int q = wave + 8 * j;
+            if (8 * j + 7 < INSTR || q < INSTR) {
+                const int r0 = q * RPI;                                   // first row of the group (wave-uniform)
+                const int half = r0 / (NTAP * KG), rr0 = r0 % (NTAP * KG);
+                const int rr = rr0 + lane / OCT;                          // this lane's row
                 const int t = rr / KG, kg = rr % KG;
-                const uint4* src = (half ? a.wl : a.wh) + ((size_t)(t * a.kgroups + k0 / 8 + kg) * p.N + n0 + lane);
-                glds16(src, base + half * C::WUNITS + rr * OCT);
+                const uint4* src = (half ? a.wl : a.wh) + ((size_t)(t * a.kgroups + k0 / 8 + kg) * p.N + n0 + lane % OCT);
+                glds16(src, base + half * C::WUNITS + rr0 * OCT);
             }
         }
     };
@@ -1570,11 +1584,11 @@ int launch(Bf16Args a, hipStream_t s) {
 }
 
 // wave-specialised kernel (conv_bf16x3_ws_kernel): 64 oc x 16 rows x 32 px tiles, one 12-wave workgroup per CU
-template <int KS>
+template <int KS, int WOC, int CB>
 int launch_ws(Bf16Args a, hipStream_t s) {
-    a.c.tiles_y = gc::ceil_div(a.c.out_h, 16);
-    a.c.tiles_x = gc::ceil_div(a.c.out_w, 32);
-    const int tiles = a.c.tiles_x * a.c.tiles_y, ocb = a.c.N / 64;
+    a.c.tiles_y = gc::ceil_div(a.c.out_h, 16 / CB);
+    a.c.tiles_x = gc::ceil_div(a.c.out_w, 32 * CB);
+    const int tiles = a.c.tiles_x * a.c.tiles_y, ocb = a.c.N / (32 * WOC);
     const long long wgs = (long long)tiles * a.c.B * ocb;
     // One workgroup per CU is resident, so nothing overlaps a workgroup's start-up (two exposed load latencies) and its store drain:
     // give every workgroup ALL the consecutive tiles its CU would get over the rounds of the launch (the staging waves then run ahead
@@ -1583,8 +1597,8 @@ int launch_ws(Bf16Args a, hipStream_t s) {
     a.groups = gc::ceil_div(tiles, a.tpb);
     const long long gx = (long long)a.groups * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
-    if (gc::probing()) return gc::probe_name("conv_bf16x3_ws_kernel<%d>|up1,down1,k%d", KS, KS);
-    hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    if (gc::probing()) return WOC == 2 ? gc::probe_name("conv_bf16x3_ws_kernel<%d>|up1,down1,k%d", KS, KS) : gc::probe_name("conv_bf16x3_ws_kernel<%d,32oc>|up1,down1,k%d", KS, KS);
+    hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
     return gc::check_launch("gc_conv2d_bf16x3_f32(ws)");
 }
 
@@ -1595,15 +1609,21 @@ inline bool ws_eligible(const Bf16Args& a) {
     return false;
 #endif
     const ConvArgs& c = a.c;
-    if (a.k_per_split || c.K % KCB != 0 || c.N % 64 != 0 || c.K < GC_WS_MIN_K || c.out_w < 32 || c.out_h < 16) return false;
-    const long long wgs = (long long)gc::ceil_div(c.out_w, 32) * gc::ceil_div(c.out_h, 16) * c.B * (c.N / 64);
+    const int oct = c.N % 64 == 0 ? 64 : 32;          // 32-channel output blocks for the layers whose N is not a multiple of 64 (the 1024^2 layers: N = 32)
+    if (a.k_per_split || c.K % KCB != 0 || c.N % 32 != 0 || c.K < (oct == 64 ? GC_WS_MIN_K : GC_WS_MIN_K32) || c.out_w < 32 || c.out_h < 16) return false;
+    const long long wgs = (long long)gc::ceil_div(c.out_w, 32) * gc::ceil_div(c.out_h, 16) * c.B * (c.N / oct);
     return wgs >= 192;
 }
 
 template <int UP, int DOWN, int KS>
 int dispatch(const Bf16Args& a, hipStream_t s) {
     if constexpr (UP == 1 && DOWN == 1) {
-        if (ws_eligible(a)) return launch_ws<KS>(a, s);
+        if (ws_eligible(a)) {
+            // wide tiles (8 rows x 64 px) where HBM, not the matrix pipe, bounds the layer: few input channels per output byte
+            const bool wide = a.c.K <= GC_WS_WIDE_MAX_K && a.c.out_w >= 64;
+            if (a.c.N % 64 == 0) return wide ? launch_ws<KS, 2, 2>(a, s) : launch_ws<KS, 2, 1>(a, s);
+            return wide ? (a.c.out_w >= 128 ? launch_ws<KS, 1, GC_WS_WIDE_CB32>(a, s) : launch_ws<KS, 1, 2>(a, s)) : launch_ws<KS, 1, 1>(a, s);
+        }
     }
     if constexpr (DOWN == 2) {
         // patch extents double: 4-row tiles only

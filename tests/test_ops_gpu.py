@@ -443,7 +443,8 @@ BF16_CASES = CONV_CASES + [
 
 # shapes the wave-specialised kernel takes (conv_bf16x3_ws_kernel: K % 16 == 0, K >= 64, N % 64 == 0, >= 192 tiles x samples x oc blocks):
 # several tiles per workgroup, odd chunk counts, ragged rows (width % 4 != 0), heights that end inside a 16-row tile, 1x1 taps
-WS_CASES = [(3, 64, 128, 130, 190, 3, 1, 1, 1), (2, 80, 64, 257, 259, 3, 1, 1, 1), (2, 128, 192, 100, 132, 1, 1, 1, 0), (4, 256, 256, 64, 96, 3, 1, 1, 1)]
+WS_CASES = [(3, 64, 128, 130, 190, 3, 1, 1, 1), (2, 80, 64, 257, 259, 3, 1, 1, 1), (2, 128, 192, 100, 132, 1, 1, 1, 0), (4, 256, 256, 64, 96, 3, 1, 1, 1),
+            (2, 32, 32, 200, 262, 3, 1, 1, 1), (2, 64, 96, 130, 190, 3, 1, 1, 1), (4, 48, 32, 150, 170, 1, 1, 1, 0)]      # ... and its 32-output-channel variant
 BF16_CASES = BF16_CASES + WS_CASES
 
 
