@@ -43,6 +43,10 @@ SIGNATURES = {
     'gc_bias_act_bwd_reduce_adjoint_f32': (_i32, [_vp] * 13 + [_i32, _i32, _i64, _f32, _f32, _vp]),
     'gc_plane_dot_f32': (_i32, [_vp, _vp, _vp, _i32, _i64, _vp]),
     'gc_rows_sum_div_f32': (_i32, [_vp, _vp, _vp, _i32, _i32, _vp]),
+    'gc_conv2d_bn_relu_f32': (_i32, [_vp, _vp, _vp, _vp, _vp] + [_i32] * 13 + [_vp]),
+    'gc_pool2d_f32': (_i32, [_vp, _vp] + [_i32] * 10 + [_vp]),
+    'gc_global_avgpool_f32': (_i32, [_vp, _vp, _i32, _i32, _vp]),
+    'gc_resize_bilinear_f32': (_i32, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _vp]),
     'gc_channel_sum_workspace': (_sz, [_i32, _i32, _i64]),
     'gc_channel_sum_f32': (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _sz, _vp]),
     'gc_conv2d_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),

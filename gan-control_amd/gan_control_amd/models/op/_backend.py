@@ -226,6 +226,50 @@ class HipBackend:
         _lib.check(rc, 'gc_bias_act_bwd_reduce_adjoint_f32')
         return g_dy, g_yref, pgb, pgn
 
+    # -- f-2: forward pass of the FID feature network (inference) ---------------------------------------
+    def conv2d_bn_relu(self, x, w, scale, shift, stride, pad_y, pad_x, relu=True, out=None, chan_off=0):
+        """relu?(scale * conv(x, w) + shift) with w in the reference layout [N, K, kh, kw]; writes channels [chan_off, chan_off + N) of
+        ``out`` when given (a block's concatenated output), else returns a new tensor."""
+        dev = _lib.require_cuda_f32(x, w, scale, shift, out)
+        b, k, h, wd = x.shape
+        n, _, kh, kw = w.shape
+        oh, ow = (h + 2 * pad_y - kh) // stride + 1, (wd + 2 * pad_x - kw) // stride + 1
+        if out is None:
+            out = torch.empty((b, n, oh, ow), dtype=x.dtype, device=dev)
+        if out.shape[0] != b or out.shape[2] != oh or out.shape[3] != ow or not out.is_contiguous():
+            raise ValueError(f'conv2d_bn_relu: output {tuple(out.shape)} does not match [{b}, *, {oh}, {ow}]')
+        rc = _lib.load().gc_conv2d_bn_relu_f32(_lib.ptr(x.contiguous()), _lib.ptr(w.contiguous()), _lib.ptr(scale), _lib.ptr(shift), _lib.ptr(out),
+                                               b, k, n, h, wd, kh, kw, stride, pad_y, pad_x, int(bool(relu)), out.shape[1], chan_off, _lib.stream_of(x))
+        _lib.check(rc, 'gc_conv2d_bn_relu_f32')
+        return out
+
+    def pool2d(self, x, k, stride, pad, mode, out=None, chan_off=0):
+        """mode 'max' | 'avg' (average over the taps inside the image); same channel-offset output convention."""
+        dev = _lib.require_cuda_f32(x, out)
+        b, c, h, wd = x.shape
+        oh, ow = (h + 2 * pad - k) // stride + 1, (wd + 2 * pad - k) // stride + 1
+        if out is None:
+            out = torch.empty((b, c, oh, ow), dtype=x.dtype, device=dev)
+        rc = _lib.load().gc_pool2d_f32(_lib.ptr(x.contiguous()), _lib.ptr(out), b, c, h, wd, k, stride, pad, 0 if mode == 'max' else 1, out.shape[1], chan_off,
+                                       _lib.stream_of(x))
+        _lib.check(rc, 'gc_pool2d_f32')
+        return out
+
+    def global_avgpool(self, x):
+        dev = _lib.require_cuda_f32(x)
+        b, c = x.shape[0], x.shape[1]
+        out = torch.empty((b, c, 1, 1), dtype=x.dtype, device=dev)
+        _lib.check(_lib.load().gc_global_avgpool_f32(_lib.ptr(x.contiguous()), _lib.ptr(out), b * c, x.numel() // max(b * c, 1), _lib.stream_of(x)), 'gc_global_avgpool_f32')
+        return out
+
+    def resize_bilinear(self, x, out_h, out_w, mul=1.0, add=0.0):
+        dev = _lib.require_cuda_f32(x)
+        b, c, h, wd = x.shape
+        out = torch.empty((b, c, out_h, out_w), dtype=x.dtype, device=dev)
+        _lib.check(_lib.load().gc_resize_bilinear_f32(_lib.ptr(x.contiguous()), _lib.ptr(out), b * c, h, wd, out_h, out_w, float(mul), float(add), _lib.stream_of(x)),
+                   'gc_resize_bilinear_f32')
+        return out
+
     def rows_sum_div(self, partial, den=None):
         """[..., J] -> [...]: sum over the last dim, divided by ``den`` (same leading shape; a zero divisor counts as one)."""
         dev = _lib.require_cuda_f32(partial, den)

@@ -312,6 +312,31 @@ int gc_affine_warp_bilinear_f32(const float* x, const float* mat, float* y, int 
 int gc_reflect_pad_f32(const float* x, float* y, int planes, int in_h, int in_w, int left, int right, int top, int bottom,
                        int adjoint, gc_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * f-2  Forward pass of the FID feature network (inference, fp32): src/gan_control/fid_utils/inception.py:17-165 over
+ * overwrite_inception.py.  Replaces BasicConv2d.forward (conv -> BatchNorm(eval) -> ReLU, overwrite_inception.py:424-434), the
+ * F.avg_pool2d / F.max_pool2d calls of the Inception blocks (inception.py:204-305, overwrite_inception.py:252-341), the
+ * nn.MaxPool2d / nn.AdaptiveAvgPool2d of the wrapper (inception.py:92-125) and its F.interpolate + `2 * x - 1` (inception.py:147-154).
+ * ------------------------------------------------------------------------------------------ */
+
+/* y[b, chan_off + n, :, :] = relu?(scale[n] * conv(x, w)[b, n] + shift[n]);  w is [out_ch, in_ch, kh, kw] (the reference layout),
+ * taps up to 7 x 7 (also 1 x 7, 7 x 1, 1 x 3, 3 x 1, 5 x 5), stride 1 or 2, zero padding; scale / shift (the folded BatchNorm) may be
+ * NULL (1 / 0).  The output tensor has out_channels planes per sample: a block's branches write their slices of the concatenation. */
+int gc_conv2d_bn_relu_f32(const float* x, const float* w, const float* scale, const float* shift, float* y,
+                          int batch, int in_ch, int out_ch, int in_h, int in_w, int kh, int kw, int stride, int pad_y, int pad_x,
+                          int relu, int out_channels, int chan_off, gc_stream_t stream);
+
+/* k x k pooling with stride / zero padding; mode 0 = max, 1 = average over the taps inside the image (count_include_pad = False,
+ * the FID patch of inception.py:204-207).  Output at a channel offset as above. */
+int gc_pool2d_f32(const float* x, float* y, int batch, int channels, int in_h, int in_w, int k, int stride, int pad, int mode,
+                  int out_channels, int chan_off, gc_stream_t stream);
+
+/* y[p] = mean(x[p, :]): nn.AdaptiveAvgPool2d((1, 1)) over planes = B * C. */
+int gc_global_avgpool_f32(const float* x, float* y, int planes, int inner, gc_stream_t stream);
+
+/* y = mul * bilinear(x) + add, F.interpolate(mode='bilinear', align_corners=False) semantics. */
+int gc_resize_bilinear_f32(const float* x, float* y, int planes, int in_h, int in_w, int out_h, int out_w, float mul, float add, gc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

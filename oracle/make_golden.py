@@ -685,6 +685,76 @@ def golden_losses():
     print('losses ok')
 
 
+def golden_inception():
+    """The FID feature network from the reference's own classes (fid_utils/inception.py + overwrite_inception.py) on procedurally
+    generated weights.  torchvision is absent here: ``torchvision.models.inception`` is stood in for by the reference's own copy of that
+    file (overwrite_inception.py defines the same Inception{A..E}), the weight download is replaced by the procedural state dict, and the
+    undefined global ``path`` of fid_inception_v3 (inception.py:181-182, a NameError as shipped) is supplied."""
+    import importlib, types
+    ow = importlib.import_module('gan_control.fid_utils.overwrite_inception') if 'torchvision' in sys.modules else None
+    tv = types.ModuleType('torchvision'); tvm = types.ModuleType('torchvision.models'); tvu = types.ModuleType('torchvision.models.utils')
+    with mock.patch.dict(sys.modules, {'torchvision': tv, 'torchvision.models': tvm, 'torchvision.models.utils': tvu}):
+        tvu.load_state_dict_from_url = lambda *a, **k: None
+        tv.models = tvm
+        ow = importlib.import_module('gan_control.fid_utils.overwrite_inception')
+        tvm.inception = ow
+        tvm.inception_v3 = ow.inception_v3
+        ref_inc = importlib.import_module('gan_control.fid_utils.inception')
+    from oracle import inception as oinc
+    holder = {}
+
+    def fake_download(*a, **k):
+        # the state dict fid_inception_v3 loads into the un-wrapped Inception3: procedural values under ITS key names
+        model = ow.inception_v3(num_classes=1008, aux_logits=False, pretrained=False)
+        model.Mixed_5b = ref_inc.FIDInceptionA(192, pool_features=32)
+        model.Mixed_5c = ref_inc.FIDInceptionA(256, pool_features=64)
+        model.Mixed_5d = ref_inc.FIDInceptionA(288, pool_features=64)
+        model.Mixed_6b = ref_inc.FIDInceptionC(768, channels_7x7=128)
+        model.Mixed_6c = ref_inc.FIDInceptionC(768, channels_7x7=160)
+        model.Mixed_6d = ref_inc.FIDInceptionC(768, channels_7x7=160)
+        model.Mixed_6e = ref_inc.FIDInceptionC(768, channels_7x7=192)
+        model.Mixed_7b = ref_inc.FIDInceptionE_1(1280)
+        model.Mixed_7c = ref_inc.FIDInceptionE_2(2048)
+        holder['raw'] = oinc.procedural_inception_fill_(model.state_dict())
+        return holder['raw']
+
+    ref_inc.load_state_dict_from_url = fake_download
+    ref_inc.path = 'unused'
+    torch.manual_seed(5)
+    net = ref_inc.InceptionV3(output_blocks=[0, 1, 2, 3]).eval()
+    net.load_state_dict(oinc.procedural_inception_fill_(net.state_dict()))      # keyed on the WRAPPER's names (blocks.<b>.<i>...), as the tests fill the product
+    sd = {k: v.clone() for k, v in net.state_dict().items()}
+    out = {}
+    gen = torch.Generator().manual_seed(21)
+    for tag, shape in (('a', (2, 3, 64, 48)), ('b', (1, 3, 299, 299))):
+        x = torch.rand(shape, generator=gen)
+        with torch.no_grad():
+            ref = net(x)
+            ora = oinc.inception_features(sd, x, output_blocks=(0, 1, 2, 3))
+        for i, (r, o) in enumerate(zip(ref, ora)):
+            close(o, r, 1e-5, f'inception/{tag}/block{i}')
+        out[f'{tag}/shape'] = np.asarray(shape)          # the input is redrawn in the tests: torch.rand(shape, generator seeded 21), cases in order a, b
+        out[f'{tag}/x_check'] = x.flatten()[:64].clone()
+        out[f'{tag}/pool3'] = ref[3].reshape(shape[0], -1)
+        # the lower blocks are large: a strided sample and the per-channel means pin them
+        for i in range(3):
+            out[f'{tag}/block{i}_mean'] = ref[i].mean((2, 3))
+            out[f'{tag}/block{i}_sample'] = ref[i][:, ::7, ::5, ::3].contiguous()
+    # the wrapper's key names against the un-wrapped checkpoint's (what load_fid_weights of the product maps)
+    wrapped = sorted(k for k in sd if not k.endswith('num_batches_tracked'))
+    out['n_keys'] = np.asarray([len(wrapped)])
+    with torch.no_grad():
+        x = torch.rand(2, 3, 64, 48, generator=torch.Generator().manual_seed(33))
+        no_resize = ref_inc.InceptionV3(output_blocks=[3], resize_input=False, normalize_input=False).eval()
+        no_resize.load_state_dict(oinc.procedural_inception_fill_(no_resize.state_dict()))
+        out['c/x'] = x
+        x_big = torch.nn.functional.interpolate(x, size=(96, 80), mode='bilinear', align_corners=False)
+        out['c/pool3'] = no_resize(x_big)[0].reshape(2, -1)
+        close(oinc.inception_features({k: v for k, v in no_resize.state_dict().items()}, x_big, (3,), False, False)[0], no_resize(x_big)[0], 1e-5, 'inception/c')
+    np.savez_compressed(os.path.join(GOLD, 'inception.npz'), **to_np(out))
+    print('inception ok')
+
+
 def golden_configs():
     """The hot-path fields of the three shipped training configurations (configs/ffhq.json:5-84, metfaces.json, afhq.json:
     numbers and switches, no code) plus what the reference's MiniBatchUtils.get_fc_config (mini_batch_multi_split_utils.py:
@@ -716,7 +786,7 @@ def main():
             'networks': golden_networks, 'step': golden_step,
             # the BASELINE resolutions: ~15 min and ~40 GiB on 8 cores (1024x1024 at batch 4 does not fit this container's 64 GiB)
             'step_512': lambda: golden_step(512, 4, 'step_512'), 'step_1024': lambda: golden_step(1024, 2, 'step_1024'),
-            'augment': golden_augment, 'fid': golden_fid, 'controller': golden_controller, 'configs': golden_configs, 'losses': golden_losses}
+            'augment': golden_augment, 'fid': golden_fid, 'controller': golden_controller, 'configs': golden_configs, 'losses': golden_losses, 'inception': golden_inception}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()
     total = sum(os.path.getsize(os.path.join(GOLD, f)) for f in os.listdir(GOLD))

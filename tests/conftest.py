@@ -149,6 +149,31 @@ class EmulatedBackend:
         g_dy = total * torch.where(y_ref > 0, torch.full_like(y_ref, gain), torch.full_like(y_ref, gain * slope))
         return g_dy, g_yref, pgb, pgn
 
+    def conv2d_bn_relu(self, x, w, scale, shift, stride, pad_y, pad_x, relu=True, out=None, chan_off=0):
+        y = F.conv2d(x, w, None, stride, (pad_y, pad_x))
+        if scale is not None:
+            y = y * scale.reshape(1, -1, 1, 1)
+        if shift is not None:
+            y = y + shift.reshape(1, -1, 1, 1)
+        y = F.relu(y) if relu else y
+        if out is None:
+            return y
+        out[:, chan_off:chan_off + y.shape[1]] = y
+        return out
+
+    def pool2d(self, x, k, stride, pad, mode, out=None, chan_off=0):
+        y = F.max_pool2d(x, k, stride, pad) if mode == 'max' else F.avg_pool2d(x, k, stride, pad, count_include_pad=False)
+        if out is None:
+            return y
+        out[:, chan_off:chan_off + y.shape[1]] = y
+        return out
+
+    def global_avgpool(self, x):
+        return x.mean((2, 3), keepdim=True)
+
+    def resize_bilinear(self, x, out_h, out_w, mul=1.0, add=0.0):
+        return F.interpolate(x, size=(out_h, out_w), mode='bilinear', align_corners=False) * mul + add
+
     def rows_sum_div(self, partial, den=None):
         out = partial.sum(-1)
         return out if den is None else out / torch.where(den == 0, torch.ones_like(den), den)
