@@ -1597,7 +1597,7 @@ int launch_ws(Bf16Args a, hipStream_t s) {
     a.groups = gc::ceil_div(tiles, a.tpb);
     const long long gx = (long long)a.groups * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
-    if (gc::probing()) return WOC == 2 ? gc::probe_name("conv_bf16x3_ws_kernel<%d>|up1,down1,k%d", KS, KS) : gc::probe_name("conv_bf16x3_ws_kernel<%d,32oc>|up1,down1,k%d", KS, KS);
+    if (gc::probing()) return gc::probe_name("conv_bf16x3_ws_kernel<%d,%d,%d>|up1,down1,k%d", KS, WOC, CB, KS);
     hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
     return gc::check_launch("gc_conv2d_bf16x3_f32(ws)");
 }

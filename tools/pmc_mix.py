@@ -6,10 +6,10 @@ pairs the kernel's dispatches with MIX in order, keeps the second launch of each
 MIX = (batch, channels, resolution, launches per 16 training iterations), from tools/shape_profile.py on the FFHQ-1024 step.
 """
 import csv, glob, json, os, sys
-MIX = [(4, 64, 512, 84), (4, 128, 256, 84), (4, 256, 128, 84), (4, 512, 64, 84), (8, 64, 512, 32), (8, 128, 256, 32), (8, 256, 128, 32), (8, 512, 64, 32),
-       (2, 64, 512, 16), (2, 128, 256, 16), (2, 256, 128, 16)]
-KERNEL = os.environ.get('PMC_KERNEL', 'conv_bf16x3_ws_kernel<3>')                 # substring of the rocprofv3 kernel name
-KERNEL_LABEL = os.environ.get('PMC_KERNEL_LABEL', 'conv_bf16x3_ws_kernel<3>|up1,down1,k3')     # the name bench.py reports
+MIX = [(4, 128, 256, 84), (4, 256, 128, 84), (4, 512, 64, 84), (8, 128, 256, 32), (8, 256, 128, 32), (8, 512, 64, 32), (2, 128, 256, 16), (2, 256, 128, 16)]
+# (the 64-channel layers of round 1's mix run on the wide-tile instantiation <3,2,2> since round 2: a kernel of its own)
+KERNEL = os.environ.get('PMC_KERNEL', 'conv_bf16x3_ws_kernel<3, 2, 1>')                 # substring of the rocprofv3 kernel name
+KERNEL_LABEL = os.environ.get('PMC_KERNEL_LABEL', 'conv_bf16x3_ws_kernel<3,2,1>|up1,down1,k3')     # the name bench.py reports
 
 
 def run():
