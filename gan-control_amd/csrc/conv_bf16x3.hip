@@ -55,6 +55,9 @@
 #ifndef GC_WS_WIDE_CB32
 #define GC_WS_WIDE_CB32 2      // column blocks of the wide tiles of the 32-output-channel variant (4: 4 rows x 128 px)
 #endif
+#ifndef GC_CT_ABL
+#define GC_CT_ABL 0           // dev ablations of convt_fused_bf16x3_kernel (wrong results): 1 no stores, 2 no MFMAs, 4 no global loads
+#endif
 #ifndef GC_WS_SLOTS
 #define GC_WS_SLOTS 256     // workgroups the wave-specialised kernel keeps resident: one per CU
 #endif
@@ -1391,8 +1394,8 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
             const int kg = k0 / 8 + kgl, n = n0 + oc;
             const bool ok = u < C::WUNITS && kg < a.kgroups && n < p.N;
             const unsigned gb = ok ? (unsigned)((tap * a.kgroups + kg) * p.N + n) * 16u : OOB;
-            wreg_h[j] = buf_load_u128(rwh, gb, 0);
-            wreg_l[j] = buf_load_u128(rwl, gb, 0);
+            wreg_h[j] = (GC_CT_ABL & 4) ? make_uint4(gb, gb, gb, gb) : buf_load_u128(rwh, gb, 0);
+            wreg_l[j] = (GC_CT_ABL & 4) ? make_uint4(gb, gb, gb, gb) : buf_load_u128(rwl, gb, 0);
         }
         const int iy = iy0 + t_row, ix = ix0 + t_col;
         const bool ok = t_used > 0 && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
@@ -1400,7 +1403,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             const int k = min(k0 + kgl_p * 8 + q, p.K - 1);          // wave-uniform -> scalar offset
-            preg[q] = buf_load_u128(rx, boff_, (unsigned)k * chan * 4u);
+            preg[q] = (GC_CT_ABL & 4) ? make_uint4(boff_, k, boff_ + 1, k + 1) : buf_load_u128(rx, boff_, (unsigned)k * chan * 4u);
         }
     };
     auto commit = [&](int k0) {
@@ -1465,7 +1468,8 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
 #pragma unroll
                         for (int j = 0; j < WPX; ++j) {
                             f32x16 c = acc[py * 2 + px][j];
-                            GC_MFMA3(c, ah, al, bh[j], bl[j]);
+                            if (GC_CT_ABL & 2) { c[0] += __builtin_bit_cast(float, ((const uint4&)ah).x ^ ((const uint4&)bh[j]).x ^ ((const uint4&)al).x ^ ((const uint4&)bl[j]).x); }
+                            else { GC_MFMA3(c, ah, al, bh[j], bl[j]); }
                             acc[py * 2 + px][j] = c;
                         }
                     }
@@ -1523,6 +1527,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
                     if (EPI == 2) { v0 = conv_epilogue(ec, v0, s_so[ocl], s_bias[ocl], nz[j][py][0]); v1 = conv_epilogue(ec, v1, s_so[ocl], s_bias[ocl], nz[j][py][1]); }
                     if (EPI == 2 && p.residual) { v0 += res[0][r]; v1 += res[1][r]; }
                     float* yp = yb + ((size_t)(n0 + ocl) * p.out_h + oy) * p.out_w + ox;
+                    if ((GC_CT_ABL & 1) && v0 != 12345.678f) continue;
                     if (pair) { f2u v = {v0, v1}; *reinterpret_cast<f2u*>(yp) = v; }
                     else yp[0] = v0;
                 }
