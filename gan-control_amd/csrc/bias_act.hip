@@ -238,6 +238,40 @@ __global__ __launch_bounds__(256) void rows_sum_div_kernel(const float* __restri
     out[r] = acc;
 }
 
+// plane_dot over row-pitched planes: chunk j of a plane covers rows [j * rpc, (j + 1) * rpc)
+__global__ __launch_bounds__(256) void plane_dot_pitched_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ partial,
+                                                                int rows, int width, int a_pitch, int b_pitch, int chunks, int rpc) {
+    __shared__ float lds[4];
+    const int plane = blockIdx.x / chunks, j = blockIdx.x - plane * chunks;
+    const float* ap = a + (size_t)plane * rows * a_pitch;
+    const float* bp = b + (size_t)plane * rows * b_pitch;
+    const int r0 = j * rpc, r1 = min(rows, r0 + rpc);
+    // four waves take rows r0 + wave, r0 + wave + 4, ...; a lane walks its row in 16-byte steps (rows of a dense (2H + 1)-wide operand are
+    // only 4-byte aligned, which a 16-byte load accepts on gfx9)
+    typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int w4 = width >> 2;
+    float acc0 = 0.f, acc1 = 0.f;
+    for (int r = r0 + wave; r < r1; r += 4) {
+        const float* ar = ap + (size_t)r * a_pitch;
+        const float* br = bp + (size_t)r * b_pitch;
+        int v = lane;
+        for (; v + 64 < w4; v += 128) {
+            const f4u a0 = *reinterpret_cast<const f4u*>(ar + 4 * v), b0 = *reinterpret_cast<const f4u*>(br + 4 * v);
+            const f4u a1 = *reinterpret_cast<const f4u*>(ar + 4 * (v + 64)), b1 = *reinterpret_cast<const f4u*>(br + 4 * (v + 64));
+            acc0 = fmaf(a0.x, b0.x, acc0); acc0 = fmaf(a0.y, b0.y, acc0); acc0 = fmaf(a0.z, b0.z, acc0); acc0 = fmaf(a0.w, b0.w, acc0);
+            acc1 = fmaf(a1.x, b1.x, acc1); acc1 = fmaf(a1.y, b1.y, acc1); acc1 = fmaf(a1.z, b1.z, acc1); acc1 = fmaf(a1.w, b1.w, acc1);
+        }
+        for (; v < w4; v += 64) {
+            const f4u a0 = *reinterpret_cast<const f4u*>(ar + 4 * v), b0 = *reinterpret_cast<const f4u*>(br + 4 * v);
+            acc0 = fmaf(a0.x, b0.x, acc0); acc0 = fmaf(a0.y, b0.y, acc0); acc0 = fmaf(a0.z, b0.z, acc0); acc0 = fmaf(a0.w, b0.w, acc0);
+        }
+        for (int c = 4 * w4 + lane; c < width; c += 64) acc1 = fmaf(ar[c], br[c], acc1);
+    }
+    const float s = block_sum(acc0 + acc1, lds);
+    if (threadIdx.x == 0) partial[(size_t)plane * chunks + j] = s;
+}
+
 // stage 1: partial[c][b * chunks + j] = sum over chunk j of plane (b, c); fixed summation order
 __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restrict__ x, float* __restrict__ partial,
                                                           int batch, int channels, int64_t inner, int chunks, int64_t chunk_len) {
@@ -393,6 +427,30 @@ extern "C" int gc_bias_act_bwd_reduce_f32(const float* dy, const float* y_ref, c
                                           float* psum, float* pdot, int batch, int channels, int64_t inner,
                                           float slope, float gain, gc_stream_t stream) {
     return gc_bias_act_bwd_reduce_self_f32(dy, y_ref, noise, nullptr, nullptr, dx, psum, pdot, nullptr, batch, channels, inner, slope, gain, stream);
+}
+
+static void plane_dot_pitched_plan(int rows, int* chunks, int* rpc) {
+    *rpc = rows <= 64 ? rows : 32;               // 32 rows per block: >= 8 K elements at the widths that are ever pitched (>= 129)
+    *chunks = (rows + *rpc - 1) / *rpc;
+}
+
+extern "C" int gc_plane_dot_pitched_chunks(int rows) {
+    if (rows <= 0) return 0;
+    int chunks, rpc;
+    plane_dot_pitched_plan(rows, &chunks, &rpc);
+    return chunks;
+}
+
+extern "C" int gc_plane_dot_pitched_f32(const float* a, const float* b, float* partial, int planes, int rows, int width, int a_pitch, int b_pitch,
+                                        gc_stream_t stream) {
+    if (!a || !b || !partial) return gc::fail(GC_ERR_BAD_ARG, "gc_plane_dot_pitched_f32: null pointer");
+    if (planes <= 0 || rows <= 0 || width <= 0 || a_pitch < width || b_pitch < width) return gc::fail(GC_ERR_BAD_ARG, "gc_plane_dot_pitched_f32: bad extents");
+    int chunks, rpc;
+    plane_dot_pitched_plan(rows, &chunks, &rpc);
+    if ((int64_t)planes * chunks > INT32_MAX) return gc::fail(GC_ERR_UNSUPPORTED, "gc_plane_dot_pitched_f32: more than 2^31 blocks");
+    hipLaunchKernelGGL(plane_dot_pitched_kernel, dim3((unsigned)planes * (unsigned)chunks), dim3(256), 0, (hipStream_t)stream,
+                       a, b, partial, rows, width, a_pitch, b_pitch, chunks, rpc);
+    return gc::check_launch("gc_plane_dot_pitched_f32");
 }
 
 extern "C" int gc_rows_sum_div_f32(const float* partial, const float* den, float* out, int rows, int chunks, gc_stream_t stream) {

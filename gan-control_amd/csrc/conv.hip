@@ -618,6 +618,7 @@ int gcconv::conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w,
                           const gc_conv_epilogue* ep, float* y, void* workspace, size_t workspace_bytes, gc_stream_t stream) {
     int rc = validate(d, "gc_conv2d_f32", false);
     if (rc) return rc;
+    if (!dense_output(d)) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_f32: out_pitch %d: the fp32 kernels write dense rows (gc_conv2d_out_pitch)", d->out_pitch);
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_f32: null pointer");
     if ((rc = validate_epilogue(ep, "gc_conv2d_f32"))) return rc;
     if (d->batch == 0) return GC_OK;

@@ -87,6 +87,7 @@ struct Bf16Args {
     // grid-level split over the input channels (small planes): slice blockIdx.z covers channels [z * k_per_split, (z + 1) * k_per_split)
     // and writes RAW partial sums to part + z * per_slice; splitk_finish_kernel (conv.hip) adds the slices and applies the epilogue
     int k_per_split; float* part; long long per_slice;
+    int out_pitch;                      // floats between output rows (convt_fused_bf16x3_kernel only; out_w elsewhere)
 };
 
 // wp[t][kg][n] = 8 x bf16 of w[t][kg*8 + q][n], q = 0..7 (zero beyond K); hi and lo parts
@@ -1488,7 +1489,8 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     // The phases px = 0 / 1 of one input column are NEIGHBOURS in the output row: they leave as one 8-byte store (4-byte aligned:
     // rows of a 1025-wide plane start anywhere), half the store instructions and whole 128-byte segments per 16 lanes.
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
-    float* yb = p.y + (size_t)b * p.N * p.out_h * p.out_w;
+    const int opitch = a.out_pitch;          // rows of a (2H + 1)-wide output are never 16-byte aligned: a pitch that is a multiple of 32 floats gives every 128-byte store run whole cache lines
+    float* yb = p.y + (size_t)b * p.N * p.out_h * opitch;
     const EpilogueConsts ec = epilogue_consts(p);
     float nz[WPX][2][2];         // fetched before the first store: a load between stores waits for every store before it
 #pragma unroll
@@ -1526,7 +1528,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
                     if (EPI == 1) { v0 *= s_so[ocl]; v1 *= s_so[ocl]; }
                     if (EPI == 2) { v0 = conv_epilogue(ec, v0, s_so[ocl], s_bias[ocl], nz[j][py][0]); v1 = conv_epilogue(ec, v1, s_so[ocl], s_bias[ocl], nz[j][py][1]); }
                     if (EPI == 2 && p.residual) { v0 += res[0][r]; v1 += res[1][r]; }
-                    float* yp = yb + ((size_t)(n0 + ocl) * p.out_h + oy) * p.out_w + ox;
+                    float* yp = yb + ((size_t)(n0 + ocl) * p.out_h + oy) * opitch + ox;
                     if ((GC_CT_ABL & 1) && v0 != 12345.678f) continue;
                     if (pair) { f2u v = {v0, v1}; *reinterpret_cast<f2u*>(yp) = v; }
                     else yp[0] = v0;
@@ -1701,6 +1703,13 @@ extern "C" size_t gc_conv2d_bf16x3_splitk_bytes(const gc_conv_desc* d) {
 #endif
 
 #ifndef GC_SINGLE
+extern "C" int gc_conv2d_out_pitch(const gc_conv_desc* d, int mode) {
+    if (!d || mode == 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->out_w <= 0) return 0;          // the fp32 kernels write dense rows
+    if (!(eligible(d) && d->kh == 3 && d->kw == 3 && d->up == 2 && d->pad_y == 2 && d->pad_x == 2)) return 0;
+    if (d->out_w % 32 == 0 || d->out_w < 129) return 0;       // already aligned, or too small to matter
+    return (d->out_w + 31) / 32 * 32;
+}
+
 extern "C" size_t gc_conv2d_bf16x3_packed_bytes(const gc_conv_desc* d) {
     if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !eligible(d)) return 0;
     return 2 * (size_t)d->kh * d->kw * ((d->in_ch + 7) / 8) * d->out_ch * sizeof(uint4);
@@ -1730,6 +1739,9 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_bf16x3_f32: null pointer");
     if (d->batch == 0) return GC_OK;
     if ((rc = validate_epilogue(ep, "gc_conv2d_bf16x3_f32"))) return rc;
+    const bool pitched_ok = eligible(d) && d->kh == 3 && d->up == 2 && d->pad_y == 2 && d->pad_x == 2;      // the fused transposed kernel
+    if (!dense_output(d) && !pitched_ok)
+        return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: out_pitch %d: only the fused transposed 3x3 convolution writes pitched rows (gc_conv2d_out_pitch)", d->out_pitch);
     if (!eligible(d)) return conv2d_f32_ws(d, x, w, in_scale, out_scale, ep, y, workspace, workspace_bytes, stream);
     const size_t need = gc_conv2d_bf16x3_packed_bytes(d);
     if (!packed || packed_bytes < need || (reinterpret_cast<uintptr_t>(packed) & 15))
@@ -1740,7 +1752,7 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
     const uint4* wh = static_cast<const uint4*>(packed);
     const uint4* wl = wh + units;
     Bf16Args a{{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
-                d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups, 1, 1, 0, nullptr, 0};
+                d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups, 1, 1, 0, nullptr, 0, d->out_pitch ? d->out_pitch : d->out_w};
     set_epilogue(a.c, ep);
     // small planes: split over K when the caller brought room for the slices (gc_conv2d_bf16x3_splitk_bytes)
     const SplitPlan sp = plan_splitk_bf16(d);

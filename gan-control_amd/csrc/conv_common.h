@@ -92,6 +92,9 @@ __device__ __forceinline__ int opaque(int v) {
     return v;
 }
 
+// true when the caller asked for dense output rows (what every launch except the fused transposed convolution writes)
+inline bool dense_output(const gc_conv_desc* d) { return d->out_pitch == 0 || d->out_pitch == d->out_w; }
+
 inline int validate(const gc_conv_desc* d, const char* who, bool wgrad) {
     if (!d) return gc::fail(GC_ERR_BAD_ARG, "%s: null descriptor", who);
     if (d->batch < 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->in_h <= 0 || d->in_w <= 0 || d->out_h <= 0 || d->out_w <= 0)
@@ -100,6 +103,7 @@ inline int validate(const gc_conv_desc* d, const char* who, bool wgrad) {
     const bool ok = (d->up == 1 && (d->down == 1 || d->down == 2)) || (d->up == 2 && d->down == 1);
     if (!ok) return gc::fail(GC_ERR_UNSUPPORTED, "%s: up=%d down=%d", who, d->up, d->down);
     if (wgrad && d->up != 1) return gc::fail(GC_ERR_UNSUPPORTED, "%s: up must be 1 (swap the operands for a transposed conv)", who);
+    if (d->out_pitch != 0 && d->out_pitch < d->out_w) return gc::fail(GC_ERR_BAD_ARG, "%s: out_pitch %d < out_w %d", who, d->out_pitch, d->out_w);
     const long long lim = 2147483647LL;
     if ((long long)d->in_ch * d->in_h * d->in_w > lim || (long long)d->out_ch * d->out_h * d->out_w > lim ||
         (long long)d->kh * d->kw * d->in_ch * d->out_ch > lim)

@@ -29,12 +29,12 @@ struct FirEpilogue {
 template <bool VEC, bool EPI>
 __global__ __launch_bounds__(256) void fir44_tile_kernel(
     const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
-    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip, FirEpilogue ep) {
+    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip, FirEpilogue ep, int in_pitch) {
     __shared__ __attribute__((aligned(16))) float patch[PH * PITCH];
     const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
     const size_t plane = blockIdx.z;
-    const float* xp = x + plane * (size_t)in_h * in_w;
+    const float* xp = x + plane * (size_t)in_h * in_pitch;      // in_pitch floats between input rows (in_w when dense)
     float* yp = y + plane * (size_t)out_h * out_w;
 
     // taps -> registers (uniform address: scalar loads); T[a][b] multiplies U[oy + a - pad][ox + b - pad]
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
         const int iy = iy0 + r, ix = ix0 + c;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (idx < PH * GPR && iy >= 0 && iy < in_h) {
-            const float* src = xp + (size_t)iy * in_w + ix;
+            const float* src = xp + (size_t)iy * in_pitch + ix;
             if (ix >= 0 && ix + 3 < in_w) {
                 const f4u t = *reinterpret_cast<const f4u*>(src);
                 v = make_float4(t.x, t.y, t.z, t.w);
@@ -492,7 +492,9 @@ namespace {
 int upfirdn2d_impl(const float* x, const float* taps, float* y,
                    int planes, int in_h, int in_w, int out_h, int out_w,
                    int kh, int kw, int up_x, int up_y, int down_x, int down_y,
-                   int pad_x0, int pad_y0, int flip_taps, const FirEpilogue* ep, gc_stream_t stream) {
+                   int pad_x0, int pad_y0, int flip_taps, const FirEpilogue* ep, gc_stream_t stream, int in_pitch = 0) {
+    if (in_pitch == 0) in_pitch = in_w;
+    if (in_pitch < in_w) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: input pitch %d < width %d", in_pitch, in_w);
     if (!x || !taps || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: null pointer");
     if (planes < 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0 || up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
         return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: non-positive extent or factor");
@@ -502,11 +504,12 @@ int upfirdn2d_impl(const float* x, const float* taps, float* y,
     const bool fast = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 &&
                       out_w >= 64 && out_h >= 16 && planes <= 65535;
     if (ep && !fast) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_act_f32: the fused epilogue needs the 4x4, up = down = 1 tile kernel (planes >= 64 x 16)");
+    if (in_pitch != in_w && !fast) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_pitched_f32: a pitched input needs the 4x4, up = down = 1 tile kernel (planes >= 64 x 16)");
     if (fast) {
         dim3 grid(gc::ceil_div(out_w, TW), gc::ceil_div(out_h, TH), planes);
         const bool vec = (out_w % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
         const FirEpilogue none{nullptr, nullptr, nullptr, 1.f, 1.f, 1};
-#define GC_FIR(V, E) hipLaunchKernelGGL((fir44_tile_kernel<V, E>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, ep ? *ep : none)
+#define GC_FIR(V, E) hipLaunchKernelGGL((fir44_tile_kernel<V, E>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, ep ? *ep : none, in_pitch)
         if (ep) { if (vec) GC_FIR(true, true); else GC_FIR(false, true); }
         else    { if (vec) GC_FIR(true, false); else GC_FIR(false, false); }
 #undef GC_FIR
@@ -558,6 +561,16 @@ extern "C" int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
                                 int kh, int kw, int up_x, int up_y, int down_x, int down_y,
                                 int pad_x0, int pad_y0, int flip_taps, gc_stream_t stream) {
     return upfirdn2d_impl(x, taps, y, planes, in_h, in_w, out_h, out_w, kh, kw, up_x, up_y, down_x, down_y, pad_x0, pad_y0, flip_taps, nullptr, stream);
+}
+
+extern "C" int gc_upfirdn2d_pitched_f32(const float* x, const float* taps, float* y, int batch, int channels, int in_h, int in_w, int in_pitch,
+                                        int out_h, int out_w, int kh, int kw, int pad_x0, int pad_y0, int flip_taps, int activate,
+                                        const float* bias, const float* noise, const float* noise_w, float slope, float gain, gc_stream_t stream) {
+    if ((noise == nullptr) != (noise_w == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_pitched_f32: noise and noise_w must both be set or both be null");
+    if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_pitched_f32: bad batch / channels");
+    const bool epi = activate || bias || noise;
+    const FirEpilogue ep{bias, noise, noise_w, activate ? slope : 1.f, activate ? gain : 1.f, channels};
+    return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, epi ? &ep : nullptr, stream, in_pitch);
 }
 
 extern "C" int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,

@@ -21,7 +21,7 @@ _i32, _i64, _f32, _vp, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, cty
 class ConvDesc(ctypes.Structure):
     """Mirror of ``gc_conv_desc``."""
     _fields_ = [(n, _i32) for n in ('batch', 'in_ch', 'out_ch', 'in_h', 'in_w', 'out_h', 'out_w',
-                                    'kh', 'kw', 'up', 'down', 'pad_y', 'pad_x')]
+                                    'kh', 'kw', 'up', 'down', 'pad_y', 'pad_x', 'out_pitch')]
 
 
 class ConvEpilogue(ctypes.Structure):
@@ -60,6 +60,10 @@ SIGNATURES = {
     'gc_conv2d_fused_bf16_packed_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _sz, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_bf16_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_variant_name': (_i32, [ctypes.POINTER(ConvDesc), _i32, ctypes.c_char_p, _i32]),
+    'gc_conv2d_out_pitch': (_i32, [ctypes.POINTER(ConvDesc), _i32]),
+    'gc_upfirdn2d_pitched_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 13 + [_vp, _vp, _vp, _f32, _f32, _vp]),
+    'gc_plane_dot_pitched_chunks': (_i32, [_i32]),
+    'gc_plane_dot_pitched_f32': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'gc_conv2d_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_wgrad_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -118,7 +122,20 @@ def stream_of(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def require_cuda_f32(*tensors):
+def row_pitch(t):
+    """The row pitch (elements) of a 4-D tensor whose planes are ``H x pitch`` blocks laid out back to back with only the first ``W``
+    columns of a row in use -- what the fused transposed convolution writes (gc_conv_desc.out_pitch) -- or 0 for anything else
+    (contiguous tensors included: they need no special handling)."""
+    if t is None or t.dim() != 4 or t.is_contiguous():
+        return 0
+    b, c, h, w = t.shape
+    sb, sc, sh, sw = t.stride()
+    if sw == 1 and sh > w and sc == h * sh and sb == c * sc:
+        return sh
+    return 0
+
+
+def require_cuda_f32(*tensors, pitched=()):
     """The kernels take contiguous float32 device memory; anything else is a caller error."""
     dev = None
     for t in tensors:
@@ -128,7 +145,7 @@ def require_cuda_f32(*tensors):
             raise RuntimeError('gan_control_amd: the HIP hot path needs tensors on a GPU (got %s); there is no CPU fallback' % t.device)
         if t.dtype != torch.float32:
             raise RuntimeError('gan_control_amd: float32 tensors expected, got %s' % t.dtype)
-        if not t.is_contiguous():
+        if not t.is_contiguous() and not (any(t is q for q in pitched) and row_pitch(t)):
             raise RuntimeError('gan_control_amd: internal error: non-contiguous tensor reached the kernel boundary')
         if dev is None:
             dev = t.device

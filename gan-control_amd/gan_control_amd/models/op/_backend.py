@@ -9,6 +9,8 @@ import contextlib
 import ctypes
 import math
 import os
+
+_PITCHED_OUTPUT = os.environ.get('GANCONTROL_PITCHED_OUTPUT', '1') != '0'      # dev knob: 0 = dense rows everywhere
 from collections import namedtuple
 
 import torch
@@ -74,8 +76,16 @@ class HipBackend:
         idx = dev.index if dev.index is not None else torch.cuda.current_device()
         return torch.cuda.device(idx) if idx != torch.cuda.current_device() else None
 
+    def _pitched_fir_ok(self, x, taps, up, down, out_h, out_w):
+        return _lib.row_pitch(x) and self.upfirdn2d_act_supported(taps, up, down, out_h, out_w, x.shape[0] * x.shape[1])
+
     def upfirdn2d(self, x, taps, up, down, pad_x0, pad_y0, out_h, out_w, flip):
-        """x [N,C,H,W] -> [N,C,out_h,out_w]; see gc_upfirdn2d_f32."""
+        """x [N,C,H,W] -> [N,C,out_h,out_w]; see gc_upfirdn2d_f32.  A row-pitched x (the output of a transposed convolution) is read in place
+        by the 4x4 tile kernel and made contiguous for every other variant."""
+        if _lib.row_pitch(x):
+            if self._pitched_fir_ok(x, taps, up, down, out_h, out_w):
+                return self.upfirdn2d_act(x, taps, pad_x0, pad_y0, out_h, out_w, flip, None, None, None, 1.0, 1.0, activate=False)
+            x = x.contiguous()
         dev = _lib.require_cuda_f32(x, taps)
         n, c, h, w = x.shape
         y = torch.empty((n, c, out_h, out_w), dtype=x.dtype, device=dev)
@@ -112,9 +122,10 @@ class HipBackend:
         """Shapes gc_upfirdn2d_act_f32 takes (the 4x4 tile kernel); everything else runs FIR and activation as two launches."""
         return tuple(taps.shape) == (4, 4) and up == 1 and down == 1 and out_w >= 64 and out_h >= 16 and planes <= 65535
 
-    def upfirdn2d_act(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, bias, noise, noise_w, slope, gain):
-        """gain * lrelu(FIR(x) + noise_w * noise + bias); see gc_upfirdn2d_act_f32."""
-        dev = _lib.require_cuda_f32(x, taps, bias, noise, noise_w)
+    def upfirdn2d_act(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, bias, noise, noise_w, slope, gain, activate=True):
+        """gain * lrelu(FIR(x) + noise_w * noise + bias); see gc_upfirdn2d_act_f32 (gc_upfirdn2d_pitched_f32 for a row-pitched x)."""
+        pitch = _lib.row_pitch(x)
+        dev = _lib.require_cuda_f32(x, taps, bias, noise, noise_w, pitched=(x,))
         n, c, h, w = x.shape
         y = torch.empty((n, c, out_h, out_w), dtype=x.dtype, device=dev)
         if y.numel() == 0:
@@ -124,9 +135,14 @@ class HipBackend:
         t0 = self.timer.start('fir44', 'fir44_tile_kernel') if self.timer else None
         if g: g.__enter__()
         try:
-            rc = lib.gc_upfirdn2d_act_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n, c, h, w, out_h, out_w, taps.shape[0], taps.shape[1],
-                                          pad_x0, pad_y0, int(flip), _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), float(slope), float(gain),
-                                          _lib.stream_of(x))
+            if pitch or not activate:
+                rc = lib.gc_upfirdn2d_pitched_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n, c, h, w, pitch or w, out_h, out_w, taps.shape[0], taps.shape[1],
+                                                  pad_x0, pad_y0, int(flip), int(bool(activate)), _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w),
+                                                  float(slope), float(gain), _lib.stream_of(x))
+            else:
+                rc = lib.gc_upfirdn2d_act_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n, c, h, w, out_h, out_w, taps.shape[0], taps.shape[1],
+                                              pad_x0, pad_y0, int(flip), _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), float(slope), float(gain),
+                                              _lib.stream_of(x))
         finally:
             if g: g.__exit__(None, None, None)
         _lib.check(rc, 'gc_upfirdn2d_act_f32')
@@ -289,6 +305,9 @@ class HipBackend:
 
     def plane_dot(self, a, b, den=None):
         """[B, C, *] x [B, C, *] -> [B, C]: sum over the trailing dims of a * b (divided by den [B, C], a zero divisor counting as one)."""
+        pa, pb = _lib.row_pitch(a), _lib.row_pitch(b)
+        if pa or pb:
+            return self._plane_dot_pitched(a, b, den, pa, pb)
         dev = _lib.require_cuda_f32(a, b)
         batch, ch = a.shape[0], a.shape[1]
         inner = a.numel() // (batch * ch)
@@ -304,6 +323,21 @@ class HipBackend:
         _lib.check(rc, 'gc_plane_dot_f32')
         if den is None and chunks == 1:
             return partial.reshape(batch, ch)
+        return self.rows_sum_div(partial, None if den is None else den.contiguous())
+
+    def _plane_dot_pitched(self, a, b, den, pa, pb):
+        """plane_dot with one or both operands row-pitched (gc_plane_dot_pitched_f32); the other must be contiguous."""
+        if not pa:
+            a = a.contiguous()
+        if not pb:
+            b = b.contiguous()
+        dev = _lib.require_cuda_f32(a, b, pitched=(a, b))
+        batch, ch, rows, width = a.shape
+        lib = _lib.load()
+        chunks = lib.gc_plane_dot_pitched_chunks(rows)
+        partial = torch.empty((batch, ch, chunks), dtype=a.dtype, device=dev)
+        rc = lib.gc_plane_dot_pitched_f32(_lib.ptr(a), _lib.ptr(b), _lib.ptr(partial), batch * ch, rows, width, pa or width, pb or width, _lib.stream_of(a))
+        _lib.check(rc, 'gc_plane_dot_pitched_f32')
         return self.rows_sum_div(partial, None if den is None else den.contiguous())
 
     def weight_layout(self, src, taps, k, n, src_stride, dst_shape, dst_stride, flip, scale):
@@ -395,11 +429,20 @@ class HipBackend:
         """
         dev = _lib.require_cuda_f32(x, w_t, in_scale, out_scale)
         n_out = w_t.shape[3]
-        y = torch.empty((x.shape[0], n_out, geom.out_h, geom.out_w), dtype=x.dtype, device=dev)
-        if y.numel() == 0:
-            return y
         desc = self._desc(x, n_out, geom)
         lib = _lib.load()
+        # Rows of a (2H + 1)-wide transposed-convolution output are never 16-byte aligned and their partial-line stores bound that kernel
+        # (64 -> 32 @512^2: 365 us, 240 us with aligned rows): where the library says so the output is written with a row pitch that is
+        # a multiple of 32 floats and handed on as a strided view; its consumers (the Blur that follows, the plane reductions) read the
+        # pitch, anything else makes it contiguous.
+        pitch = lib.gc_conv2d_out_pitch(desc, {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(self.conv_mode, 0)) if (geom.up == 2 and x.shape[0] > 0 and _PITCHED_OUTPUT) else 0
+        if pitch:
+            desc.out_pitch = pitch
+            y = torch.empty((x.shape[0], n_out, geom.out_h, pitch), dtype=x.dtype, device=dev)[..., :geom.out_w]
+        else:
+            y = torch.empty((x.shape[0], n_out, geom.out_h, geom.out_w), dtype=x.dtype, device=dev)
+        if y.numel() == 0:
+            return y
         ep = None
         if epilogue is not None:
             bias, noise, noise_w, slope, gain, activate = epilogue[:6]

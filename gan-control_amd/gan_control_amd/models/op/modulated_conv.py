@@ -111,7 +111,8 @@ class _PlaneDot(Function):
 
     @staticmethod
     def forward(ctx, a, b, den=None):
-        out = _backend.get().plane_dot(a.contiguous(), b.contiguous(), den)
+        from .upfirdn2d import _dense_or_pitched
+        out = _backend.get().plane_dot(_dense_or_pitched(a), _dense_or_pitched(b), den)
         ctx.has_den = den is not None
         ctx.save_for_backward(a, b, den if den is not None else a.new_empty(0), out if den is not None else a.new_empty(0))
         ctx.set_materialize_grads(False)

@@ -12,6 +12,12 @@ def _out_size(n, k, up, down, p0, p1):
     return (n * up + p0 + p1 - k) // down + 1
 
 
+def _dense_or_pitched(x):
+    """Contiguous, except a row-pitched tensor (the output of a transposed convolution, _lib.row_pitch): the FIR tile kernel reads it in place."""
+    from ... import _lib
+    return x if (x.is_cuda and _lib.row_pitch(x)) else x.contiguous()
+
+
 class _UpFirDn2d(Function):
     @staticmethod
     def forward(ctx, x, kernel, up, down, p0, p1):
@@ -23,7 +29,7 @@ class _UpFirDn2d(Function):
         ctx.save_for_backward(kernel)
         ctx.cfg = (up, down, p0, p1, h, w)
         ctx.set_materialize_grads(False)        # a gradient nobody asked for arrives as None, not as a tensor of zeros to push through the kernels
-        return _backend.get().upfirdn2d(x.contiguous(), kernel, up, down, p0, p0, oh, ow, True)
+        return _backend.get().upfirdn2d(_dense_or_pitched(x), kernel, up, down, p0, p0, oh, ow, True)
 
     @staticmethod
     def backward(ctx, gy):
@@ -42,7 +48,7 @@ class _UpFirDn2dAdjoint(Function):
         ctx.save_for_backward(kernel)
         ctx.cfg = cfg
         ctx.set_materialize_grads(False)        # a gradient nobody asked for arrives as None, not as a tensor of zeros to push through the kernels
-        return _backend.get().upfirdn2d(gy.contiguous(), kernel, down, up, kw - 1 - p0, kh - 1 - p0, h, w, False)
+        return _backend.get().upfirdn2d(_dense_or_pitched(gy), kernel, down, up, kw - 1 - p0, kh - 1 - p0, h, w, False)
 
     @staticmethod
     def backward(ctx, ggx):
@@ -67,7 +73,7 @@ class _UpFirDn2dAct(Function):
         kh, kw = kernel.shape
         n, c, h, w = x.shape
         oh, ow = _out_size(h, kh, 1, 1, p0, p1), _out_size(w, kw, 1, 1, p0, p1)
-        out = _backend.get().upfirdn2d_act(x.contiguous(), kernel, p0, p0, oh, ow, True, bias, None if noise is None else noise.contiguous(), noise_w, slope, gain)
+        out = _backend.get().upfirdn2d_act(_dense_or_pitched(x), kernel, p0, p0, oh, ow, True, bias, None if noise is None else noise.contiguous(), noise_w, slope, gain)
         ctx.cfg, ctx.act = (1, 1, p0, p1, h, w), (slope, gain)
         ctx.has_bias, ctx.has_noise = bias is not None, noise is not None
         empty = x.new_empty(0)

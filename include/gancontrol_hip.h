@@ -68,6 +68,14 @@ int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
  * in the arithmetic order of gc_bias_act_f32 (bit-identical to the two-pass result, one write + one read of the tensor
  * saved).  4x4 taps, up = down = 1, planes at least 64 x 16: GC_ERR_UNSUPPORTED otherwise (callers then run K1 + K2).
  * bias ([channels]) may be NULL; noise ([batch, out_h*out_w]) and noise_w go together. */
+/* gc_upfirdn2d_f32 / gc_upfirdn2d_act_f32 over an input whose rows are in_pitch >= in_w floats apart (planes in_h * in_pitch apart): the
+ * pitched output of a transposed convolution (gc_conv_desc.out_pitch) read by the Blur that follows it (gan_model.py:304-307).
+ * up = down = 1 with 4 x 4 taps on planes the tile kernel takes (out_w >= 64, out_h >= 16); bias / noise / noise_w NULL and
+ * slope = gain = 1, activate = 0 give the plain FIR. */
+int gc_upfirdn2d_pitched_f32(const float* x, const float* taps, float* y, int batch, int channels, int in_h, int in_w, int in_pitch,
+                             int out_h, int out_w, int kh, int kw, int pad_x0, int pad_y0, int flip_taps, int activate,
+                             const float* bias, const float* noise, const float* noise_w, float slope, float gain, gc_stream_t stream);
+
 int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,
                          int batch, int channels, int in_h, int in_w, int out_h, int out_w,
                          int kh, int kw, int pad_x0, int pad_y0, int flip_taps,
@@ -136,6 +144,11 @@ int gc_bias_act_bwd_reduce_adjoint_f32(const float* ggx, const float* cs, const 
  * Gradients of the per-sample modulation / demodulation factors of K3 (sum_hw x * dx and sum_hw dy * y). */
 int gc_plane_dot_f32(const float* a, const float* b, float* partial, int planes, int64_t inner, gc_stream_t stream);
 
+/* The same reduction over planes of `rows` x `width` elements whose rows are a_pitch / b_pitch floats apart (planes rows * pitch apart):
+ * partial[p * chunks + j] with chunks = gc_plane_dot_pitched_chunks(rows). */
+int gc_plane_dot_pitched_chunks(int rows);
+int gc_plane_dot_pitched_f32(const float* a, const float* b, float* partial, int planes, int rows, int width, int a_pitch, int b_pitch, gc_stream_t stream);
+
 /* out[r] = (sum_j partial[r*chunks + j]) / den[r]; den may be NULL (plain sum), a zero denominator counts as one.
  * The second stage of gc_plane_dot_f32 / the pself sums of gc_bias_act_bwd_reduce_self_f32 fused with the division by the modulation
  * (in_scale) / demodulation (out_scale) factor: `sum_hw x * dx / s` of ModulatedConv2d's weight algebra (gan_model.py:284-293) in one
@@ -172,7 +185,14 @@ typedef struct gc_conv_desc {
     int32_t kh, kw;
     int32_t up, down;
     int32_t pad_y, pad_x;
+    int32_t out_pitch;   /* floats between the starts of two output rows; 0 (or out_w) = dense.  Only the launches gc_conv2d_out_pitch()
+                          * names honour another value (a plane is then out_h * out_pitch floats): rows of a (2H + 1)-wide transposed-
+                          * convolution output are never 16-byte aligned, and their partial-line stores bound that kernel. */
 } gc_conv_desc;
+
+/* The row pitch (floats, a multiple of 32) the convolution of `d` in arithmetic `mode` (0 f32, 1 bf16x3, 2 bf16) can write its output with
+ * when that pays -- the fused transposed 3x3 convolution with an odd output width -- or 0: write dense rows. */
+int gc_conv2d_out_pitch(const gc_conv_desc* d, int mode);
 
 int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,
                   const float* in_scale, const float* out_scale, float* y, gc_stream_t stream);

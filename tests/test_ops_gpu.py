@@ -499,7 +499,7 @@ def test_conv2d_fused_epilogue(case, mode):
         bias = torch.randn(N, generator=gen).to(DEV)
         nz, nw = torch.randn(b, 1, oh, ow, generator=gen).to(DEV), torch.randn(1, generator=gen).to(DEV)
         for scales in ((None, None), (si, so)):
-            plain = hip.conv2d(x, wt, *scales, geom)
+            plain = hip.conv2d(x, wt, *scales, geom).contiguous()      # (a transposed convolution may hand out row-pitched views)
             fused = hip.conv2d(x, wt, *scales, geom, epilogue=(bias, None, None, 0.2, 2 ** 0.5, True))
             assert torch.equal(fused, hip.bias_act(plain, bias, None, None, 0.2, 2 ** 0.5))
             fused = hip.conv2d(x, wt, *scales, geom, epilogue=(bias, nz, nw, 0.2, 2 ** 0.5, True))
