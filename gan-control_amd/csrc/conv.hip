@@ -619,6 +619,7 @@ int gcconv::conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w,
     int rc = validate(d, "gc_conv2d_f32", false);
     if (rc) return rc;
     if (!dense_output(d)) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_f32: out_pitch %d: the fp32 kernels write dense rows (gc_conv2d_out_pitch)", d->out_pitch);
+    if (d->in_pitch != 0 && d->in_pitch != d->in_w) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_f32: in_pitch %d: the fp32 kernels read dense rows", d->in_pitch);
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_f32: null pointer");
     if ((rc = validate_epilogue(ep, "gc_conv2d_f32"))) return rc;
     if (d->batch == 0) return GC_OK;
@@ -678,6 +679,7 @@ extern "C" int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const 
                                    void* workspace, size_t workspace_bytes, gc_stream_t stream) {
     int rc = validate(d, "gc_conv2d_wgrad_f32", true);
     if (rc) return rc;
+    if (d->in_pitch != 0 && d->in_pitch != d->in_w) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_f32: in_pitch %d: the fp32 kernels read dense rows", d->in_pitch);
     if (!x || !dy || !dw) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_wgrad_f32: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const size_t count = (size_t)d->kh * d->kw * d->in_ch * d->out_ch;

@@ -88,6 +88,7 @@ struct Bf16Args {
     // and writes RAW partial sums to part + z * per_slice; splitk_finish_kernel (conv.hip) adds the slices and applies the epilogue
     int k_per_split; float* part; long long per_slice;
     int out_pitch;                      // floats between output rows (convt_fused_bf16x3_kernel only; out_w elsewhere)
+    int in_pitch;                       // floats between input rows (conv_bf16x3_kernel; in_w when dense)
 };
 
 // wp[t][kg][n] = 8 x bf16 of w[t][kg*8 + q][n], q = 0..7 (zero beyond K); hi and lo parts
@@ -254,9 +255,9 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
 
     const int aoff = hi * OCT + wave_oc * WOC * 32 + l31;
 
-    const float* xb = p.x + (size_t)b * p.K * p.in_h * p.in_w;
+    const float* xb = p.x + (size_t)b * p.K * p.in_h * a.in_pitch;
     const float* sib = p.si ? p.si + (size_t)b * p.K : nullptr;
-    const int chan = p.in_h * p.in_w;
+    const int chan = p.in_h * a.in_pitch;          // a.in_pitch floats between input rows (the pitched output of a Blur; in_w when dense)
 
     uint4 wreg_h[C::NWU], wreg_l[C::NWU];
     uint4 preg[C::NT][8];                       // [task][channel] = 4 consecutive pixels
@@ -290,7 +291,7 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
             const typename C::Task tk = C::task_of(tb + 128 * j, lead);
             const int iy = iy0 + tk.row, ix = ix0 + tk.col;
             const bool ok = tk.used > 0 && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
-            const unsigned boff = ok ? (unsigned)(iy * p.in_w + ix) * 4u : OOB;
+            const unsigned boff = ok ? (unsigned)(iy * a.in_pitch + ix) * 4u : OOB;
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int k = min(k0 + kgl * 8 + q, p.K - 1);          // wave-uniform -> scalar offset
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
         // 16-byte groups start at multiples of four pixels (ix0 + lead is a multiple of 32), so in a row whose width is a multiple of
         // four a group lies entirely inside the image or entirely outside (and was then fetched as zeros): the per-pixel row-end mask --
         // 32 selects per chunk -- is only needed for the odd widths (the 1025-wide planes of the stride-2 convolutions).
-        const bool ragged_rows = (p.in_w & 3) != 0 && ix0 + lead + 32 * C::SEG_M + 4 > p.in_w;      // ... and there only in the tiles that reach the row end
+        const bool ragged_rows = ((p.in_w & 3) != 0 || a.in_pitch != p.in_w) && ix0 + lead + 32 * C::SEG_M + 4 > p.in_w;      // ... and there only in the tiles that reach the row end
         auto convert = [&](auto masked) {
 #pragma unroll
             for (int j = 0; j < C::NT; ++j) {
@@ -747,6 +748,7 @@ struct WgArgs {
     const float* x; const float* dy; const float* si; const float* so; float* ws;
     int B, K, N, in_h, in_w, out_h, out_w, pad_y, pad_x;
     int tiles_x, tiles_y, tiles_per_split;
+    int x_pitch;          // floats between the rows of x (wgrad_bf16x3_s2_kernel; in_w when dense)
 };
 
 __device__ __forceinline__ uint4 shift_px(const uint4 a, const uint4 b, int tx) {
@@ -1067,7 +1069,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
     const int total_tiles = tiles_per_sample * p.B;
     const int t_begin = split * p.tiles_per_split;
     const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
-    const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
+    const int xchan = p.in_h * p.x_pitch, ychan = p.out_h * p.out_w;
     const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
 
     // Only the loaded data lives in registers between prefetch and commit: the per-sample scales sit in an LDS table
@@ -1107,14 +1109,14 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
         const int rem = tile - b * tiles_per_sample;
         const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows (L2 hits)
         const int iy0 = oy0 * 2, ix0 = ox0 * 2;                      // pad = 0 (checked on the host)
-        const int xoff = (k0 * xchan + iy0 * p.in_w + ix0) * 4, yoff = (n0 * ychan + oy0 * p.out_w + ox0) * 4;
+        const int xoff = (k0 * xchan + iy0 * p.x_pitch + ix0) * 4, yoff = (n0 * ychan + oy0 * p.out_w + ox0) * 4;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
 #pragma unroll
         for (int j = 0; j < C::NPX; ++j) {
             const unsigned d = xd(j);
             const int r = (int)((d >> 20) & 15u);
-            const int lin = (int)((d >> 24) & 63u) * (xchan * 4) + r * (p.in_w * 4) + (int)((d >> 16) & 15u) * 64 + xoff;
+            const int lin = (int)((d >> 24) & 63u) * (xchan * 4) + r * (p.x_pitch * 4) + (int)((d >> 16) & 15u) * 64 + xoff;
             const unsigned off = ((int)d >= 0 && iy0 + r < p.in_h) ? (unsigned)lin : OUTSIDE;
 #pragma unroll
             for (int v = 0; v < 4; ++v) xreg[j][v] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 16 * v));
@@ -1710,6 +1712,11 @@ extern "C" int gc_conv2d_out_pitch(const gc_conv_desc* d, int mode) {
     return (d->out_w + 31) / 32 * 32;
 }
 
+extern "C" int gc_conv2d_in_pitch_ok(const gc_conv_desc* d, int mode, int wgrad) {
+    if (!d || mode == 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->up != 1 || d->down != 2) return 0;
+    return wgrad ? (wg_eligible(d) ? 1 : 0) : (eligible(d) ? 1 : 0);
+}
+
 extern "C" size_t gc_conv2d_bf16x3_packed_bytes(const gc_conv_desc* d) {
     if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !eligible(d)) return 0;
     return 2 * (size_t)d->kh * d->kw * ((d->in_ch + 7) / 8) * d->out_ch * sizeof(uint4);
@@ -1739,6 +1746,8 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
     if (!x || !w || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_bf16x3_f32: null pointer");
     if (d->batch == 0) return GC_OK;
     if ((rc = validate_epilogue(ep, "gc_conv2d_bf16x3_f32"))) return rc;
+    if (d->in_pitch != 0 && d->in_pitch != d->in_w && !(eligible(d) && d->up == 1 && d->down == 2))
+        return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: in_pitch %d: only the split-bf16 stride-2 kernel reads pitched rows (gc_conv2d_in_pitch_ok)", d->in_pitch);
     const bool pitched_ok = eligible(d) && d->kh == 3 && d->up == 2 && d->pad_y == 2 && d->pad_x == 2;      // the fused transposed kernel
     if (!dense_output(d) && !pitched_ok)
         return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: out_pitch %d: only the fused transposed 3x3 convolution writes pitched rows (gc_conv2d_out_pitch)", d->out_pitch);
@@ -1752,7 +1761,7 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
     const uint4* wh = static_cast<const uint4*>(packed);
     const uint4* wl = wh + units;
     Bf16Args a{{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w,
-                d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups, 1, 1, 0, nullptr, 0, d->out_pitch ? d->out_pitch : d->out_w};
+                d->pad_y, d->pad_x, 0, 0}, wh, wl, kgroups, 1, 1, 0, nullptr, 0, d->out_pitch ? d->out_pitch : d->out_w, d->in_pitch ? d->in_pitch : d->in_w};
     set_epilogue(a.c, ep);
     // small planes: split over K when the caller brought room for the slices (gc_conv2d_bf16x3_splitk_bytes)
     const SplitPlan sp = plan_splitk_bf16(d);
@@ -1820,6 +1829,8 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
     int rc = validate(d, "gc_conv2d_wgrad_bf16x3_f32", true);
     if (rc) return rc;
     if (!x || !dy || !dw) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_wgrad_bf16x3_f32: null pointer");
+    if (d->in_pitch != 0 && d->in_pitch != d->in_w && !(wg_eligible(d) && d->down == 2))
+        return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_bf16x3_f32: in_pitch %d: only the split-bf16 stride-2 kernel reads pitched rows (gc_conv2d_in_pitch_ok)", d->in_pitch);
     if (d->batch == 0 || !wg_eligible(d)) return gc_conv2d_wgrad_f32(d, x, dy, in_scale, out_scale, dw, workspace, workspace_bytes, stream);
     const WgPlan pl = plan_wg(d);
     const size_t count = (size_t)d->kh * d->kw * d->in_ch * d->out_ch;
@@ -1827,7 +1838,7 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
     if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_bf16x3_f32: workspace %zu < %zu bytes", workspace_bytes, need);
     hipStream_t s = (hipStream_t)stream;
     WgArgs a{x, dy, in_scale, out_scale, pl.splits == 1 ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch,
-             d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
+             d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split, d->in_pitch ? d->in_pitch : d->in_w};
     dim3 grid(gc::ceil_div(d->in_ch, pl.kt), gc::ceil_div(d->out_ch, pl.ct), pl.splits);
     if (d->down == 2) {
         if (pl.kt == 32) {

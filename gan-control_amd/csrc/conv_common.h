@@ -103,6 +103,7 @@ inline int validate(const gc_conv_desc* d, const char* who, bool wgrad) {
     const bool ok = (d->up == 1 && (d->down == 1 || d->down == 2)) || (d->up == 2 && d->down == 1);
     if (!ok) return gc::fail(GC_ERR_UNSUPPORTED, "%s: up=%d down=%d", who, d->up, d->down);
     if (wgrad && d->up != 1) return gc::fail(GC_ERR_UNSUPPORTED, "%s: up must be 1 (swap the operands for a transposed conv)", who);
+    if (d->in_pitch != 0 && d->in_pitch < d->in_w) return gc::fail(GC_ERR_BAD_ARG, "%s: in_pitch %d < in_w %d", who, d->in_pitch, d->in_w);
     if (d->out_pitch != 0 && d->out_pitch < d->out_w) return gc::fail(GC_ERR_BAD_ARG, "%s: out_pitch %d < out_w %d", who, d->out_pitch, d->out_w);
     const long long lim = 2147483647LL;
     if ((long long)d->in_ch * d->in_h * d->in_w > lim || (long long)d->out_ch * d->out_h * d->out_w > lim ||

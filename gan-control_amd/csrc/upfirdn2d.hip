@@ -29,13 +29,13 @@ struct FirEpilogue {
 template <bool VEC, bool EPI>
 __global__ __launch_bounds__(256) void fir44_tile_kernel(
     const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
-    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip, FirEpilogue ep, int in_pitch) {
+    int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip, FirEpilogue ep, int in_pitch, int out_pitch) {
     __shared__ __attribute__((aligned(16))) float patch[PH * PITCH];
     const int tid = threadIdx.x;
     const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
     const size_t plane = blockIdx.z;
     const float* xp = x + plane * (size_t)in_h * in_pitch;      // in_pitch floats between input rows (in_w when dense)
-    float* yp = y + plane * (size_t)out_h * out_w;
+    float* yp = y + plane * (size_t)out_h * out_pitch;          // out_pitch floats between output rows (out_w when dense)
 
     // taps -> registers (uniform address: scalar loads); T[a][b] multiplies U[oy + a - pad][ox + b - pad]
     float T[4][4];
@@ -130,9 +130,14 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
     for (int r = 0; r < 4; ++r) {
         const int oy = oy0 + rg * 4 + r;
         if (oy >= out_h) break;
-        float* dst = yp + (size_t)oy * out_w + ox;
+        float* dst = yp + (size_t)oy * out_pitch + ox;
         if (VEC) {
             if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ox + j < out_w) dst[j] = acc[r][j];          // the ragged end of a pitched odd-width row
+            }
         } else if (ox + 3 < out_w) {
             // odd widths (1025, 513, ...): rows are only 4-byte aligned, which a 16-byte store accepts on gfx9 (as the
             // 16-byte loads of the weight-gradient kernels do): one store instruction instead of four
@@ -492,8 +497,10 @@ namespace {
 int upfirdn2d_impl(const float* x, const float* taps, float* y,
                    int planes, int in_h, int in_w, int out_h, int out_w,
                    int kh, int kw, int up_x, int up_y, int down_x, int down_y,
-                   int pad_x0, int pad_y0, int flip_taps, const FirEpilogue* ep, gc_stream_t stream, int in_pitch = 0) {
+                   int pad_x0, int pad_y0, int flip_taps, const FirEpilogue* ep, gc_stream_t stream, int in_pitch = 0, int out_pitch = 0) {
     if (in_pitch == 0) in_pitch = in_w;
+    if (out_pitch == 0) out_pitch = out_w;
+    if (out_pitch < out_w) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: output pitch %d < width %d", out_pitch, out_w);
     if (in_pitch < in_w) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: input pitch %d < width %d", in_pitch, in_w);
     if (!x || !taps || !y) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_f32: null pointer");
     if (planes < 0 || in_h <= 0 || in_w <= 0 || kh <= 0 || kw <= 0 || up_x <= 0 || up_y <= 0 || down_x <= 0 || down_y <= 0)
@@ -504,12 +511,12 @@ int upfirdn2d_impl(const float* x, const float* taps, float* y,
     const bool fast = up_x == 1 && up_y == 1 && down_x == 1 && down_y == 1 && kh == 4 && kw == 4 &&
                       out_w >= 64 && out_h >= 16 && planes <= 65535;
     if (ep && !fast) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_act_f32: the fused epilogue needs the 4x4, up = down = 1 tile kernel (planes >= 64 x 16)");
-    if (in_pitch != in_w && !fast) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_pitched_f32: a pitched input needs the 4x4, up = down = 1 tile kernel (planes >= 64 x 16)");
+    if ((in_pitch != in_w || out_pitch != out_w) && !fast) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_pitched_f32: a pitched input needs the 4x4, up = down = 1 tile kernel (planes >= 64 x 16)");
     if (fast) {
         dim3 grid(gc::ceil_div(out_w, TW), gc::ceil_div(out_h, TH), planes);
-        const bool vec = (out_w % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);
+        const bool vec = (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);      // rows start on 16-byte boundaries
         const FirEpilogue none{nullptr, nullptr, nullptr, 1.f, 1.f, 1};
-#define GC_FIR(V, E) hipLaunchKernelGGL((fir44_tile_kernel<V, E>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, ep ? *ep : none, in_pitch)
+#define GC_FIR(V, E) hipLaunchKernelGGL((fir44_tile_kernel<V, E>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, ep ? *ep : none, in_pitch, out_pitch)
         if (ep) { if (vec) GC_FIR(true, true); else GC_FIR(false, true); }
         else    { if (vec) GC_FIR(true, false); else GC_FIR(false, false); }
 #undef GC_FIR
@@ -564,13 +571,13 @@ extern "C" int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
 }
 
 extern "C" int gc_upfirdn2d_pitched_f32(const float* x, const float* taps, float* y, int batch, int channels, int in_h, int in_w, int in_pitch,
-                                        int out_h, int out_w, int kh, int kw, int pad_x0, int pad_y0, int flip_taps, int activate,
+                                        int out_h, int out_w, int out_pitch, int kh, int kw, int pad_x0, int pad_y0, int flip_taps, int activate,
                                         const float* bias, const float* noise, const float* noise_w, float slope, float gain, gc_stream_t stream) {
     if ((noise == nullptr) != (noise_w == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_pitched_f32: noise and noise_w must both be set or both be null");
     if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_pitched_f32: bad batch / channels");
     const bool epi = activate || bias || noise;
     const FirEpilogue ep{bias, noise, noise_w, activate ? slope : 1.f, activate ? gain : 1.f, channels};
-    return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, epi ? &ep : nullptr, stream, in_pitch);
+    return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, epi ? &ep : nullptr, stream, in_pitch, out_pitch);
 }
 
 extern "C" int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,

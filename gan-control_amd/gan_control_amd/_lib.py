@@ -21,7 +21,7 @@ _i32, _i64, _f32, _vp, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, cty
 class ConvDesc(ctypes.Structure):
     """Mirror of ``gc_conv_desc``."""
     _fields_ = [(n, _i32) for n in ('batch', 'in_ch', 'out_ch', 'in_h', 'in_w', 'out_h', 'out_w',
-                                    'kh', 'kw', 'up', 'down', 'pad_y', 'pad_x', 'out_pitch')]
+                                    'kh', 'kw', 'up', 'down', 'pad_y', 'pad_x', 'in_pitch', 'out_pitch')]
 
 
 class ConvEpilogue(ctypes.Structure):
@@ -61,7 +61,8 @@ SIGNATURES = {
     'gc_conv2d_wgrad_bf16_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_variant_name': (_i32, [ctypes.POINTER(ConvDesc), _i32, ctypes.c_char_p, _i32]),
     'gc_conv2d_out_pitch': (_i32, [ctypes.POINTER(ConvDesc), _i32]),
-    'gc_upfirdn2d_pitched_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 13 + [_vp, _vp, _vp, _f32, _f32, _vp]),
+    'gc_conv2d_in_pitch_ok': (_i32, [ctypes.POINTER(ConvDesc), _i32, _i32]),
+    'gc_upfirdn2d_pitched_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 14 + [_vp, _vp, _vp, _f32, _f32, _vp]),
     'gc_plane_dot_pitched_chunks': (_i32, [_i32]),
     'gc_plane_dot_pitched_f32': (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     'gc_conv2d_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

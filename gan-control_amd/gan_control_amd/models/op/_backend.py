@@ -86,6 +86,12 @@ class HipBackend:
             if self._pitched_fir_ok(x, taps, up, down, out_h, out_w):
                 return self.upfirdn2d_act(x, taps, pad_x0, pad_y0, out_h, out_w, flip, None, None, None, 1.0, 1.0, activate=False)
             x = x.contiguous()
+        elif (_PITCHED_OUTPUT and out_w % 4 != 0 and out_w >= 129 and self.conv_mode != 'f32'
+              and self.upfirdn2d_act_supported(taps, up, down, out_h, out_w, x.shape[0] * x.shape[1])):
+            # the (H + 1)-wide output of the Blur in front of a stride-2 convolution (and of the Blur adjoint in G): aligned rows for its
+            # 16-byte stores (4.4 -> 5.6 TB/s); the stride-2 kernels read the pitch (gc_conv_desc.in_pitch)
+            return self.upfirdn2d_act(x, taps, pad_x0, pad_y0, out_h, out_w, flip, None, None, None, 1.0, 1.0, activate=False,
+                                      out_pitch=(out_w + 31) // 32 * 32)
         dev = _lib.require_cuda_f32(x, taps)
         n, c, h, w = x.shape
         y = torch.empty((n, c, out_h, out_w), dtype=x.dtype, device=dev)
@@ -122,12 +128,15 @@ class HipBackend:
         """Shapes gc_upfirdn2d_act_f32 takes (the 4x4 tile kernel); everything else runs FIR and activation as two launches."""
         return tuple(taps.shape) == (4, 4) and up == 1 and down == 1 and out_w >= 64 and out_h >= 16 and planes <= 65535
 
-    def upfirdn2d_act(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, bias, noise, noise_w, slope, gain, activate=True):
+    def upfirdn2d_act(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, bias, noise, noise_w, slope, gain, activate=True, out_pitch=0):
         """gain * lrelu(FIR(x) + noise_w * noise + bias); see gc_upfirdn2d_act_f32 (gc_upfirdn2d_pitched_f32 for a row-pitched x)."""
         pitch = _lib.row_pitch(x)
         dev = _lib.require_cuda_f32(x, taps, bias, noise, noise_w, pitched=(x,))
         n, c, h, w = x.shape
-        y = torch.empty((n, c, out_h, out_w), dtype=x.dtype, device=dev)
+        if out_pitch:
+            y = torch.empty((n, c, out_h, out_pitch), dtype=x.dtype, device=dev)[..., :out_w]
+        else:
+            y = torch.empty((n, c, out_h, out_w), dtype=x.dtype, device=dev)
         if y.numel() == 0:
             return y
         lib = _lib.load()
@@ -135,8 +144,9 @@ class HipBackend:
         t0 = self.timer.start('fir44', 'fir44_tile_kernel') if self.timer else None
         if g: g.__enter__()
         try:
-            if pitch or not activate:
-                rc = lib.gc_upfirdn2d_pitched_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n, c, h, w, pitch or w, out_h, out_w, taps.shape[0], taps.shape[1],
+            if pitch or out_pitch or not activate:
+                rc = lib.gc_upfirdn2d_pitched_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n, c, h, w, pitch or w, out_h, out_w, out_pitch or out_w,
+                                                  taps.shape[0], taps.shape[1],
                                                   pad_x0, pad_y0, int(flip), int(bool(activate)), _lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w),
                                                   float(slope), float(gain), _lib.stream_of(x))
             else:
@@ -427,10 +437,16 @@ class HipBackend:
 
         epilogue = (bias [N] | None, noise [B,1,oh,ow] | None, noise_w [1] | None, slope, gain, activate[, residual [B,N,oh,ow] | None]) or None.
         """
-        dev = _lib.require_cuda_f32(x, w_t, in_scale, out_scale)
+        lib = _lib.load()
         n_out = w_t.shape[3]
         desc = self._desc(x, n_out, geom)
-        lib = _lib.load()
+        in_pitch = _lib.row_pitch(x)
+        if in_pitch:          # the pitched output of a Blur: the split-bf16 stride-2 kernel reads it in place
+            if geom.down == 2 and lib.gc_conv2d_in_pitch_ok(desc, {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(self.conv_mode, 0), 0):
+                desc.in_pitch = in_pitch
+            else:
+                x = x.contiguous()
+        dev = _lib.require_cuda_f32(x, w_t, in_scale, out_scale, pitched=(x,))
         # Rows of a (2H + 1)-wide transposed-convolution output are never 16-byte aligned and their partial-line stores bound that kernel
         # (64 -> 32 @512^2: 365 us, 240 us with aligned rows): where the library says so the output is written with a row pitch that is
         # a multiple of 32 floats and handed on as a strided view; its consumers (the Blur that follows, the plane reductions) read the
@@ -447,7 +463,7 @@ class HipBackend:
         if epilogue is not None:
             bias, noise, noise_w, slope, gain, activate = epilogue[:6]
             residual = epilogue[6] if len(epilogue) > 6 else None
-            _lib.require_cuda_f32(x, bias, noise, noise_w, residual)
+            _lib.require_cuda_f32(x, bias, noise, noise_w, residual, pitched=(x,))
             if residual is not None and tuple(residual.shape) != tuple(y.shape):
                 raise RuntimeError('conv2d epilogue: residual shape %s, output shape %s' % (tuple(residual.shape), tuple(y.shape)))
             if bias is not None and bias.numel() != n_out:
@@ -498,11 +514,22 @@ class HipBackend:
         return y
 
     def conv2d_wgrad(self, x, dy, in_scale, out_scale, geom):
+        in_pitch = _lib.row_pitch(x)
+        if in_pitch or _lib.row_pitch(dy):
+            n_out_ = dy.shape[1]
+            ok = in_pitch and geom.down == 2 and _lib.load().gc_conv2d_in_pitch_ok(self._desc(x, n_out_, geom), {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(self.conv_mode, 0), 1)
+            if not ok:
+                x, in_pitch = x.contiguous(), 0
+            dy = dy.contiguous()
+        return self._conv2d_wgrad(x, dy, in_scale, out_scale, geom, in_pitch)
+
+    def _conv2d_wgrad(self, x, dy, in_scale, out_scale, geom, in_pitch=0):
         """x [B,K,H,W], dy [B,N,out_h,out_w] -> dw [kh,kw,K,N]; see gc_conv2d_wgrad_f32."""
-        dev = _lib.require_cuda_f32(x, dy, in_scale, out_scale)
+        dev = _lib.require_cuda_f32(x, dy, in_scale, out_scale, pitched=(x,))
         n_out = dy.shape[1]
         dw = torch.empty((geom.kh, geom.kw, x.shape[1], n_out), dtype=x.dtype, device=dev)
         desc = self._desc(x, n_out, geom)
+        desc.in_pitch = in_pitch
         lib = _lib.load()
         fast = self.conv_mode in ('bf16x3', 'bf16')
         nbytes = (lib.gc_conv2d_wgrad_bf16x3_workspace if fast else lib.gc_conv2d_wgrad_workspace)(desc)

@@ -17,6 +17,7 @@ import torch
 from torch.autograd import Function
 
 from . import _backend
+from .upfirdn2d import _dense_or_pitched
 from ._backend import ConvGeom
 from .weight_layout import adjoint_layout, kernel_layout
 
@@ -42,7 +43,7 @@ class _GConv(Function):
         ctx.save_for_backward(x, w_t)
         ctx.set_materialize_grads(False)
         ep = None if residual is None else (None, None, None, 1.0, 1.0, False, residual.contiguous())
-        return _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None, None, geom, epilogue=ep)
+        return _backend.get().conv2d(_dense_or_pitched(x), w_t.contiguous(), None, None, geom, epilogue=ep)
 
     @staticmethod
     def backward(ctx, gy):
@@ -74,7 +75,7 @@ class _WGrad(Function):
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.save_for_backward(x, gy)
         ctx.set_materialize_grads(False)
-        return _backend.get().conv2d_wgrad(x.contiguous(), gy.contiguous(), None, None, geom)
+        return _backend.get().conv2d_wgrad(_dense_or_pitched(x), _dense_or_pitched(gy), None, None, geom)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -102,7 +103,7 @@ class _GConvAct(Function):
 
     @staticmethod
     def forward(ctx, x, w_t, bias, geom, slope, gain, fork=False):
-        out = _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None, None, geom, epilogue=(bias, None, None, slope, gain, True))
+        out = _backend.get().conv2d(_dense_or_pitched(x), w_t.contiguous(), None, None, geom, epilogue=(bias, None, None, slope, gain, True))
         ctx.geom, ctx.cfg = geom, (slope, gain)
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.save_for_backward(x, w_t, out)

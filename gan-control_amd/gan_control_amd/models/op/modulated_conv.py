@@ -27,7 +27,7 @@ from . import _backend
 from ._backend import ConvGeom
 from .conv2d_gradfix import _adjoint_geom, _adjoint_weight
 from .weight_layout import kernel_layout
-from .upfirdn2d import upfirdn2d
+from .upfirdn2d import upfirdn2d, _dense_or_pitched
 
 
 class _WeightSq(Function):
@@ -111,7 +111,6 @@ class _PlaneDot(Function):
 
     @staticmethod
     def forward(ctx, a, b, den=None):
-        from .upfirdn2d import _dense_or_pitched
         out = _backend.get().plane_dot(_dense_or_pitched(a), _dense_or_pitched(b), den)
         ctx.has_den = den is not None
         ctx.save_for_backward(a, b, den if den is not None else a.new_empty(0), out if den is not None else a.new_empty(0))
@@ -143,7 +142,7 @@ class _ModConv(Function):
         ep = None
         if bias is not None or residual is not None:
             ep = (bias, None, None, 1.0, 1.0, False, None if residual is None else residual.contiguous())
-        y = _backend.get().conv2d(x.contiguous(), w_t.contiguous(), None if si is None else si.contiguous(),
+        y = _backend.get().conv2d(_dense_or_pitched(x), w_t.contiguous(), None if si is None else si.contiguous(),
                                   None if so is None else so.contiguous(), geom, epilogue=ep)
         ctx.geom, ctx.in_hw = geom, (x.shape[2], x.shape[3])
         ctx.has_si, ctx.has_so, ctx.has_bias, ctx.has_res = si is not None, so is not None, bias is not None, residual is not None
@@ -264,7 +263,7 @@ class _ModWGrad(Function):
         empty = x.new_empty(0)
         ctx.save_for_backward(x, gy, si if si is not None else empty, so if so is not None else empty)
         ctx.set_materialize_grads(False)
-        return _backend.get().conv2d_wgrad(x.contiguous(), gy.contiguous(), None if si is None else si.contiguous(),
+        return _backend.get().conv2d_wgrad(_dense_or_pitched(x), _dense_or_pitched(gy), None if si is None else si.contiguous(),
                                            None if so is None else so.contiguous(), geom)
 
     @staticmethod

@@ -69,11 +69,13 @@ int gc_upfirdn2d_f32(const float* x, const float* taps, float* y,
  * saved).  4x4 taps, up = down = 1, planes at least 64 x 16: GC_ERR_UNSUPPORTED otherwise (callers then run K1 + K2).
  * bias ([channels]) may be NULL; noise ([batch, out_h*out_w]) and noise_w go together. */
 /* gc_upfirdn2d_f32 / gc_upfirdn2d_act_f32 over an input whose rows are in_pitch >= in_w floats apart (planes in_h * in_pitch apart): the
- * pitched output of a transposed convolution (gc_conv_desc.out_pitch) read by the Blur that follows it (gan_model.py:304-307).
+ * pitched output of a transposed convolution (gc_conv_desc.out_pitch) read by the Blur that follows it (gan_model.py:304-307) -- and / or
+ * writing rows out_pitch >= out_w floats apart (0 = dense): the (H + 1)-wide output of the Blur in front of a stride-2 convolution
+ * (ConvLayer gan_model.py:866-872), whose 16-byte stores otherwise straddle cache lines (4.4 vs 5.6 TB/s).
  * up = down = 1 with 4 x 4 taps on planes the tile kernel takes (out_w >= 64, out_h >= 16); bias / noise / noise_w NULL and
  * slope = gain = 1, activate = 0 give the plain FIR. */
 int gc_upfirdn2d_pitched_f32(const float* x, const float* taps, float* y, int batch, int channels, int in_h, int in_w, int in_pitch,
-                             int out_h, int out_w, int kh, int kw, int pad_x0, int pad_y0, int flip_taps, int activate,
+                             int out_h, int out_w, int out_pitch, int kh, int kw, int pad_x0, int pad_y0, int flip_taps, int activate,
                              const float* bias, const float* noise, const float* noise_w, float slope, float gain, gc_stream_t stream);
 
 int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,
@@ -185,6 +187,9 @@ typedef struct gc_conv_desc {
     int32_t kh, kw;
     int32_t up, down;
     int32_t pad_y, pad_x;
+    int32_t in_pitch;    /* floats between the starts of two INPUT rows (planes in_h * in_pitch apart); 0 (or in_w) = dense.  Honoured by the
+                          * stride-2 launches gc_conv2d_in_pitch_ok() names (forward and weight gradient), whose input is the (H + 1)-wide
+                          * output of a Blur written with aligned rows (gc_upfirdn2d_pitched_f32, out_pitch). */
     int32_t out_pitch;   /* floats between the starts of two output rows; 0 (or out_w) = dense.  Only the launches gc_conv2d_out_pitch()
                           * names honour another value (a plane is then out_h * out_pitch floats): rows of a (2H + 1)-wide transposed-
                           * convolution output are never 16-byte aligned, and their partial-line stores bound that kernel. */
@@ -193,6 +198,10 @@ typedef struct gc_conv_desc {
 /* The row pitch (floats, a multiple of 32) the convolution of `d` in arithmetic `mode` (0 f32, 1 bf16x3, 2 bf16) can write its output with
  * when that pays -- the fused transposed 3x3 convolution with an odd output width -- or 0: write dense rows. */
 int gc_conv2d_out_pitch(const gc_conv_desc* d, int mode);
+
+/* 1 when the forward convolution (wgrad = 0) / weight gradient (wgrad = 1) of `d` in arithmetic `mode` reads a row-pitched input
+ * (gc_conv_desc.in_pitch) in place: the split-bf16 stride-2 kernels. */
+int gc_conv2d_in_pitch_ok(const gc_conv_desc* d, int mode, int wgrad);
 
 int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,
                   const float* in_scale, const float* out_scale, float* y, gc_stream_t stream);
