@@ -635,6 +635,80 @@ def test_weight_cache_survives_fused_optimizer_and_data_writes_gpu():
     _fused_step_conv_check(DEV)
 
 
+def _pitched(t, pitch):
+    """A row-pitched copy of a dense [B, C, H, W] tensor: the layout gc_conv_desc.out_pitch / gc_upfirdn2d_pitched_f32 write, with
+    garbage in the padding columns (nothing may read them)."""
+    b, c, h, w = t.shape
+    buf = torch.full((b, c, h, pitch), float('nan'), device=t.device, dtype=t.dtype)
+    buf[..., :w] = t
+    return buf[..., :w]
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 129, 131), (1, 3, 257, 257), (3, 2, 70, 161)])
+def test_row_pitched_fir_and_plane_dot(shape):
+    """Row-pitched tensors (the aligned-row layout of the (2H + 1)- / (H + 1)-wide intermediates): the Blur tile kernel reads and writes
+    them, the plane reductions read them -- bit-identical to the dense path."""
+    from gan_control_amd import _lib
+    hip, _ = _be()
+    prev, hip.conv_mode = hip.conv_mode, 'bf16x3'
+    try:
+        gen = torch.Generator().manual_seed(4)
+        x = torch.randn(shape, generator=gen).to(DEV)
+        k4 = torch.rand(4, 4, generator=gen).to(DEV)
+        b, c, h, w = shape
+        xp = _pitched(x, (w + 31) // 32 * 32 + 32)
+        assert _lib.row_pitch(xp) and not _lib.row_pitch(x)
+        for pad, (oh, ow) in ((1, (h - 1, w - 1)), (2, (h + 1, w + 1))):
+            dense = hip.upfirdn2d(x, k4, 1, 1, pad, pad, oh, ow, True).contiguous()
+            assert torch.equal(hip.upfirdn2d(xp, k4, 1, 1, pad, pad, oh, ow, True), dense), (pad, 'pitched input')
+            bias, nz, nw = torch.randn(c, generator=gen).to(DEV), torch.randn(b, 1, oh, ow, generator=gen).to(DEV), torch.randn(1, generator=gen).to(DEV)
+            assert torch.equal(hip.upfirdn2d_act(xp, k4, pad, pad, oh, ow, True, bias, nz, nw, 0.2, 1.4), hip.upfirdn2d_act(x, k4, pad, pad, oh, ow, True, bias, nz, nw, 0.2, 1.4))
+            if ow % 4 and ow >= 129:          # an odd-width output comes back row-pitched itself
+                assert _lib.row_pitch(hip.upfirdn2d(x, k4, 1, 1, pad, pad, oh, ow, True))
+        y = torch.randn(shape, generator=gen).to(DEV)
+        den = (torch.rand(b, c, generator=gen) + 0.5).to(DEV)
+        ref = (x.double() * y.double()).sum((2, 3))
+        for a_, b_ in ((xp, y), (x, _pitched(y, w + 7)), (xp, _pitched(y, w + 40))):
+            assert rel_err(hip.plane_dot(a_, b_), ref) < 1e-5
+            assert rel_err(hip.plane_dot(a_, b_, den), ref / den.double()) < 1e-5
+    finally:
+        hip.conv_mode = prev
+
+
+@pytest.mark.parametrize('case', [(2, 32, 64, 131, 133, 3), (1, 64, 64, 257, 257, 3), (2, 48, 96, 129, 161, 1)])
+def test_stride2_kernels_read_row_pitched_input(case, bf16x3_mode):
+    """The split-bf16 stride-2 convolution and its weight gradient on a row-pitched input (gc_conv_desc.in_pitch): bit-identical to the dense
+    input; the transposed convolution's pitched output (gc_conv_desc.out_pitch) equals its dense values."""
+    from gan_control_amd.models.op._backend import ConvGeom
+    from gan_control_amd import _lib
+    hip, _ = _be()
+    b, K, N, h, w, k = case
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(b, K, h, w, generator=gen).to(DEV)
+    wt = torch.randn(k, k, K, N, generator=gen).to(DEV)
+    si, so = torch.randn(b, K, generator=gen).to(DEV), (torch.rand(b, N, generator=gen) + 0.5).to(DEV)
+    oh, ow = (h - k) // 2 + 1, (w - k) // 2 + 1
+    geom = ConvGeom(k, k, 1, 2, 0, 0, oh, ow)
+    xp = _pitched(x, (w + 31) // 32 * 32)
+    assert torch.equal(hip.conv2d(xp, wt, si, so, geom), hip.conv2d(x, wt, si, so, geom))
+    dy = torch.randn(b, N, oh, ow, generator=gen).to(DEV)
+    assert torch.equal(hip.conv2d_wgrad(xp, dy, si, so, geom), hip.conv2d_wgrad(x, dy, si, so, geom))
+    if k == 3:
+        # the adjoint geometry (input gradient of the stride-2 convolution = a transposed convolution): (2 oh + 1)-wide rows come back pitched
+        tg = ConvGeom(3, 3, 2, 1, 2, 2, 2 * oh + 1, 2 * ow + 1)
+        wa = torch.randn(3, 3, N, K, generator=gen).to(DEV)
+        out = hip.conv2d(dy, wa, so, si, tg)
+        import gan_control_amd.models.op._backend as be_mod
+        be_mod._PITCHED_OUTPUT, keep = False, be_mod._PITCHED_OUTPUT
+        try:
+            dense = hip.conv2d(dy, wa, so, si, tg)
+        finally:
+            be_mod._PITCHED_OUTPUT = keep
+        assert dense.is_contiguous() and torch.equal(out, dense)
+        if (2 * ow + 1) >= 129:
+            assert _lib.row_pitch(out) % 32 == 0 and _lib.row_pitch(out) >= 2 * ow + 1
+
+
 def test_split_fc_gpu():
     oc.check_split_fc(DEV)
 
