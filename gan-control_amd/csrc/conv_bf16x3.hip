@@ -58,6 +58,9 @@
 #ifndef GC_CT_ABL
 #define GC_CT_ABL 0           // dev ablations of convt_fused_bf16x3_kernel (wrong results): 1 no stores, 2 no MFMAs, 4 no global loads
 #endif
+#ifndef GC_WS_DMA_STAGER
+#define GC_WS_DMA_STAGER 0     // 1: the staging waves issue the weight LDS-DMA -- measured SLOWER (512 -> 512 @64^2: 177 -> 203 us): the DMA wait lands on the staging waves' critical path
+#endif
 #ifndef GC_WS_SLOTS
 #define GC_WS_SLOTS 256     // workgroups the wave-specialised kernel keeps resident: one per CU
 #endif
@@ -504,6 +507,36 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     }
     __syncthreads();
 
+    // The weight slab of the NEXT item: rows (half, tap, kg) of 64 units, one LDS-DMA instruction each, dealt round-robin to the eight
+    // multiplying waves (4 or 5 each) at the start of their MFMA phase.  The instruction is issued from an asm statement: the
+    // compiler-tracked builtin makes every later LDS read of the wave (the fragment reads of THIS item) wait for the DMA first, which
+    // puts its latency at the head of each MFMA phase.  Untracked, its completion is counted by hand: vmcnt(0) before the barrier.
+#ifdef GC_SINGLE
+    constexpr int ROWS = NTAP * KG;
+#else
+    constexpr int ROWS = 2 * NTAP * KG;
+#endif
+    // one instruction moves 64 units = 64 / OCT consecutive rows (rows are adjacent in LDS; the halves hold an even number of rows)
+    constexpr int RPI = 64 / OCT, INSTR = ROWS / RPI;
+    static_assert(ROWS % RPI == 0 && (NTAP * KG) % RPI == 0, "row groups do not straddle the hi / lo halves");
+    // GC_WS_DMA_STAGER = 1: the four staging waves issue it instead (right after their patch loads, vmcnt(0) before their barrier)
+    constexpr int DMA_WAVES = GC_WS_DMA_STAGER ? 4 : 8;
+    const int dma_wave = GC_WS_DMA_STAGER ? (wave - 8) & 3 : wave;
+    auto weights = [&](int k0, int buf) {
+        uint4* const base = smem + buf * STAGE;
+#pragma unroll
+        for (int j = 0; j < (INSTR + DMA_WAVES - 1) / DMA_WAVES; ++j) {
+            const int q = dma_wave + DMA_WAVES * j;
+            if (DMA_WAVES * j + DMA_WAVES - 1 < INSTR || q < INSTR) {
+                const int r0 = q * RPI;                                   // first row of the group (wave-uniform)
+                const int half = r0 / (NTAP * KG), rr0 = r0 % (NTAP * KG);
+                const int rr = rr0 + lane / OCT;                          // this lane's row
+                const int t = rr / KG, kg = rr % KG;
+                const uint4* src = (half ? a.wl : a.wh) + ((size_t)(t * a.kgroups + k0 / 8 + kg) * p.N + n0 + lane % OCT);
+                glds16(src, base + half * C::WUNITS + rr0 * OCT);
+            }
+        }
+    };
     if (wave >= 8) {
         // ---------------- staging waves ----------------
         if (GC_WS_STAGER_PRIO) __builtin_amdgcn_s_setprio(GC_WS_STAGER_PRIO);
@@ -569,16 +602,20 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
         loads(pa, t0, k0);
         int t1 = t0, k1 = k0; advance(t1, k1);          // item 1 -> set B
         loads(pb, t1, k1);
+        if (GC_WS_DMA_STAGER) weights(0, 0);
         convert(pa, t0, k0, 0);
+        if (GC_WS_DMA_STAGER) wait_staged_loads();
         __syncthreads();
         // interval `it`: the multiplying waves work on item it; item it + 1 is converted here, item it + 2 is fetched
         for (int it = 0; it < items; it += 2) {
             int t2 = t1, k2 = k1; advance(t2, k2);
-            if (!(GC_WS_ABL & 1)) { loads(pa, t2, k2); convert(pb, t1, k1, 1); }
+            if (!(GC_WS_ABL & 1)) { loads(pa, t2, k2); if (GC_WS_DMA_STAGER) weights(k1, 1); convert(pb, t1, k1, 1); }
+            if (GC_WS_DMA_STAGER) wait_staged_loads();
             __syncthreads();
             if (it + 1 >= items) break;
             t1 = t2; k1 = k2; advance(t1, k1);
-            if (!(GC_WS_ABL & 1)) { loads(pb, t1, k1); convert(pa, t2, k2, 0); }
+            if (!(GC_WS_ABL & 1)) { loads(pb, t1, k1); if (GC_WS_DMA_STAGER) weights(k2, 0); convert(pa, t2, k2, 0); }
+            if (GC_WS_DMA_STAGER) wait_staged_loads();
             __syncthreads();
         }
         return;
@@ -640,39 +677,11 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
             }
         }
     };
-    // The weight slab of the NEXT item: rows (half, tap, kg) of 64 units, one LDS-DMA instruction each, dealt round-robin to the eight
-    // multiplying waves (4 or 5 each) at the start of their MFMA phase.  The instruction is issued from an asm statement: the
-    // compiler-tracked builtin makes every later LDS read of the wave (the fragment reads of THIS item) wait for the DMA first, which
-    // puts its latency at the head of each MFMA phase.  Untracked, its completion is counted by hand: vmcnt(0) before the barrier.
-#ifdef GC_SINGLE
-    constexpr int ROWS = NTAP * KG;
-#else
-    constexpr int ROWS = 2 * NTAP * KG;
-#endif
-    // one instruction moves 64 units = 64 / OCT consecutive rows (rows are adjacent in LDS; the halves hold an even number of rows)
-    constexpr int RPI = 64 / OCT, INSTR = ROWS / RPI;
-    static_assert(ROWS % RPI == 0 && (NTAP * KG) % RPI == 0, "row groups do not straddle the hi / lo halves");
-    auto weights = [&](int k0, int buf) {
-        uint4* const base = smem + buf * STAGE;
-#pragma unroll
-        for (int j = 0; j < (INSTR + 7) / 8; ++j) {
-            const int q = wave + 8 * j;
-            if (8 * j + 7 < INSTR || q < INSTR) {
-                const int r0 = q * RPI;                                   // first row of the group (wave-uniform)
-                const int half = r0 / (NTAP * KG), rr0 = r0 % (NTAP * KG);
-                const int rr = rr0 + lane / OCT;                          // this lane's row
-                const int t = rr / KG, kg = rr % KG;
-                const uint4* src = (half ? a.wl : a.wh) + ((size_t)(t * a.kgroups + k0 / 8 + kg) * p.N + n0 + lane % OCT);
-                glds16(src, base + half * C::WUNITS + rr0 * OCT);
-            }
-        }
-    };
     int tile_c = tile_begin, k0_c = 0;
-    weights(0, 0);
-    wait_staged_loads();
+    if (!GC_WS_DMA_STAGER) { weights(0, 0); wait_staged_loads(); }
     __syncthreads();                 // stage 0 is staged
     for (int it = 0; it < items; ++it) {
-        if (!(GC_WS_ABL & 2)) weights(k0_c + KCB < p.K ? k0_c + KCB : 0, (it + 1) & 1);          // after the last item: a valid slab into a stage nobody reads
+        if (!(GC_WS_ABL & 2) && !GC_WS_DMA_STAGER) weights(k0_c + KCB < p.K ? k0_c + KCB : 0, (it + 1) & 1);          // after the last item: a valid slab into a stage nobody reads
         const uint4* const wl_h = smem + (it & 1) * STAGE;
         const uint4* const wl_l = wl_h + C::WUNITS;
         const uint4* const p_h = wl_l + C::WUNITS;
@@ -710,7 +719,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
-        wait_staged_loads();         // the LDS-DMA rows of this wave have landed (they were issued a whole MFMA phase ago)
+        if (!GC_WS_DMA_STAGER) wait_staged_loads();         // the LDS-DMA rows of this wave have landed (they were issued a whole MFMA phase ago)
         __syncthreads();             // this stage may be rewritten from the next item on; the other one is staged
         k0_c += KCB;
         if (k0_c >= p.K) { finish_tile(tile_c); k0_c = 0; ++tile_c; }
