@@ -61,6 +61,9 @@
 #ifndef GC_WS_DMA_STAGER
 #define GC_WS_DMA_STAGER 0     // 1: the staging waves issue the weight LDS-DMA -- measured SLOWER (512 -> 512 @64^2: 177 -> 203 us): the DMA wait lands on the staging waves' critical path
 #endif
+#ifndef GC_CONVT_NARROW
+#define GC_CONVT_NARROW 1       // 16-column q-tiles where they waste fewer lanes than 32-column ones (0: always 32)
+#endif
 #ifndef GC_WS_SLOTS
 #define GC_WS_SLOTS 256     // workgroups the wave-specialised kernel keeps resident: one per CU
 #endif
@@ -1569,8 +1572,10 @@ int launch_t(Bf16Args a, hipStream_t s) {
 // q-space is (H + 1) wide for a (2H + 1)-wide output: take the tile width that wastes fewer lanes
 int dispatch_t(const Bf16Args& a, hipStream_t s) {
     const int qw = gc::ceil_div(a.c.out_w, 2);
-    const bool narrow = gc::ceil_div(qw, 16) * 16 < gc::ceil_div(qw, 32) * 32;
-    if (a.c.N <= 32) return narrow ? launch_t<1, 4, 2, 16>(a, s) : launch_t<1, 4, 2, 32>(a, s);
+    const bool narrow = GC_CONVT_NARROW && gc::ceil_div(qw, 16) * 16 < gc::ceil_div(qw, 32) * 32;
+    // <= 32 output channels: the layer is bound by its stores, and 32-column q-tiles write 256-byte runs per row instead of 128-byte
+    // ones (64 -> 32 @512^2: 254 -> 232 us) -- worth more than the 16 columns of lanes a 513-wide q-row wastes
+    if (a.c.N <= 32) return launch_t<1, 4, 2, 32>(a, s);
     return narrow ? launch_t<2, 2, 2, 16>(a, s) : launch_t<2, 2, 2, 32>(a, s);
 }
 
