@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU): race screen of the wave-specialised kernels.  LDS-DMA data is ordered for its readers only by the issuing wave's
+vmcnt wait + a barrier; a misplaced read passes single checks whenever the DMA happens to land first.  The same launch is repeated many
+times, on a busy device, and every output must be bit-identical to the first one -- and to the one-role kernel's output when
+GANCONTROL_HIP_LIB_REF points at a build with -DGC_NO_WS (same summation order)."""
+import os, sys
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'gan-control_amd'))
+import torch
+from gan_control_amd.models.op import _backend
+from gan_control_amd.models.op._backend import ConvGeom
+be = _backend.get(); be.conv_mode = 'bf16x3'
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+gen = torch.Generator().manual_seed(1)
+bad = 0
+for (B, K, N, res, k) in [(4, 512, 512, 64, 3), (8, 256, 256, 128, 3), (4, 128, 128, 256, 3), (4, 64, 64, 512, 3), (4, 32, 32, 1024, 3), (4, 128, 256, 128, 1), (2, 80, 64, 257, 3)]:
+    x = torch.randn(B, K, res, res, generator=gen).cuda(); w = torch.randn(k, k, K, N, generator=gen).cuda()
+    si = torch.randn(B, K, generator=gen).cuda(); so = (torch.rand(B, N, generator=gen) + 0.5).cuda()
+    bias = torch.randn(N, generator=gen).cuda(); nz = torch.randn(B, 1, res, res, generator=gen).cuda(); nw = torch.randn(1, generator=gen).cuda()
+    g = ConvGeom(k, k, 1, 1, k // 2, k // 2, res, res)
+    ep = (bias, nz, nw, 0.2, 1.4, True)
+    first = be.conv2d(x, w, si, so, g, epilogue=ep).clone()
+    junk = torch.randn(64 << 20, device='cuda')
+    n_bad = 0
+    for i in range(reps):
+        if i % 3 == 0:
+            junk.mul_(1.0001)                   # other traffic in flight next to the launch
+        y = be.conv2d(x, w, si, so, g, epilogue=ep)
+        if not torch.equal(y, first):
+            n_bad += 1
+    torch.cuda.synchronize()
+    print(f'{B}x{K}->{N} @{res} k{k}: {reps} launches, {n_bad} differ from the first; checksum {float(first.double().sum()):.6f} finite={bool(torch.isfinite(first).all())}')
+    bad += n_bad
+print('RACE SCREEN', 'FAILED' if bad else 'clean')
