@@ -445,7 +445,11 @@ BF16_CASES = CONV_CASES + [
 # several tiles per workgroup, odd chunk counts, ragged rows (width % 4 != 0), heights that end inside a 16-row tile, 1x1 taps
 WS_CASES = [(3, 64, 128, 130, 190, 3, 1, 1, 1), (2, 80, 64, 257, 259, 3, 1, 1, 1), (2, 128, 192, 100, 132, 1, 1, 1, 0), (4, 256, 256, 64, 96, 3, 1, 1, 1),
             (2, 32, 32, 200, 262, 3, 1, 1, 1), (2, 64, 96, 130, 190, 3, 1, 1, 1), (4, 48, 32, 150, 170, 1, 1, 1, 0)]      # ... and its 32-output-channel variant
-BF16_CASES = BF16_CASES + WS_CASES
+# planes of <= 8 x 8 pixels (conv_bf16x3_small_kernel: K % 16 == 0, K >= 64, N % 64 == 0, batch * pixels <= 512): the networks' 4^2 / 8^2
+# layers, odd planes, a pixel count that ends inside a 32-pixel MFMA column block, one sample, 1x1 taps, the largest batch
+SMALL_CASES = [(4, 512, 512, 4, 4, 3, 1, 1, 1), (4, 512, 512, 8, 8, 3, 1, 1, 1), (3, 80, 64, 5, 7, 3, 1, 1, 1), (1, 64, 128, 3, 3, 3, 1, 1, 1),
+               (2, 96, 64, 8, 6, 1, 1, 1, 0), (8, 64, 192, 8, 8, 3, 1, 1, 1), (5, 128, 64, 1, 1, 3, 1, 1, 1)]
+BF16_CASES = BF16_CASES + WS_CASES + SMALL_CASES
 
 
 @pytest.mark.parametrize('case', BF16_CASES)
@@ -464,6 +468,9 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
     if case in WS_CASES:
         from gan_control_amd.utils.profiling import conv_variant
         assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_bf16x3_ws_kernel'), 'this shape is meant to reach the wave-specialised kernel'
+    if case in SMALL_CASES:
+        from gan_control_amd.utils.profiling import conv_variant
+        assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_bf16x3_small_kernel'), 'this shape is meant to reach the small-plane kernel'
     for use_scales in (False, True):
         a = (si, so) if use_scales else (None, None)
         ref = emu.conv2d(x.double(), wt.double(), *[None if t is None else t.double() for t in a], geom)
@@ -478,7 +485,7 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
             assert rel_err(out, ref) < 5e-5, ('wgrad', use_scales)
 
 
-EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3 and c not in WS_CASES][::2] + WS_CASES
+EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3 and c not in WS_CASES + SMALL_CASES][::2] + WS_CASES + SMALL_CASES[1:4]
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
