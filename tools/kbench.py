@@ -73,7 +73,7 @@ def main():
             t = timeit(lambda: be.upfirdn2d(x, k4, 1, 1, 1, 1, res - 1, res - 1, True), args.reps)
             by = 4.0 * (x.numel() + B * c * (res - 1) ** 2)
             rows.append((f'fir44 {c}x{res}', 'fir44_tile', t * 1e6, by / t / 1e9, 'GB/s', by / t / 1e9 / 8000))
-        for c, res in [(32, 1024), (64, 512), (512, 64)]:
+        for c, res in [(32, 1024), (64, 512), (128, 256), (512, 64), (32, 1025), (64, 513)]:
             x = torch.randn(B, c, res, res, device=dev)
             b = torch.randn(c, device=dev)
             nz = torch.randn(B, 1, res, res, device=dev)
@@ -85,6 +85,10 @@ def main():
             t = timeit(lambda: be.bias_act_bwd(x, y, 0.2, 1.414), args.reps)
             by = 4.0 * 3 * x.numel()
             rows.append((f'bias_act_bwd {c}x{res}', 'bias_act_bwd', t * 1e6, by / t / 1e9, 'GB/s', by / t / 1e9 / 8000))
+            t = timeit(lambda: be.bias_act_bwd_reduce(x, y, None, 0.2, 1.414), args.reps)
+            rows.append((f'bias_act_bwd_reduce {c}x{res}', 'bias_act_bwd_reduce', t * 1e6, by / t / 1e9, 'GB/s', by / t / 1e9 / 8000))
+            t = timeit(lambda: be.bias_act_bwd_reduce(x, y, nz, 0.2, 1.414, self_dot=(b, nw)), args.reps)
+            rows.append((f'bias_act_bwd_reduce+noise+self {c}x{res}', 'bias_act_bwd_reduce', t * 1e6, (by + 4.0 * nz.numel()) / t / 1e9, 'GB/s', (by + 4.0 * nz.numel()) / t / 1e9 / 8000))
             t = timeit(lambda: be.channel_sum(x), args.reps)
             rows.append((f'channel_sum {c}x{res}', 'channel_sum', t * 1e6, 4.0 * x.numel() / t / 1e9, 'GB/s', 4.0 * x.numel() / t / 1e9 / 8000))
     for r in rows:
