@@ -1755,8 +1755,17 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_bf16x3_small_kernel(SmallA
     }
 }
 
+// LDS of the small-plane kernel with `nch` channel chunks per workgroup: the weight slab + the zero-haloed planes of every sample
+inline size_t small_lds_bytes(const gc_conv_desc* d, int nch) {
+    const int halo = d->kh / 2;
+    const size_t plane = (size_t)(d->in_h + 2 * halo) * (d->in_w + 2 * halo);
+    return (2 * (size_t)d->kh * d->kw * KG * 64 + 2 * (size_t)nch * KG * ((size_t)d->batch * plane + 1)) * sizeof(uint4);
+}
+constexpr size_t SMALL_LDS_MAX = 160 * 1024;
+
 // shapes the small-plane kernel takes: stride 1, "same" padding, whole 16-channel chunks and 64-channel output blocks, at most 512 pixels
-// over all samples (8 x 8 planes up to batch 8) and a patch that fits the LDS next to the weight slab
+// over all samples (8 x 8 planes up to batch 8) and a patch that fits the LDS next to the weight slab (many samples of tiny planes do not:
+// their halo is most of the patch)
 inline bool small_eligible(const gc_conv_desc* d) {
 #ifdef GC_NO_SMALL
     return false;
@@ -1765,26 +1774,22 @@ inline bool small_eligible(const gc_conv_desc* d) {
     if (d->in_ch % KCB != 0 || d->in_ch < 64 || d->in_ch > MAX_K_BF16X3 || d->out_ch % 64 != 0) return false;
     if (d->out_w > 8 || d->out_h > 8 || d->out_h != d->in_h || d->out_w != d->in_w) return false;
     const long long pixels = (long long)d->batch * d->out_h * d->out_w;
-    return pixels >= 1 && pixels <= 512;
+    return pixels >= 1 && pixels <= 512 && small_lds_bytes(d, 1) <= SMALL_LDS_MAX;
 }
 
 // channel chunks per workgroup: two (32 channels x 32 output channels) when the partial sums of 16-channel slices would outweigh the weights
 inline int small_chunks(const gc_conv_desc* d) {
+    if (d->in_ch % (2 * KCB) != 0 || small_lds_bytes(d, 2) > SMALL_LDS_MAX) return 1;
 #ifdef GC_SMALL_NCH
-    return (d->in_ch % (2 * KCB) == 0) ? GC_SMALL_NCH : 1;
+    return GC_SMALL_NCH;
 #endif
     const long long pixels = (long long)d->batch * d->out_h * d->out_w;
-    return (d->in_ch % (2 * KCB) == 0 && pixels > 16 * d->kh * d->kw) ? 2 : 1;     // slices * pixels * N * 4 bytes  vs  taps * K * N * 4 bytes
-}
-
-inline size_t small_lds_bytes(const gc_conv_desc* d) {
-    const int halo = d->kh / 2, plane = (d->in_h + 2 * halo) * (d->in_w + 2 * halo), nch = small_chunks(d);
-    return (size_t)(2 * d->kh * d->kw * KG * 64 + 2 * nch * KG * (d->batch * plane + 1)) * sizeof(uint4);
+    return pixels > 16 * d->kh * d->kw ? 2 : 1;     // slices * pixels * N * 4 bytes  vs  taps * K * N * 4 bytes
 }
 
 template <int KS>
 int launch_small(const gc_conv_desc* d, const SmallArgs& sa, hipStream_t s) {
-    const size_t lds = small_lds_bytes(d);
+    const size_t lds = small_lds_bytes(d, small_chunks(d));
     if (small_chunks(d) == 2) {
         static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_small_kernel<KS, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
         (void)attr;

@@ -448,8 +448,9 @@ WS_CASES = [(3, 64, 128, 130, 190, 3, 1, 1, 1), (2, 80, 64, 257, 259, 3, 1, 1, 1
 # planes of <= 8 x 8 pixels (conv_bf16x3_small_kernel: K % 16 == 0, K >= 64, N % 64 == 0, batch * pixels <= 512): the networks' 4^2 / 8^2
 # layers, odd planes, a pixel count that ends inside a 32-pixel MFMA column block, one sample, 1x1 taps, the largest batch
 SMALL_CASES = [(4, 512, 512, 4, 4, 3, 1, 1, 1), (4, 512, 512, 8, 8, 3, 1, 1, 1), (3, 80, 64, 5, 7, 3, 1, 1, 1), (1, 64, 128, 3, 3, 3, 1, 1, 1),
-               (2, 96, 64, 8, 6, 1, 1, 1, 0), (8, 64, 192, 8, 8, 3, 1, 1, 1), (5, 128, 64, 1, 1, 3, 1, 1, 1)]
-BF16_CASES = BF16_CASES + WS_CASES + SMALL_CASES
+               (2, 96, 64, 8, 6, 1, 1, 1, 0), (8, 64, 192, 8, 8, 3, 1, 1, 1), (5, 128, 64, 1, 1, 3, 1, 1, 1),
+               (200, 64, 64, 1, 1, 3, 1, 1, 1)]       # many samples of 1 x 1 planes: the halo fills the LDS (152 KB), one chunk per workgroup
+BF16_CASES = BF16_CASES + WS_CASES + SMALL_CASES + [(400, 64, 64, 1, 1, 3, 1, 1, 1)]      # ... and past the LDS: back on the general path
 
 
 @pytest.mark.parametrize('case', BF16_CASES)
