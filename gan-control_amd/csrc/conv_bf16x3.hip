@@ -53,7 +53,7 @@
 #define GC_WS_WIDE_MAX_K 64   // input channels up to which the wave-specialised kernel uses 8 x 64 tiles
 #endif
 #ifndef GC_WS_WIDE_CB32
-#define GC_WS_WIDE_CB32 2      // column blocks of the wide tiles of the 32-output-channel variant (4: 4 rows x 128 px)
+#define GC_WS_WIDE_CB32 4      // column blocks of the wide tiles of the 32-output-channel variant (4: 4 rows x 128 px)
 #endif
 #ifndef GC_CT_ABL
 #define GC_CT_ABL 0           // dev ablations of convt_fused_bf16x3_kernel (wrong results): 1 no stores, 2 no MFMAs, 4 no global loads
@@ -69,6 +69,9 @@
 #endif
 #ifndef GC_WS_STAGER_PRIO
 #define GC_WS_STAGER_PRIO 0
+#endif
+#ifndef GC_WS_STRIDED
+#define GC_WS_STRIDED 1     // a workgroup's tiles are `groups` apart instead of consecutive (DRAM locality of the resident workgroups)
 #endif
 #ifndef GC_WS_ABL
 #define GC_WS_ABL 0         // dev ablations of conv_bf16x3_ws_kernel (wrong results): 1 no patch staging, 2 no weight DMA, 4 fragments read once, 8 no stores
@@ -497,9 +500,14 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     const int grp = bid % a.groups;
     const int b = bid / a.groups;
     const int n0 = blockIdx.y * OCT;
-    const int tile_begin = grp * a.tpb, tile_end = min(p.tiles_x * p.tiles_y, tile_begin + a.tpb);
+    // The `tpb` tiles of a workgroup are `groups` apart (GC_WS_STRIDED): at any moment the 256 resident workgroups then work on ~256
+    // NEIGHBOURING tiles -- a band of rows of one sample, contiguous per channel in DRAM -- instead of 256 bands spread over the batch.
+    const int tiles_all = p.tiles_x * p.tiles_y;
+    const int tstep = GC_WS_STRIDED ? a.groups : 1;
+    const int tile_begin = GC_WS_STRIDED ? grp : grp * a.tpb;
+    const int ntiles = GC_WS_STRIDED ? (tiles_all - grp + a.groups - 1) / a.groups : min(tiles_all, tile_begin + a.tpb) - tile_begin;
     const int nchunks = p.K / KCB;
-    const int items = (tile_end - tile_begin) * nchunks;
+    const int items = ntiles * nchunks;
     const int chan = p.in_h * p.in_w;
 
     for (int k = tid; k < p.K; k += 768) s_si[k] = p.si ? p.si[(size_t)b * p.K + k] : 1.f;
@@ -600,7 +608,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
             if (p.si) { if (ragged_rows) body(std::true_type{}, std::true_type{}); else body(std::false_type{}, std::true_type{}); }
             else      { if (ragged_rows) body(std::true_type{}, std::false_type{}); else body(std::false_type{}, std::false_type{}); }
         };
-        auto advance = [&](int& tile, int& k0) { k0 += KCB; if (k0 >= p.K) { k0 = 0; ++tile; } };
+        auto advance = [&](int& tile, int& k0) { k0 += KCB; if (k0 >= p.K) { k0 = 0; tile += tstep; } };
         int t0 = tile_begin, k0 = 0;                    // item 0 -> set A
         loads(pa, t0, k0);
         int t1 = t0, k1 = k0; advance(t1, k1);          // item 1 -> set B
@@ -725,7 +733,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
         if (!GC_WS_DMA_STAGER) wait_staged_loads();         // the LDS-DMA rows of this wave have landed (they were issued a whole MFMA phase ago)
         __syncthreads();             // this stage may be rewritten from the next item on; the other one is staged
         k0_c += KCB;
-        if (k0_c >= p.K) { finish_tile(tile_c); k0_c = 0; ++tile_c; }
+        if (k0_c >= p.K) { finish_tile(tile_c); k0_c = 0; tile_c += tstep; }
     }
 }
 
@@ -1821,7 +1829,7 @@ int dispatch(const Bf16Args& a, hipStream_t s) {
         if (ws_eligible(a)) {
             // wide tiles (8 rows x 64 px) where HBM, not the matrix pipe, bounds the layer: few input channels per output byte
             const bool wide = a.c.K <= GC_WS_WIDE_MAX_K && a.c.out_w >= 64;
-            if (a.c.N % 64 == 0) return wide ? launch_ws<KS, 2, 2>(a, s) : launch_ws<KS, 2, 1>(a, s);
+            if (a.c.N % 64 == 0) return wide ? launch_ws<KS, 2, 2>(a, s) : launch_ws<KS, 2, 1>(a, s);      // (4 x 128 px tiles of 64 channels do not fit two LDS stages)
             return wide ? (a.c.out_w >= 128 ? launch_ws<KS, 1, GC_WS_WIDE_CB32>(a, s) : launch_ws<KS, 1, 2>(a, s)) : launch_ws<KS, 1, 1>(a, s);
         }
     }
