@@ -70,6 +70,9 @@
 #ifndef GC_WS_STAGER_PRIO
 #define GC_WS_STAGER_PRIO 0
 #endif
+#ifndef GC_WG_STRIDED
+#define GC_WG_STRIDED 1     // the same for the pixel splits of the stride-1 weight gradient (tiles across the rows, a split's tiles gridDim.z apart)
+#endif
 #ifndef GC_WS_STRIDED
 #define GC_WS_STRIDED 1     // a workgroup's tiles are `groups` apart instead of consecutive (DRAM locality of the resident workgroups)
 #endif
@@ -839,8 +842,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
 
     const int tiles_per_sample = p.tiles_x * p.tiles_y;
     const int total_tiles = tiles_per_sample * p.B;
-    const int t_begin = split * p.tiles_per_split;
-    const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
+    // GC_WG_STRIDED: tiles run ACROSS the rows and the tiles of one split are gridDim.z apart, so the resident workgroups read a band
+    // of neighbouring rows (contiguous in DRAM, halo rows shared through L2) instead of one 32-column strip each, all over the batch.
+    const int tstep = GC_WG_STRIDED ? (int)gridDim.z : 1;
+    const int t_begin = GC_WG_STRIDED ? split : split * p.tiles_per_split;
+    const int t_end = GC_WG_STRIDED ? total_tiles : min(total_tiles, t_begin + p.tiles_per_split);
     const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
 
     // Staging is kept LEAN: with two workgroups per CU the vector ALUs (index arithmetic, masks, conversions), not the
@@ -873,7 +879,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
     auto prefetch = [&](int tile) {
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
-        const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows (L2 hits)
+        const int oy0 = GC_WG_STRIDED ? (rem / p.tiles_x) * TR : (rem % p.tiles_y) * TR, ox0 = GC_WG_STRIDED ? (rem % p.tiles_x) * 32 : (rem / p.tiles_y) * 32;      // see the tile loop
         const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
         const int xoff = (k0 * xchan + iy0 * p.in_w + ix0) * 4, yoff = (n0 * ychan + oy0 * p.out_w + ox0) * 4;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
@@ -912,7 +918,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
     auto commit = [&](int tile) {
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
-        const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;
+        const int oy0 = GC_WG_STRIDED ? (rem / p.tiles_x) * TR : (rem % p.tiles_y) * TR, ox0 = GC_WG_STRIDED ? (rem % p.tiles_x) * 32 : (rem / p.tiles_y) * 32;
         const bool scaled = p.si != nullptr || p.so != nullptr;
         if (scaled && b != b_tab) {          // uniform: every lane of the workgroup sees the same tile
             __syncthreads();
@@ -963,10 +969,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
         commit(t_begin);
         __syncthreads();
         const int xa = (wk * 32 + l31) * C::CSX + hi, yb_ = (wn * 32 + l31) * C::CSY + hi;
-        for (int tile = t_begin; tile < t_end; ++tile) {
+        for (int tile = t_begin; tile < t_end; tile += tstep) {
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
-            const bool more = tile + 1 < t_end;
-            prefetch(more ? tile + 1 : tile);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
+            const bool more = tile + tstep < t_end;
+            prefetch(more ? tile + tstep : tile);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
             __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
 #pragma unroll 1
             for (int step = 0; step < 2 * TR / WP; ++step) {
@@ -997,7 +1003,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             __syncthreads();
             if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
             {
-                commit(tile + 1);
+                commit(tile + tstep);
                 __syncthreads();
             }
         }
