@@ -70,6 +70,12 @@
 #ifndef GC_WS_STAGER_PRIO
 #define GC_WS_STAGER_PRIO 0
 #endif
+#ifndef GC_CONV_STRIDED
+#define GC_CONV_STRIDED 0   // ... and of conv_bf16x3_kernel's tiles per workgroup: measured neutral (its >= 2048 short-lived workgroups are dispatched in tile order anyway)
+#endif
+#ifndef GC_WG2_STRIDED
+#define GC_WG2_STRIDED 1    // ... and of the stride-2 weight gradient
+#endif
 #ifndef GC_WG_STRIDED
 #define GC_WG_STRIDED 1     // the same for the pixel splits of the stride-1 weight gradient (tiles across the rows, a split's tiles gridDim.z apart)
 #endif
@@ -241,7 +247,10 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
     const int phy = phase / UP, phx = phase % UP;
     const int n0 = blockIdx.y * OCT, n0_blk = n0;
     const int qh = (p.out_h - phy + UP - 1) / UP, qw = (p.out_w - phx + UP - 1) / UP;
-    const int tile_begin = grp * a.tpb, tile_end = min(p.tiles_x * p.tiles_y, tile_begin + a.tpb);
+    // (GC_CONV_STRIDED: the tiles of a workgroup are `groups` apart, so that the workgroups resident together read neighbouring tiles)
+    const int tstep = GC_CONV_STRIDED ? a.groups : 1;
+    const int tile_begin = GC_CONV_STRIDED ? grp : grp * a.tpb;
+    const int tile_end = GC_CONV_STRIDED ? p.tiles_x * p.tiles_y : min(p.tiles_x * p.tiles_y, tile_begin + a.tpb);
     const int kz0 = a.k_per_split ? (int)blockIdx.z * a.k_per_split : 0;
     const int kz1 = a.k_per_split ? min(p.K, kz0 + a.k_per_split) : p.K;
     if (UP > 1) {      // tpb == 1; phases other than 0 have a smaller sub-grid
@@ -423,11 +432,11 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
     };
 
     if (ntaps == 0) {       // a phase no tap reaches: zeros (+ epilogue)
-        for (int tile = tile_begin; tile < tile_end; ++tile) finish_tile(tile);
+        for (int tile = tile_begin; tile < tile_end; tile += tstep) finish_tile(tile);
         return;
     }
     const int nchunks = (kz1 - kz0 + KCB - 1) / KCB;
-    const int items = (tile_end - tile_begin) * nchunks;
+    const int items = (tile_end - tile_begin + tstep - 1) / tstep * nchunks;
     int tile_n = tile_begin, k0_n = kz0;      // cursor of the staging side (prefetch / commit)
     int tile_c = tile_begin, k0_c = kz0;      // cursor of the compute side (MFMA / stores)
     prefetch(tile_n, k0_n);
@@ -439,22 +448,20 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
     }
     __syncthreads();
     commit(tile_n, k0_n);
-    k0_n += KCB; if (k0_n >= kz1) { k0_n = kz0; ++tile_n; }
+    k0_n += KCB; if (k0_n >= kz1) { k0_n = kz0; tile_n += tstep; }
     __syncthreads();
     // Steady state.  Every step is unconditional, so no control-flow path reaches the loop header with staged loads
     // in flight and the compiler plants no wait inside the next prefetch; the last item is peeled below.
     for (int it = 1; it < items; ++it) {
         prefetch(tile_n, k0_n);
         __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
-        __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
-    mfma_phase();
-    __builtin_amdgcn_s_setprio(0);
+        mfma_phase();
         __builtin_amdgcn_s_setprio(0);
         __syncthreads();
         commit(tile_n, k0_n);                               // retires the loads first: no store is outstanding yet
-        k0_n += KCB; if (k0_n >= kz1) { k0_n = kz0; ++tile_n; }
+        k0_n += KCB; if (k0_n >= kz1) { k0_n = kz0; tile_n += tstep; }
         if (k0_c + KCB >= kz1) finish_tile(tile_c);         // stores drain while the next MFMA phase runs
-        k0_c += KCB; if (k0_c >= kz1) { k0_c = kz0; ++tile_c; }
+        k0_c += KCB; if (k0_c >= kz1) { k0_c = kz0; tile_c += tstep; }
         __syncthreads();
     }
     mfma_phase();
@@ -1093,8 +1100,9 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
 
     const int tiles_per_sample = p.tiles_x * p.tiles_y;
     const int total_tiles = tiles_per_sample * p.B;
-    const int t_begin = split * p.tiles_per_split;
-    const int t_end = min(total_tiles, t_begin + p.tiles_per_split);
+    const int tstep = GC_WG2_STRIDED ? (int)gridDim.z : 1;
+    const int t_begin = GC_WG2_STRIDED ? split : split * p.tiles_per_split;
+    const int t_end = GC_WG2_STRIDED ? total_tiles : min(total_tiles, t_begin + p.tiles_per_split);
     const int xchan = p.in_h * p.x_pitch, ychan = p.out_h * p.out_w;
     const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
 
@@ -1133,7 +1141,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
     auto prefetch = [&](int tile) {
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
-        const int oy0 = (rem % p.tiles_y) * TR, ox0 = (rem / p.tiles_y) * 32;      // tiles run DOWN a 32-column strip: consecutive tiles share their halo rows (L2 hits)
+        const int oy0 = GC_WG2_STRIDED ? (rem / p.tiles_x) * TR : (rem % p.tiles_y) * TR, ox0 = GC_WG2_STRIDED ? (rem % p.tiles_x) * 32 : (rem / p.tiles_y) * 32;      // as in wgrad_bf16x3_kernel
         const int iy0 = oy0 * 2, ix0 = ox0 * 2;                      // pad = 0 (checked on the host)
         const int xoff = (k0 * xchan + iy0 * p.x_pitch + ix0) * 4, yoff = (n0 * ychan + oy0 * p.out_w + ox0) * 4;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
@@ -1160,7 +1168,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
     auto commit = [&](int tile) {
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
-        const int ox0 = (rem / p.tiles_y) * 32;
+        const int ox0 = GC_WG2_STRIDED ? (rem % p.tiles_x) * 32 : (rem / p.tiles_y) * 32;
         const bool scaled = p.si != nullptr || p.so != nullptr;
         if (scaled && b != b_tab) {          // uniform: every lane of the workgroup sees the same tile
             __syncthreads();
@@ -1218,10 +1226,10 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
         commit(t_begin);
         __syncthreads();
         const int xa = (wk * 32 + l31) * C::CSX + hi, yb_ = (wn * 32 + l31) * C::CSY + hi;
-        for (int tile = t_begin; tile < t_end; ++tile) {
+        for (int tile = t_begin; tile < t_end; tile += tstep) {
             wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
-            const bool more = tile + 1 < t_end;
-            prefetch(more ? tile + 1 : tile);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
+            const bool more = tile + tstep < t_end;
+            prefetch(more ? tile + tstep : tile);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
             __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
 #pragma unroll ((TR == 1 || WK == 1) ? 1 : 2)
             for (int r = 0; r < TR; ++r) {
@@ -1262,7 +1270,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             __syncthreads();
             if (!more) break;       // leave here: no path may reach the loop header with staged loads in flight
             {
-                commit(tile + 1);
+                commit(tile + tstep);
                 __syncthreads();
             }
         }
