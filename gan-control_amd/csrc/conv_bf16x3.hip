@@ -1661,13 +1661,14 @@ struct SmallArgs {
 
 constexpr int SMALL_THREADS = 512;       // eight waves: two per SIMD hide the staging latency; 8 x 8 planes of four samples give them one work item each
 
-template <int KS, int WOC, int NCH>
+template <int KS, int WOC, int NCH, int DOWN>
 __global__ __launch_bounds__(SMALL_THREADS) void conv_bf16x3_small_kernel(SmallArgs a) {
-    constexpr int NTAP = KS * KS, HALO = KS / 2, OCT = 32 * WOC, RPI = 64 / OCT, NW = SMALL_THREADS / 64;
+    constexpr int NTAP = KS * KS, OCT = 32 * WOC, RPI = 64 / OCT, NW = SMALL_THREADS / 64;
     constexpr int WUNITS = NCH * NTAP * KG * OCT;                // per hi / lo: [chunk][tap][kg][oc]
     extern __shared__ uint4 dyn_smem[];
     const ConvArgs& p = a.c;
-    const int ph = p.in_h + 2 * HALO, pw = p.in_w + 2 * HALO, plane = ph * pw;      // zero-haloed plane of one sample
+    const int halo = p.pad_y;                                    // = pad_x: KS / 2 at stride 1, 0 at stride 2
+    const int ph = p.in_h + 2 * halo, pw = p.in_w + 2 * halo, plane = ph * pw;      // zero-haloed plane of one sample
     const int per_kg = p.B * plane + 1;                          // + one zero unit for the lanes past the last pixel
     uint4* wl_h = dyn_smem;
     uint4* wl_l = wl_h + WUNITS;
@@ -1677,7 +1678,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_bf16x3_small_kernel(SmallA
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int k0 = blockIdx.x * KCB * NCH, n0 = blockIdx.y * OCT;
-    // weights: rows (half, chunk, tap, kg) of OCT units; one LDS-DMA instruction moves 1 KiB = RPI rows (waited for before the barrier)
+    // weights: rows (half, chunk, tap, kg) of OCT units; one LDS-DMA instruction moves 1 KiB = RPI rows (waited for before the barrier).
+    // Rows of channel groups past K (513 channels: the last chunk has one group) and units of output channels past N are zeros.
 #ifdef GC_SINGLE
     constexpr int INSTR = NCH * NTAP * KG / RPI;
 #else
@@ -1691,8 +1693,10 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_bf16x3_small_kernel(SmallA
             const int half = r0 / (NCH * NTAP * KG), rr0 = r0 % (NCH * NTAP * KG);
             const int rr = rr0 + lane / OCT;                     // this lane's row
             const int ch = rr / (NTAP * KG), t = rr / KG % NTAP, kg = rr % KG;
-            const uint4* src = (half ? a.wl : a.wh) + ((size_t)(t * a.kgroups + k0 / 8 + ch * KG + kg) * p.N + n0 + lane % OCT);
-            glds16(src, (half ? wl_l : wl_h) + rr0 * OCT);
+            const int kgi = k0 / 8 + ch * KG + kg, n = n0 + lane % OCT;
+            uint4* const dst = (half ? wl_l : wl_h) + rr0 * OCT;
+            if (kgi < a.kgroups && n < p.N) glds16((half ? a.wl : a.wh) + ((size_t)(t * a.kgroups + kgi) * p.N + n), dst);
+            else dst[lane] = make_uint4(0u, 0u, 0u, 0u);
         }
     }
     // patch: every sample's plane with a zero halo, channel-last units, scaled by in_scale and split
@@ -1704,19 +1708,21 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_bf16x3_small_kernel(SmallA
         for (int j = 0; j < 4; ++j) {
             const int u = u0 + SMALL_THREADS * j;
             const int kg = u / per_kg, rem = u - kg * per_kg;    // kg: 8-channel group of the workgroup's NCH * 16 channels
-            const int b = rem / plane, q0 = rem - b * plane, yy = q0 / pw - HALO, xx = q0 % pw - HALO;
+            const int b = rem / plane, q0 = rem - b * plane, yy = q0 / pw - halo, xx = q0 % pw - halo;
             const bool inside = u < units && rem < p.B * plane && yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w;
-            // branch-free: the lanes outside the plane load the workgroup's first element and drop it
-            const float* src = p.x + (inside ? ((size_t)b * p.K + k0 + kg * 8) * chan + yy * p.in_w + xx : (size_t)k0 * chan);
-            const float* ssrc = p.si + (inside ? (size_t)b * p.K + k0 + kg * 8 : (size_t)k0);
+            // branch-free: the lanes outside the plane load the workgroup's first element and drop it; channels past K re-read the last one
+            const int kb = k0 + kg * 8;
+            const float* src = p.x + (inside ? (size_t)b * p.K * chan + yy * p.in_w + xx : (size_t)0);
+            const float* ssrc = p.si + (inside ? (size_t)b * p.K : (size_t)0);
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
-                const float val = src[(size_t)q * chan];
-                v[j][q] = inside ? val : 0.f;
+                const int k = inside ? min(kb + q, p.K - 1) : k0;
+                const float val = src[(size_t)k * chan];
+                v[j][q] = (inside && kb + q < p.K) ? val : 0.f;
             }
             if (p.si) {
 #pragma unroll
-                for (int q = 0; q < 8; ++q) sc[j][q] = ssrc[q];
+                for (int q = 0; q < 8; ++q) sc[j][q] = ssrc[inside ? min(kb + q, p.K - 1) : k0];
             } else {
 #pragma unroll
                 for (int q = 0; q < 8; ++q) sc[j][q] = 1.f;
@@ -1746,7 +1752,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_bf16x3_small_kernel(SmallA
         const int b = live ? pix / oplane : 0, o = live ? pix - b * oplane : 0;
         const int oy = o / p.out_w, ox = o - oy * p.out_w;
         // unit of this lane's pixel under tap (0, 0); the lanes past the last pixel read the zero unit at the end of their channel group
-        const int base = hi * per_kg + (live ? b * plane + oy * pw + ox : p.B * plane);
+        const int base = hi * per_kg + (live ? b * plane + oy * DOWN * pw + ox * DOWN : p.B * plane);
         f32x16 acc;
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
@@ -1771,7 +1777,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_bf16x3_small_kernel(SmallA
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                out[((size_t)b * p.N + n) * oplane + o] = acc[r];
+                if (n < p.N) out[((size_t)b * p.N + n) * oplane + o] = acc[r];
             }
         }
     }
@@ -1779,22 +1785,26 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_bf16x3_small_kernel(SmallA
 
 // LDS of the small-plane kernel with `nch` channel chunks per workgroup: the weight slab + the zero-haloed planes of every sample
 inline size_t small_lds_bytes(const gc_conv_desc* d, int nch) {
-    const int halo = d->kh / 2;
-    const size_t plane = (size_t)(d->in_h + 2 * halo) * (d->in_w + 2 * halo);
+    const size_t plane = (size_t)(d->in_h + 2 * d->pad_y) * (d->in_w + 2 * d->pad_x);
     return (2 * (size_t)d->kh * d->kw * KG * 64 + 2 * (size_t)nch * KG * ((size_t)d->batch * plane + 1)) * sizeof(uint4);
 }
 constexpr size_t SMALL_LDS_MAX = 160 * 1024;
 
-// shapes the small-plane kernel takes: stride 1, "same" padding, whole 16-channel chunks and 64-channel output blocks, at most 512 pixels
-// over all samples (8 x 8 planes up to batch 8) and a patch that fits the LDS next to the weight slab (many samples of tiny planes do not:
-// their halo is most of the patch)
+// shapes the small-plane kernel takes: 1x1 / 3x3 taps at stride 1 with "same" padding or at stride 2 without padding (D's down-sampling
+// convolutions after the Blur), >= 64 input channels (any count: the last 16-channel chunk may be ragged, 513 -> 512 of D's last block),
+// >= 64 output channels (any count), output planes <= 8 x 8 with at most 512 pixels over all samples, dense rows, and a patch that fits
+// the LDS next to the weight slab (many samples of tiny planes do not: their halo is most of the patch)
 inline bool small_eligible(const gc_conv_desc* d) {
 #ifdef GC_NO_SMALL
     return false;
 #endif
-    if (d->up != 1 || d->down != 1 || d->kh != d->kw || (d->kh != 1 && d->kh != 3) || d->pad_y != d->kh / 2 || d->pad_x != d->kw / 2) return false;
-    if (d->in_ch % KCB != 0 || d->in_ch < 64 || d->in_ch > MAX_K_BF16X3 || d->out_ch % 64 != 0) return false;
-    if (d->out_w > 8 || d->out_h > 8 || d->out_h != d->in_h || d->out_w != d->in_w) return false;
+    if (d->up != 1 || d->kh != d->kw || (d->kh != 1 && d->kh != 3) || d->pad_y != d->pad_x) return false;
+    if (d->down == 1) { if (d->pad_y != d->kh / 2 || d->out_h != d->in_h || d->out_w != d->in_w) return false; }
+    else if (d->down == 2) { if (d->pad_y != 0 || d->in_h < d->kh || d->in_w < d->kw || d->out_h != (d->in_h - d->kh) / 2 + 1 || d->out_w != (d->in_w - d->kw) / 2 + 1) return false; }
+    else return false;
+    if ((d->in_pitch != 0 && d->in_pitch != d->in_w) || !dense_output(d)) return false;
+    if (d->in_ch < 64 || d->in_ch > MAX_K_BF16X3 || d->out_ch < 64) return false;
+    if (d->out_w > 8 || d->out_h > 8) return false;
     const long long pixels = (long long)d->batch * d->out_h * d->out_w;
     return pixels >= 1 && pixels <= 512 && small_lds_bytes(d, 1) <= SMALL_LDS_MAX;
 }
@@ -1808,18 +1818,19 @@ inline int small_chunks(const gc_conv_desc* d) {
     const long long pixels = (long long)d->batch * d->out_h * d->out_w;
     return pixels > 16 * d->kh * d->kw ? 2 : 1;     // slices * pixels * N * 4 bytes  vs  taps * K * N * 4 bytes
 }
+inline int small_slices(const gc_conv_desc* d) { return gc::ceil_div(d->in_ch, KCB * small_chunks(d)); }
 
-template <int KS>
+template <int KS, int DOWN>
 int launch_small(const gc_conv_desc* d, const SmallArgs& sa, hipStream_t s) {
     const size_t lds = small_lds_bytes(d, small_chunks(d));
     if (small_chunks(d) == 2) {
-        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_small_kernel<KS, 1, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_small_kernel<KS, 1, 2, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
         (void)attr;
-        hipLaunchKernelGGL((conv_bf16x3_small_kernel<KS, 1, 2>), dim3(d->in_ch / (2 * KCB), d->out_ch / 32), dim3(SMALL_THREADS), lds, s, sa);
+        hipLaunchKernelGGL((conv_bf16x3_small_kernel<KS, 1, 2, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 32)), dim3(SMALL_THREADS), lds, s, sa);
     } else {
-        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_small_kernel<KS, 2, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_small_kernel<KS, 2, 1, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
         (void)attr;
-        hipLaunchKernelGGL((conv_bf16x3_small_kernel<KS, 2, 1>), dim3(d->in_ch / KCB, d->out_ch / 64), dim3(SMALL_THREADS), lds, s, sa);
+        hipLaunchKernelGGL((conv_bf16x3_small_kernel<KS, 2, 1, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 64)), dim3(SMALL_THREADS), lds, s, sa);
     }
     return gc::check_launch("gc_conv2d_bf16x3_f32(small planes)");
 }
@@ -1893,7 +1904,7 @@ SplitPlan plan_splitk_bf16(const gc_conv_desc* d) {
 }
 
 size_t splitk_bytes(const gc_conv_desc* d) {
-    if (small_eligible(d)) return (size_t)(d->in_ch / (KCB * small_chunks(d))) * d->batch * d->out_ch * d->out_h * d->out_w * sizeof(float);      // one slice per workgroup row
+    if (small_eligible(d)) return (size_t)small_slices(d) * d->batch * d->out_ch * d->out_h * d->out_w * sizeof(float);      // one slice per workgroup row
     const SplitPlan sp = plan_splitk_bf16(d);
     return sp.slices > 1 ? (size_t)sp.slices * d->batch * d->out_ch * d->out_h * d->out_w * sizeof(float) : 0;
 }
@@ -1969,7 +1980,7 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
         const size_t need_s = gc_conv2d_bf16x3_packed_bytes(d);
         if (packed_bytes < need_s || (reinterpret_cast<uintptr_t>(packed) & 15))
             return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_bf16x3_f32: packed weights %zu < %zu bytes (or not 16-byte aligned)", packed_bytes, need_s);
-        if (gc::probing()) return gc::probe_name("conv_bf16x3_small_kernel<%d,%d,%d>|up1,down1,k%d", d->kh, small_chunks(d) == 2 ? 1 : 2, small_chunks(d), d->kh);
+        if (gc::probing()) return gc::probe_name("conv_bf16x3_small_kernel<%d,%d,%d,%d>|up1,down%d,k%d", d->kh, small_chunks(d) == 2 ? 1 : 2, small_chunks(d), d->down, d->down, d->kh);
         const int kgroups_s = (d->in_ch + 7) / 8;
         const size_t units_s = (size_t)d->kh * d->kw * kgroups_s * d->out_ch;
         const uint4* wh_s = static_cast<const uint4*>(packed);
@@ -1977,10 +1988,12 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
                      wh_s, wh_s + units_s, kgroups_s, static_cast<float*>(workspace), (long long)d->batch * d->out_ch * d->out_h * d->out_w,
                      d->batch * d->out_h * d->out_w};
         set_epilogue(sa.c, ep);
-        if ((rc = d->kh == 3 ? launch_small<3>(d, sa, (hipStream_t)stream) : launch_small<1>(d, sa, (hipStream_t)stream))) return rc;
+        if (d->down == 2) rc = d->kh == 3 ? launch_small<3, 2>(d, sa, (hipStream_t)stream) : launch_small<1, 2>(d, sa, (hipStream_t)stream);
+        else              rc = d->kh == 3 ? launch_small<3, 1>(d, sa, (hipStream_t)stream) : launch_small<1, 1>(d, sa, (hipStream_t)stream);
+        if (rc) return rc;
         ConvArgs fin_s = sa.c;
         fin_s.part = sa.part;
-        return launch_splitk_finish(fin_s, d->in_ch / (KCB * small_chunks(d)), sa.per_slice, (hipStream_t)stream);
+        return launch_splitk_finish(fin_s, small_slices(d), sa.per_slice, (hipStream_t)stream);
     }
     if (!eligible(d)) return conv2d_f32_ws(d, x, w, in_scale, out_scale, ep, y, workspace, workspace_bytes, stream);
     const size_t need = gc_conv2d_bf16x3_packed_bytes(d);

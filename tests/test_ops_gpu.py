@@ -445,11 +445,15 @@ BF16_CASES = CONV_CASES + [
 # several tiles per workgroup, odd chunk counts, ragged rows (width % 4 != 0), heights that end inside a 16-row tile, 1x1 taps
 WS_CASES = [(3, 64, 128, 130, 190, 3, 1, 1, 1), (2, 80, 64, 257, 259, 3, 1, 1, 1), (2, 128, 192, 100, 132, 1, 1, 1, 0), (4, 256, 256, 64, 96, 3, 1, 1, 1),
             (2, 32, 32, 200, 262, 3, 1, 1, 1), (2, 64, 96, 130, 190, 3, 1, 1, 1), (4, 48, 32, 150, 170, 1, 1, 1, 0)]      # ... and its 32-output-channel variant
-# planes of <= 8 x 8 pixels (conv_bf16x3_small_kernel: K % 16 == 0, K >= 64, N % 64 == 0, batch * pixels <= 512): the networks' 4^2 / 8^2
+# output planes of <= 8 x 8 pixels (conv_bf16x3_small_kernel: K >= 64, N >= 64, batch * pixels <= 512): the networks' 4^2 / 8^2
 # layers, odd planes, a pixel count that ends inside a 32-pixel MFMA column block, one sample, 1x1 taps, the largest batch
 SMALL_CASES = [(4, 512, 512, 4, 4, 3, 1, 1, 1), (4, 512, 512, 8, 8, 3, 1, 1, 1), (3, 80, 64, 5, 7, 3, 1, 1, 1), (1, 64, 128, 3, 3, 3, 1, 1, 1),
                (2, 96, 64, 8, 6, 1, 1, 1, 0), (8, 64, 192, 8, 8, 3, 1, 1, 1), (5, 128, 64, 1, 1, 3, 1, 1, 1),
-               (200, 64, 64, 1, 1, 3, 1, 1, 1)]       # many samples of 1 x 1 planes: the halo fills the LDS (152 KB), one chunk per workgroup
+               (200, 64, 64, 1, 1, 3, 1, 1, 1),       # many samples of 1 x 1 planes: the halo fills the LDS (152 KB), one chunk per workgroup
+               # stride 2 without padding (D's down-sampling convolutions after the Blur: 17 -> 8, 9 -> 4), odd planes, 1x1 taps
+               (4, 512, 512, 17, 17, 3, 1, 2, 0), (4, 512, 512, 9, 9, 3, 1, 2, 0), (2, 64, 64, 7, 11, 3, 1, 2, 0), (3, 128, 64, 9, 9, 1, 1, 2, 0),
+               # ragged channel counts: 513 -> 512 (D's last block after the minibatch-stddev channel) and its input gradient 512 -> 513
+               (4, 513, 512, 4, 4, 3, 1, 1, 1), (4, 512, 513, 4, 4, 3, 1, 1, 1), (2, 72, 100, 8, 8, 3, 1, 1, 1), (2, 100, 70, 15, 15, 3, 1, 2, 0)]
 BF16_CASES = BF16_CASES + WS_CASES + SMALL_CASES + [(400, 64, 64, 1, 1, 3, 1, 1, 1)]      # ... and past the LDS: back on the general path
 
 
