@@ -60,7 +60,7 @@ def main():
         w = torch.randn(k, k, ic, oc, device=dev)
         fl = conv_flops(B, ic, oc, res, res, g)
         t = timeit(lambda: be.conv2d(x, w, None, None, g), args.reps)
-        rows.append((f'{name} {ic}->{oc} @{res}', conv_variant(g, oc, B), t * 1e6, fl / t / 1e12, 'TF/s', fl / t / 1e12 / 157.3))
+        rows.append((f'{name} {ic}->{oc} @{res}', conv_variant(g, oc, B, ic, args.mode, (res, res)), t * 1e6, fl / t / 1e12, 'TF/s', fl / t / 1e12 / 157.3))
         if up == 1:
             dy = torch.randn(B, oc, oh, oh, device=dev)
             t = timeit(lambda: be.conv2d_wgrad(x, dy, None, None, g), args.reps)
