@@ -593,6 +593,162 @@ WgradPlan plan_wgrad(const gc_conv_desc* d) {
     return pl;
 }
 
+// --------------------------------------------------------------------------------------------
+// Output planes of <= 8 x 8 pixels (the 4^2 / 8^2 layers of G and D, D's 17 -> 8 and 9 -> 4 down-sampling convolutions, 513 -> 512 of D's
+// last block: 512 channels, 9.4 MB of weights for 0.3 .. 2.4 GFLOP): the launch is bound by reading the weights once, by the partial
+// sums and by latency, not by arithmetic -- so these layers stay in EXACT fp32 in every mode (v_mfma_f32_32x32x2_f32; their sums run
+// over few pixels, where rounding errors do not average out).  One workgroup = ONE weight slab applied to every pixel of every sample,
+// either 16 input channels x 64 output channels <WOC 2, NCH 1> or 32 x 32 <WOC 1, NCH 2>: 256 workgroups for a 512 -> 512 layer both
+// ways, the second with half as many K slices to write and add up again (it needs twice the patch in LDS and is chosen when the partial
+// sums, not the weights, are the larger traffic).  The zero-haloed planes of ALL samples are staged once, scaled by in_scale; eight
+// waves take (32 pixels x 32 output channels) work items; each workgroup writes raw partial sums of its channels to part[slice], and
+// splitk_finish_kernel adds the slices in fixed order and applies out_scale + the fused epilogue.
+// conv_mfma_kernel with its split over K took 27 .. 65 us on these shapes (92 without a workspace); this one 10 .. 30 us.
+struct SmallArgs { ConvArgs c; float* part; long long per_slice; int pixels; };
+constexpr int SMALL_THREADS = 512;       // eight waves: two per SIMD hide the staging latency
+constexpr int SMALL_KC = 16;             // input channels per chunk
+
+template <int KS, int WOC, int NCH, int DOWN>
+__global__ __launch_bounds__(SMALL_THREADS) void conv_f32_small_kernel(SmallArgs a) {
+    constexpr int NTAP = KS * KS, OCT = 32 * WOC, NW = SMALL_THREADS / 64, KC = SMALL_KC;
+    constexpr int WFLOATS = NCH * NTAP * KC * OCT;               // [chunk][tap][k][oc]
+    extern __shared__ float small_smem[];
+    const ConvArgs& p = a.c;
+    const int halo = p.pad_y;                                    // = pad_x: KS / 2 at stride 1, 0 at stride 2
+    const int ph = p.in_h + 2 * halo, pw = p.in_w + 2 * halo, plane = ph * pw;      // zero-haloed plane of one sample
+    const int per_k = p.B * plane + 1;                           // + one zero for the lanes past the last pixel
+    float* wl = small_smem;
+    float* pl = wl + WFLOATS;                                    // [chunk * 16 + k][sample][ph][pw] (+ zero)
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k0 = blockIdx.x * KC * NCH, n0 = blockIdx.y * OCT;
+    // weights: w[tap][k][n], rows of OCT consecutive output channels; zeros past K / N (513 channels: a ragged last chunk)
+    constexpr int NWL = (WFLOATS + SMALL_THREADS - 1) / SMALL_THREADS;
+    float wreg[NWL];
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+        const int e = tid + SMALL_THREADS * j;
+        const int oc = e % OCT, row = e / OCT;                   // row = (chunk * NTAP + tap) * KC + k
+        const int kk = row % KC, t = row / KC % NTAP, ch = row / (KC * NTAP);
+        const int k = k0 + ch * KC + kk, n = n0 + oc;
+        const bool ok = e < WFLOATS && k < p.K && n < p.N;
+        wreg[j] = ok ? p.w[((size_t)t * p.K + k) * p.N + n] : 0.f;
+    }
+    // patch: every sample's plane with a zero halo, times in_scale.  One item = one position of the haloed planes x 8 channels (one
+    // decode of the position, eight loads in flight, eight conflict-free LDS stores: consecutive lanes hold consecutive positions)
+    const int chan = p.in_h * p.in_w, npos = p.B * plane, nitems = npos * (NCH * KC / 8);
+    for (int it = tid; it < nitems; it += SMALL_THREADS) {
+        const int kg = it / npos, pos = it - kg * npos;
+        const int b = pos / plane, q0 = pos - b * plane, yy = q0 / pw - halo, xx = q0 % pw - halo;
+        const bool inside = yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w;
+        const int kb = k0 + kg * 8;
+        const float* src = p.x + (inside ? (size_t)b * p.K * chan + yy * p.in_w + xx : (size_t)0);
+        const float* ssrc = p.si + (size_t)b * p.K;
+        float v[8], sc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = inside ? min(kb + q, p.K - 1) : 0;      // branch-free: positions in the halo load the tensor's first value and drop it
+            v[q] = src[(size_t)k * chan];
+            sc[q] = p.si ? ssrc[min(kb + q, p.K - 1)] : 1.f;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pl[(kg * 8 + q) * per_k + pos] = (inside && kb + q < p.K) ? v[q] * sc[q] : 0.f;
+    }
+    if (tid < NCH * KC) pl[tid * per_k + npos] = 0.f;          // the zero the lanes past the last pixel read
+#pragma unroll
+    for (int j = 0; j < NWL; ++j) {
+        const int e = tid + SMALL_THREADS * j;
+        if (SMALL_THREADS * (j + 1) <= WFLOATS || e < WFLOATS) wl[e] = wreg[j];
+    }
+    __syncthreads();
+    // one work item = 32 pixels x 32 output channels; the waves take them round-robin
+    const int items = (a.pixels + 31) / 32 * WOC;
+    float* out = a.part + (size_t)blockIdx.x * a.per_slice;
+    const int oplane = p.out_h * p.out_w;
+    for (int item = wave; item < items; item += NW) {
+        const int cb = item / WOC, i = item % WOC;
+        const int pix = cb * 32 + l31;
+        const bool live = pix < a.pixels;
+        const int b = live ? pix / oplane : 0, o = live ? pix - b * oplane : 0;
+        const int oy = o / p.out_w, ox = o - oy * p.out_w;
+        // this lane's pixel under tap (0, 0); the lanes past the last pixel read the zero at the end of their channel's row
+        const int base = hi * per_k + (live ? b * plane + oy * DOWN * pw + ox * DOWN : p.B * plane);
+        const int wbase = hi * OCT + i * 32 + l31;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+#pragma unroll
+            for (int t = 0; t < NTAP; ++t) {
+                const int ty = t / KS, tx = t % KS;
+                const float* pb = pl + base + (size_t)ch * KC * per_k + (live ? ty * pw + tx : 0);
+                const float* wa = wl + (ch * NTAP + t) * KC * OCT + wbase;
+#pragma unroll
+                for (int kp = 0; kp < KC / 2; ++kp)       // lanes 0..31 take channel 2 kp, lanes 32..63 channel 2 kp + 1
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[2 * kp * OCT], pb[2 * kp * per_k], acc, 0, 0, 0);
+            }
+        if (live) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                if (n < p.N) out[((size_t)b * p.N + n) * oplane + o] = acc[r];
+            }
+        }
+    }
+}
+
+// LDS of the small-plane kernel with `nch` channel chunks per workgroup: the weight slab + the zero-haloed planes of every sample
+inline size_t small_lds_bytes(const gc_conv_desc* d, int nch) {
+    const size_t plane = (size_t)(d->in_h + 2 * d->pad_y) * (d->in_w + 2 * d->pad_x);
+    return ((size_t)d->kh * d->kw * SMALL_KC * 64 + (size_t)nch * SMALL_KC * ((size_t)d->batch * plane + 1)) * sizeof(float);
+}
+constexpr size_t SMALL_LDS_MAX = 160 * 1024;
+
+// shapes the small-plane kernel takes: 1x1 / 3x3 taps at stride 1 with "same" padding or at stride 2 without padding, >= 64 input and
+// output channels (any count), output planes <= 8 x 8 with at most 512 pixels over all samples, dense rows, and a patch that fits the
+// LDS next to the weight slab (many samples of tiny planes do not: their halo is most of the patch)
+inline bool small_eligible(const gc_conv_desc* d) {
+#ifdef GC_NO_SMALL
+    return false;
+#endif
+    if (d->up != 1 || d->kh != d->kw || (d->kh != 1 && d->kh != 3) || d->pad_y != d->pad_x) return false;
+    if (d->down == 1) { if (d->pad_y != d->kh / 2 || d->out_h != d->in_h || d->out_w != d->in_w) return false; }
+    else if (d->down == 2) { if (d->pad_y != 0 || d->in_h < d->kh || d->in_w < d->kw || d->out_h != (d->in_h - d->kh) / 2 + 1 || d->out_w != (d->in_w - d->kw) / 2 + 1) return false; }
+    else return false;
+    if ((d->in_pitch != 0 && d->in_pitch != d->in_w) || !dense_output(d)) return false;
+    if (d->in_ch < 64 || d->out_ch < 64) return false;
+    if (d->out_w > 8 || d->out_h > 8) return false;
+    const long long pixels = (long long)d->batch * d->out_h * d->out_w;
+    return pixels >= 1 && pixels <= 512 && small_lds_bytes(d, 1) <= SMALL_LDS_MAX;
+}
+
+// channel chunks per workgroup: two (32 channels x 32 output channels) when the partial sums of 16-channel slices would outweigh the weights
+inline int small_chunks(const gc_conv_desc* d) {
+    if (d->in_ch % (2 * SMALL_KC) != 0 || small_lds_bytes(d, 2) > SMALL_LDS_MAX) return 1;
+#ifdef GC_SMALL_NCH
+    return GC_SMALL_NCH;
+#endif
+    const long long pixels = (long long)d->batch * d->out_h * d->out_w;
+    return pixels > 16 * d->kh * d->kw ? 2 : 1;     // slices * pixels * N * 4 bytes  vs  taps * K * N * 4 bytes
+}
+inline int small_slices(const gc_conv_desc* d) { return gc::ceil_div(d->in_ch, SMALL_KC * small_chunks(d)); }
+
+template <int KS, int DOWN>
+int launch_small(const gc_conv_desc* d, const SmallArgs& sa, hipStream_t s) {
+    const size_t lds = small_lds_bytes(d, small_chunks(d));
+    if (small_chunks(d) == 2) {
+        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 1, 2, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)attr;
+        hipLaunchKernelGGL((conv_f32_small_kernel<KS, 1, 2, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 32)), dim3(SMALL_THREADS), lds, s, sa);
+    } else {
+        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 2, 1, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+        (void)attr;
+        hipLaunchKernelGGL((conv_f32_small_kernel<KS, 2, 1, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 64)), dim3(SMALL_THREADS), lds, s, sa);
+    }
+    return gc::check_launch("gc_conv2d_f32(small planes)");
+}
+
 template <int DOWN, int KS>
 int dispatch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
     dim3 grid(gc::ceil_div(a.K, pl.kt), gc::ceil_div(a.N, pl.nt), pl.splits);
@@ -610,6 +766,7 @@ int dispatch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
 
 size_t gcconv::conv2d_f32_workspace(const gc_conv_desc* d) {
     if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->up <= 0) return 0;
+    if (small_eligible(d)) return (size_t)small_slices(d) * d->batch * d->out_ch * d->out_h * d->out_w * sizeof(float);      // one slice per workgroup row
     const SplitPlan sp = plan_splitk(d);
     return sp.slices > 1 ? (size_t)sp.slices * d->batch * d->out_ch * d->out_h * d->out_w * sizeof(float) : 0;
 }
@@ -629,8 +786,18 @@ int gcconv::conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w,
     set_epilogue(a, ep);
     a.k_per_split = 0; a.part = nullptr;
     hipStream_t s = (hipStream_t)stream;
-    const SplitPlan sp = plan_splitk(d);
     const size_t need = conv2d_f32_workspace(d);
+    if (small_eligible(d) && (gc::probing() || (workspace && workspace_bytes >= need))) {
+        if (gc::probing()) return gc::probe_name("conv_f32_small_kernel<%d,%d,%d,%d>|up1,down%d,k%d", d->kh, small_chunks(d) == 2 ? 1 : 2, small_chunks(d), d->down, d->down, d->kh);
+        SmallArgs sa{a, static_cast<float*>(workspace), (long long)d->batch * d->out_ch * d->out_h * d->out_w, d->batch * d->out_h * d->out_w};
+        if (d->down == 2) rc = d->kh == 3 ? launch_small<3, 2>(d, sa, s) : launch_small<1, 2>(d, sa, s);
+        else              rc = d->kh == 3 ? launch_small<3, 1>(d, sa, s) : launch_small<1, 1>(d, sa, s);
+        if (rc) return rc;
+        ConvArgs fin_s = a;
+        fin_s.part = sa.part;
+        return launch_splitk_finish(fin_s, small_slices(d), sa.per_slice, s);
+    }
+    const SplitPlan sp = plan_splitk(d);
     const bool split = sp.slices > 1 && workspace && workspace_bytes >= need;
     ConvArgs fin = a;
     if (split) {        // raw partial sums now, out_scale + epilogue in the finish pass
@@ -660,6 +827,14 @@ extern "C" int gc_conv2d_fused_f32(const gc_conv_desc* d, const float* x, const 
                                    const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep,
                                    float* y, gc_stream_t stream) {
     return gcconv::conv2d_f32_ws(d, x, w, in_scale, out_scale, ep, y, nullptr, 0, stream);
+}
+
+extern "C" size_t gc_conv2d_f32_workspace(const gc_conv_desc* d) { return gcconv::conv2d_f32_workspace(d); }
+
+extern "C" int gc_conv2d_fused_f32_ws(const gc_conv_desc* d, const float* x, const float* w,
+                                      const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep,
+                                      float* y, void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    return gcconv::conv2d_f32_ws(d, x, w, in_scale, out_scale, ep, y, workspace, workspace_bytes, stream);
 }
 
 extern "C" int gc_conv2d_f32(const gc_conv_desc* d, const float* x, const float* w,

@@ -1647,194 +1647,6 @@ int launch_ws(Bf16Args a, hipStream_t s) {
     return gc::check_launch("gc_conv2d_bf16x3_f32(ws)");
 }
 
-// ---------------------------------------------------------------------------------------------------------
-// Planes of <= 8 x 8 pixels (the 4^2 / 8^2 layers: 512 channels, 9.4 MB of weights for 0.3 .. 2.4 GFLOP): the launch is bound by
-// reading the weights once, by the partial sums and by latency, not by arithmetic.  One workgroup = ONE 36.8 KB weight slab (fetched by
-// LDS-DMA) applied to every pixel of every sample, either 16 input channels x 64 output channels <1 chunk, WOC 2> or 32 x 32 <2 chunks,
-// WOC 1>: 256 workgroups for a 512 -> 512 layer both ways, the second with half as many K slices to write and add up again (it needs
-// twice the patch in LDS and is chosen when the partial sums, not the weights, are the larger traffic).  Each workgroup writes raw partial
-// sums of its channels to part[slice]; splitk_finish_kernel adds the slices in fixed order and applies out_scale + the fused epilogue.
-// The exact-fp32 kernel with its split over K took 27 .. 32 us here; this one 8 .. 13 us (B 4, 512 -> 512; the finish pass 5 .. 7 us both).
-struct SmallArgs {
-    ConvArgs c; const uint4* wh; const uint4* wl; int kgroups; float* part; long long per_slice; int pixels;
-};
-
-constexpr int SMALL_THREADS = 512;       // eight waves: two per SIMD hide the staging latency; 8 x 8 planes of four samples give them one work item each
-
-template <int KS, int WOC, int NCH, int DOWN>
-__global__ __launch_bounds__(SMALL_THREADS) void conv_bf16x3_small_kernel(SmallArgs a) {
-    constexpr int NTAP = KS * KS, OCT = 32 * WOC, RPI = 64 / OCT, NW = SMALL_THREADS / 64;
-    constexpr int WUNITS = NCH * NTAP * KG * OCT;                // per hi / lo: [chunk][tap][kg][oc]
-    extern __shared__ uint4 dyn_smem[];
-    const ConvArgs& p = a.c;
-    const int halo = p.pad_y;                                    // = pad_x: KS / 2 at stride 1, 0 at stride 2
-    const int ph = p.in_h + 2 * halo, pw = p.in_w + 2 * halo, plane = ph * pw;      // zero-haloed plane of one sample
-    const int per_kg = p.B * plane + 1;                          // + one zero unit for the lanes past the last pixel
-    uint4* wl_h = dyn_smem;
-    uint4* wl_l = wl_h + WUNITS;
-    uint4* p_h = wl_l + WUNITS;                                  // [chunk][kg][sample][ph][pw] (+ zero unit)
-    uint4* p_l = p_h + NCH * KG * per_kg;
-    (void)p_l;
-    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int k0 = blockIdx.x * KCB * NCH, n0 = blockIdx.y * OCT;
-    // weights: rows (half, chunk, tap, kg) of OCT units; one LDS-DMA instruction moves 1 KiB = RPI rows (waited for before the barrier).
-    // Rows of channel groups past K (513 channels: the last chunk has one group) and units of output channels past N are zeros.
-#ifdef GC_SINGLE
-    constexpr int INSTR = NCH * NTAP * KG / RPI;
-#else
-    constexpr int INSTR = 2 * NCH * NTAP * KG / RPI;
-#endif
-#pragma unroll
-    for (int j = 0; j < (INSTR + NW - 1) / NW; ++j) {
-        const int q = wave + NW * j;
-        if (NW * j + NW - 1 < INSTR || q < INSTR) {
-            const int r0 = q * RPI;
-            const int half = r0 / (NCH * NTAP * KG), rr0 = r0 % (NCH * NTAP * KG);
-            const int rr = rr0 + lane / OCT;                     // this lane's row
-            const int ch = rr / (NTAP * KG), t = rr / KG % NTAP, kg = rr % KG;
-            const int kgi = k0 / 8 + ch * KG + kg, n = n0 + lane % OCT;
-            uint4* const dst = (half ? wl_l : wl_h) + rr0 * OCT;
-            if (kgi < a.kgroups && n < p.N) glds16((half ? a.wl : a.wh) + ((size_t)(t * a.kgroups + kgi) * p.N + n), dst);
-            else dst[lane] = make_uint4(0u, 0u, 0u, 0u);
-        }
-    }
-    // patch: every sample's plane with a zero halo, channel-last units, scaled by in_scale and split
-    // (four units per thread at a time, every load issued before the first conversion: the launch is latency-bound)
-    const int chan = p.in_h * p.in_w, units = NCH * KG * per_kg;
-    for (int u0 = tid; u0 < units; u0 += 4 * SMALL_THREADS) {
-        float v[4][8], sc[4][8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int u = u0 + SMALL_THREADS * j;
-            const int kg = u / per_kg, rem = u - kg * per_kg;    // kg: 8-channel group of the workgroup's NCH * 16 channels
-            const int b = rem / plane, q0 = rem - b * plane, yy = q0 / pw - halo, xx = q0 % pw - halo;
-            const bool inside = u < units && rem < p.B * plane && yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w;
-            // branch-free: the lanes outside the plane load the workgroup's first element and drop it; channels past K re-read the last one
-            const int kb = k0 + kg * 8;
-            const float* src = p.x + (inside ? (size_t)b * p.K * chan + yy * p.in_w + xx : (size_t)0);
-            const float* ssrc = p.si + (inside ? (size_t)b * p.K : (size_t)0);
-#pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int k = inside ? min(kb + q, p.K - 1) : k0;
-                const float val = src[(size_t)k * chan];
-                v[j][q] = (inside && kb + q < p.K) ? val : 0.f;
-            }
-            if (p.si) {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) sc[j][q] = ssrc[inside ? min(kb + q, p.K - 1) : k0];
-            } else {
-#pragma unroll
-                for (int q = 0; q < 8; ++q) sc[j][q] = 1.f;
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int u = u0 + SMALL_THREADS * j;
-            uint4 h, l;
-            split8s<true>(v[j], sc[j], &h, &l);
-            if (u < units) {
-                p_h[u] = h;
-                GC_LO(p_l[u] = l;)
-            }
-        }
-    }
-    wait_staged_loads();        // this wave's LDS-DMA rows have landed before it signals the barrier
-    __syncthreads();
-    // one work item = 32 pixels x 32 output channels; the waves take them round-robin
-    const int items = (a.pixels + 31) / 32 * WOC;
-    float* out = a.part + (size_t)blockIdx.x * a.per_slice;
-    const int oplane = p.out_h * p.out_w;
-    for (int item = wave; item < items; item += NW) {
-        const int cb = item / WOC, i = item % WOC;
-        const int pix = cb * 32 + l31;
-        const bool live = pix < a.pixels;
-        const int b = live ? pix / oplane : 0, o = live ? pix - b * oplane : 0;
-        const int oy = o / p.out_w, ox = o - oy * p.out_w;
-        // unit of this lane's pixel under tap (0, 0); the lanes past the last pixel read the zero unit at the end of their channel group
-        const int base = hi * per_kg + (live ? b * plane + oy * DOWN * pw + ox * DOWN : p.B * plane);
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int ch = 0; ch < NCH; ++ch)
-#pragma unroll
-            for (int t = 0; t < NTAP; ++t) {
-                const int ty = t / KS, tx = t % KS;
-                const int pu = base + ch * KG * per_kg + (live ? ty * pw + tx : 0);
-                const int wu = ((ch * NTAP + t) * KG + hi) * OCT + i * 32 + l31;
-                const uint4 ubh = p_h[pu], uah = wl_h[wu];
-                const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&ubh), ah = *reinterpret_cast<const bf16x8*>(&uah);
-#ifdef GC_SINGLE
-                const bf16x8 bl = bh, al = ah;
-#else
-                const uint4 ubl = p_l[pu], ual = wl_l[wu];
-                const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&ubl), al = *reinterpret_cast<const bf16x8*>(&ual);
-#endif
-                GC_MFMA3(acc, ah, al, bh, bl);
-            }
-        if (live) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                if (n < p.N) out[((size_t)b * p.N + n) * oplane + o] = acc[r];
-            }
-        }
-    }
-}
-
-// LDS of the small-plane kernel with `nch` channel chunks per workgroup: the weight slab + the zero-haloed planes of every sample
-inline size_t small_lds_bytes(const gc_conv_desc* d, int nch) {
-    const size_t plane = (size_t)(d->in_h + 2 * d->pad_y) * (d->in_w + 2 * d->pad_x);
-    return (2 * (size_t)d->kh * d->kw * KG * 64 + 2 * (size_t)nch * KG * ((size_t)d->batch * plane + 1)) * sizeof(uint4);
-}
-constexpr size_t SMALL_LDS_MAX = 160 * 1024;
-
-// shapes the small-plane kernel takes: 1x1 / 3x3 taps at stride 1 with "same" padding or at stride 2 without padding (D's down-sampling
-// convolutions after the Blur), >= 64 input channels (any count: the last 16-channel chunk may be ragged, 513 -> 512 of D's last block),
-// >= 64 output channels (any count), output planes <= 8 x 8 with at most 512 pixels over all samples, dense rows, and a patch that fits
-// the LDS next to the weight slab (many samples of tiny planes do not: their halo is most of the patch)
-inline bool small_eligible(const gc_conv_desc* d) {
-#ifdef GC_NO_SMALL
-    return false;
-#endif
-    if (d->up != 1 || d->kh != d->kw || (d->kh != 1 && d->kh != 3) || d->pad_y != d->pad_x) return false;
-    if (d->down == 1) { if (d->pad_y != d->kh / 2 || d->out_h != d->in_h || d->out_w != d->in_w) return false; }
-    else if (d->down == 2) { if (d->pad_y != 0 || d->in_h < d->kh || d->in_w < d->kw || d->out_h != (d->in_h - d->kh) / 2 + 1 || d->out_w != (d->in_w - d->kw) / 2 + 1) return false; }
-    else return false;
-    if ((d->in_pitch != 0 && d->in_pitch != d->in_w) || !dense_output(d)) return false;
-    if (d->in_ch < 64 || d->in_ch > MAX_K_BF16X3 || d->out_ch < 64) return false;
-    if (d->out_w > 8 || d->out_h > 8) return false;
-    const long long pixels = (long long)d->batch * d->out_h * d->out_w;
-    return pixels >= 1 && pixels <= 512 && small_lds_bytes(d, 1) <= SMALL_LDS_MAX;
-}
-
-// channel chunks per workgroup: two (32 channels x 32 output channels) when the partial sums of 16-channel slices would outweigh the weights
-inline int small_chunks(const gc_conv_desc* d) {
-    if (d->in_ch % (2 * KCB) != 0 || small_lds_bytes(d, 2) > SMALL_LDS_MAX) return 1;
-#ifdef GC_SMALL_NCH
-    return GC_SMALL_NCH;
-#endif
-    const long long pixels = (long long)d->batch * d->out_h * d->out_w;
-    return pixels > 16 * d->kh * d->kw ? 2 : 1;     // slices * pixels * N * 4 bytes  vs  taps * K * N * 4 bytes
-}
-inline int small_slices(const gc_conv_desc* d) { return gc::ceil_div(d->in_ch, KCB * small_chunks(d)); }
-
-template <int KS, int DOWN>
-int launch_small(const gc_conv_desc* d, const SmallArgs& sa, hipStream_t s) {
-    const size_t lds = small_lds_bytes(d, small_chunks(d));
-    if (small_chunks(d) == 2) {
-        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_small_kernel<KS, 1, 2, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)attr;
-        hipLaunchKernelGGL((conv_bf16x3_small_kernel<KS, 1, 2, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 32)), dim3(SMALL_THREADS), lds, s, sa);
-    } else {
-        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_bf16x3_small_kernel<KS, 2, 1, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)attr;
-        hipLaunchKernelGGL((conv_bf16x3_small_kernel<KS, 2, 1, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 64)), dim3(SMALL_THREADS), lds, s, sa);
-    }
-    return gc::check_launch("gc_conv2d_bf16x3_f32(small planes)");
-}
-
 // the layers the wave-specialised kernel takes: whole 16-channel chunks and 64-channel output blocks, enough chunks per tile to
 // amortise its two-stage start-up, and enough tiles to give every CU a workgroup
 inline bool ws_eligible(const Bf16Args& a) {
@@ -1904,7 +1716,6 @@ SplitPlan plan_splitk_bf16(const gc_conv_desc* d) {
 }
 
 size_t splitk_bytes(const gc_conv_desc* d) {
-    if (small_eligible(d)) return (size_t)small_slices(d) * d->batch * d->out_ch * d->out_h * d->out_w * sizeof(float);      // one slice per workgroup row
     const SplitPlan sp = plan_splitk_bf16(d);
     return sp.slices > 1 ? (size_t)sp.slices * d->batch * d->out_ch * d->out_h * d->out_w * sizeof(float) : 0;
 }
@@ -1918,13 +1729,13 @@ size_t splitk_bytes(const gc_conv_desc* d) {
 #else
 extern "C" size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d) {
     if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
-    if (!eligible(d) && !small_eligible(d)) return conv2d_f32_workspace(d);        // runs on the fp32 kernel: split-K partial sums (small planes) or nothing
+    if (!eligible(d)) return conv2d_f32_workspace(d);        // runs on the fp32 kernel: split-K partial sums (small planes) or nothing
     const size_t units = (size_t)d->kh * d->kw * ((d->in_ch + 7) / 8) * d->out_ch;
     return 2 * units * sizeof(uint4) + splitk_bytes(d);      // the split weights (gc_conv2d_fused_bf16x3_f32 packs them here), then the K slices
 }
 
 extern "C" size_t gc_conv2d_bf16x3_splitk_bytes(const gc_conv_desc* d) {
-    if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !(eligible(d) || small_eligible(d))) return 0;
+    if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !eligible(d)) return 0;
     return splitk_bytes(d);
 }
 #endif
@@ -1943,7 +1754,7 @@ extern "C" int gc_conv2d_in_pitch_ok(const gc_conv_desc* d, int mode, int wgrad)
 }
 
 extern "C" size_t gc_conv2d_bf16x3_packed_bytes(const gc_conv_desc* d) {
-    if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !(eligible(d) || (d->batch > 0 && small_eligible(d)))) return 0;
+    if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0 || !eligible(d)) return 0;
     return 2 * (size_t)d->kh * d->kw * ((d->in_ch + 7) / 8) * d->out_ch * sizeof(uint4);
 }
 
@@ -1976,25 +1787,6 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
     const bool pitched_ok = eligible(d) && d->kh == 3 && d->up == 2 && d->pad_y == 2 && d->pad_x == 2;      // the fused transposed kernel
     if (!dense_output(d) && !pitched_ok)
         return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: out_pitch %d: only the fused transposed 3x3 convolution writes pitched rows (gc_conv2d_out_pitch)", d->out_pitch);
-    if (small_eligible(d) && dense_output(d) && packed && (gc::probing() || (workspace && workspace_bytes >= splitk_bytes(d) && (reinterpret_cast<uintptr_t>(workspace) & 15) == 0))) {
-        const size_t need_s = gc_conv2d_bf16x3_packed_bytes(d);
-        if (packed_bytes < need_s || (reinterpret_cast<uintptr_t>(packed) & 15))
-            return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_bf16x3_f32: packed weights %zu < %zu bytes (or not 16-byte aligned)", packed_bytes, need_s);
-        if (gc::probing()) return gc::probe_name("conv_bf16x3_small_kernel<%d,%d,%d,%d>|up1,down%d,k%d", d->kh, small_chunks(d) == 2 ? 1 : 2, small_chunks(d), d->down, d->down, d->kh);
-        const int kgroups_s = (d->in_ch + 7) / 8;
-        const size_t units_s = (size_t)d->kh * d->kw * kgroups_s * d->out_ch;
-        const uint4* wh_s = static_cast<const uint4*>(packed);
-        SmallArgs sa{{x, w, in_scale, out_scale, y, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, 0, 0},
-                     wh_s, wh_s + units_s, kgroups_s, static_cast<float*>(workspace), (long long)d->batch * d->out_ch * d->out_h * d->out_w,
-                     d->batch * d->out_h * d->out_w};
-        set_epilogue(sa.c, ep);
-        if (d->down == 2) rc = d->kh == 3 ? launch_small<3, 2>(d, sa, (hipStream_t)stream) : launch_small<1, 2>(d, sa, (hipStream_t)stream);
-        else              rc = d->kh == 3 ? launch_small<3, 1>(d, sa, (hipStream_t)stream) : launch_small<1, 1>(d, sa, (hipStream_t)stream);
-        if (rc) return rc;
-        ConvArgs fin_s = sa.c;
-        fin_s.part = sa.part;
-        return launch_splitk_finish(fin_s, small_slices(d), sa.per_slice, (hipStream_t)stream);
-    }
     if (!eligible(d)) return conv2d_f32_ws(d, x, w, in_scale, out_scale, ep, y, workspace, workspace_bytes, stream);
     const size_t need = gc_conv2d_bf16x3_packed_bytes(d);
     if (!packed || packed_bytes < need || (reinterpret_cast<uintptr_t>(packed) & 15))

@@ -51,6 +51,8 @@ SIGNATURES = {
     'gc_channel_sum_f32': (_i32, [_vp, _vp, _i32, _i32, _i64, _vp, _sz, _vp]),
     'gc_conv2d_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     'gc_conv2d_fused_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp]),
+    'gc_conv2d_f32_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
+    'gc_conv2d_fused_f32_ws': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
     'gc_conv2d_fused_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
     'gc_conv2d_bf16x3_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_bf16x3_packed_bytes': (_sz, [ctypes.POINTER(ConvDesc)]),

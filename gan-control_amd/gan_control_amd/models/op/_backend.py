@@ -487,7 +487,10 @@ class HipBackend:
             else:
                 nbytes = lib.gc_conv2d_bf16x3_workspace(desc)
                 ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
-        elif self.conv_mode != 'f32':
+        elif self.conv_mode == 'f32':
+            nbytes = lib.gc_conv2d_f32_workspace(desc)          # K slices of a small-plane launch (planes <= 16 px wide), else 0
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev) if nbytes else None
+        else:
             raise RuntimeError('GANCONTROL_CONV_PRECISION must be f32, bf16x3 or bf16, got %r' % self.conv_mode)
         g = self._guard(dev)
         t0 = None
@@ -498,7 +501,8 @@ class HipBackend:
         if g: g.__enter__()
         try:
             if self.conv_mode == 'f32':
-                rc = lib.gc_conv2d_fused_f32(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y), _lib.stream_of(x))
+                rc = lib.gc_conv2d_fused_f32_ws(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(in_scale), _lib.ptr(out_scale), ep, _lib.ptr(y),
+                                                _lib.ptr(ws), ws.numel() * 4 if ws is not None else 0, _lib.stream_of(x))
             elif packed is not None:
                 fn = lib.gc_conv2d_fused_bf16_packed_f32 if self.conv_mode == 'bf16' else lib.gc_conv2d_fused_bf16x3_packed_f32
                 rc = fn(desc, _lib.ptr(x), _lib.ptr(w_t), _lib.ptr(packed), packed.numel() * 4, _lib.ptr(in_scale),

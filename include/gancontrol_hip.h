@@ -233,6 +233,16 @@ int gc_conv2d_fused_f32(const gc_conv_desc* d, const float* x, const float* w,
                         const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep,
                         float* y, gc_stream_t stream);
 
+/* gc_conv2d_fused_f32 with scratch memory: with gc_conv2d_f32_workspace(d) bytes (0 for most shapes) the layers whose output planes are
+ * <= 16 pixels wide are split over the input channels -- one 16 / 32-channel weight slab per workgroup over every sample for planes
+ * <= 8 x 8 (conv_f32_small_kernel), K slices of conv_mfma_kernel otherwise -- and a fixed-order pass adds the slices and applies
+ * out_scale and the epilogue: same arithmetic (exact fp32), 256 workgroups instead of 8..64.  Without workspace (or with too little) it
+ * is gc_conv2d_fused_f32. */
+size_t gc_conv2d_f32_workspace(const gc_conv_desc* d);
+int gc_conv2d_fused_f32_ws(const gc_conv_desc* d, const float* x, const float* w,
+                           const float* in_scale, const float* out_scale, const gc_conv_epilogue* ep,
+                           float* y, void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
 /* The same contraction on the bf16 matrix cores with split-bf16 ("bf16x3") arithmetic: every fp32
  * operand is split into bf16 hi + lo parts and a*b is formed as hi*hi + hi*lo + lo*hi with fp32
  * accumulation (~5e-6 relative error per layer, 5.3x the fp32 MFMA rate).  Inputs and outputs stay

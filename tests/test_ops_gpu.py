@@ -317,7 +317,17 @@ def _out_size(n, k, up, down, pad, transposed):
     return (n + 2 * pad - k) // down + 1
 
 
-@pytest.mark.parametrize('case', CONV_CASES)
+# output planes of <= 8 x 8 pixels (conv_f32_small_kernel, exact fp32 in every mode: K >= 64, N >= 64, batch * pixels <= 512): the networks' 4^2 / 8^2
+# layers, odd planes, a pixel count that ends inside a 32-pixel MFMA column block, one sample, 1x1 taps, the largest batch
+SMALL_CASES = [(4, 512, 512, 4, 4, 3, 1, 1, 1), (4, 512, 512, 8, 8, 3, 1, 1, 1), (3, 80, 64, 5, 7, 3, 1, 1, 1), (1, 64, 128, 3, 3, 3, 1, 1, 1),
+               (2, 96, 64, 8, 6, 1, 1, 1, 0), (8, 64, 192, 8, 8, 3, 1, 1, 1), (5, 128, 64, 1, 1, 3, 1, 1, 1),
+               (200, 64, 64, 1, 1, 3, 1, 1, 1),       # many samples of 1 x 1 planes: the halo fills the LDS (152 KB), one chunk per workgroup
+               # stride 2 without padding (D's down-sampling convolutions after the Blur: 17 -> 8, 9 -> 4), odd planes, 1x1 taps
+               (4, 512, 512, 17, 17, 3, 1, 2, 0), (4, 512, 512, 9, 9, 3, 1, 2, 0), (2, 64, 64, 7, 11, 3, 1, 2, 0), (3, 128, 64, 9, 9, 1, 1, 2, 0),
+               # ragged channel counts: 513 -> 512 (D's last block after the minibatch-stddev channel) and its input gradient 512 -> 513
+               (4, 513, 512, 4, 4, 3, 1, 1, 1), (4, 512, 513, 4, 4, 3, 1, 1, 1), (2, 72, 100, 8, 8, 3, 1, 1, 1), (2, 100, 70, 15, 15, 3, 1, 2, 0)]
+
+@pytest.mark.parametrize('case', CONV_CASES + SMALL_CASES)
 def test_conv2d_kernel(case):
     from gan_control_amd.models.op._backend import ConvGeom
     hip, emu = _be()
@@ -329,6 +339,9 @@ def test_conv2d_kernel(case):
     so = torch.rand(b, N, generator=gen) + 0.5
     oh, ow = _out_size(h, k, up, down, pad, up > 1), _out_size(w, k, up, down, pad, up > 1)
     geom = ConvGeom(k, k, up, down, pad, pad, oh, ow)
+    if case in SMALL_CASES:
+        from gan_control_amd.utils.profiling import conv_variant
+        assert conv_variant(geom, N, b, K, 'f32', (h, w)).startswith('conv_f32_small_kernel'), 'this shape is meant to reach the small-plane kernel'
     for use_scales in (False, True):
         a = (si, so) if use_scales else (None, None)
         ref = emu.conv2d(x.double(), wt.double(), *[None if t is None else t.double() for t in a], geom)
@@ -445,15 +458,6 @@ BF16_CASES = CONV_CASES + [
 # several tiles per workgroup, odd chunk counts, ragged rows (width % 4 != 0), heights that end inside a 16-row tile, 1x1 taps
 WS_CASES = [(3, 64, 128, 130, 190, 3, 1, 1, 1), (2, 80, 64, 257, 259, 3, 1, 1, 1), (2, 128, 192, 100, 132, 1, 1, 1, 0), (4, 256, 256, 64, 96, 3, 1, 1, 1),
             (2, 32, 32, 200, 262, 3, 1, 1, 1), (2, 64, 96, 130, 190, 3, 1, 1, 1), (4, 48, 32, 150, 170, 1, 1, 1, 0)]      # ... and its 32-output-channel variant
-# output planes of <= 8 x 8 pixels (conv_bf16x3_small_kernel: K >= 64, N >= 64, batch * pixels <= 512): the networks' 4^2 / 8^2
-# layers, odd planes, a pixel count that ends inside a 32-pixel MFMA column block, one sample, 1x1 taps, the largest batch
-SMALL_CASES = [(4, 512, 512, 4, 4, 3, 1, 1, 1), (4, 512, 512, 8, 8, 3, 1, 1, 1), (3, 80, 64, 5, 7, 3, 1, 1, 1), (1, 64, 128, 3, 3, 3, 1, 1, 1),
-               (2, 96, 64, 8, 6, 1, 1, 1, 0), (8, 64, 192, 8, 8, 3, 1, 1, 1), (5, 128, 64, 1, 1, 3, 1, 1, 1),
-               (200, 64, 64, 1, 1, 3, 1, 1, 1),       # many samples of 1 x 1 planes: the halo fills the LDS (152 KB), one chunk per workgroup
-               # stride 2 without padding (D's down-sampling convolutions after the Blur: 17 -> 8, 9 -> 4), odd planes, 1x1 taps
-               (4, 512, 512, 17, 17, 3, 1, 2, 0), (4, 512, 512, 9, 9, 3, 1, 2, 0), (2, 64, 64, 7, 11, 3, 1, 2, 0), (3, 128, 64, 9, 9, 1, 1, 2, 0),
-               # ragged channel counts: 513 -> 512 (D's last block after the minibatch-stddev channel) and its input gradient 512 -> 513
-               (4, 513, 512, 4, 4, 3, 1, 1, 1), (4, 512, 513, 4, 4, 3, 1, 1, 1), (2, 72, 100, 8, 8, 3, 1, 1, 1), (2, 100, 70, 15, 15, 3, 1, 2, 0)]
 BF16_CASES = BF16_CASES + WS_CASES + SMALL_CASES + [(400, 64, 64, 1, 1, 3, 1, 1, 1)]      # ... and past the LDS: back on the general path
 
 
@@ -475,7 +479,7 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
         assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_bf16x3_ws_kernel'), 'this shape is meant to reach the wave-specialised kernel'
     if case in SMALL_CASES:
         from gan_control_amd.utils.profiling import conv_variant
-        assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_bf16x3_small_kernel'), 'this shape is meant to reach the small-plane kernel'
+        assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_f32_small_kernel'), 'this shape is meant to reach the small-plane kernel (exact fp32 in this mode too)'
     for use_scales in (False, True):
         a = (si, so) if use_scales else (None, None)
         ref = emu.conv2d(x.double(), wt.double(), *[None if t is None else t.double() for t in a], geom)
