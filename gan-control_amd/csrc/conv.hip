@@ -541,7 +541,15 @@ __global__ __launch_bounds__(256) void splitk_finish_kernel(ConvArgs p, int slic
     const long long plane = (long long)p.out_h * p.out_w;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < per_slice; i += (long long)gridDim.x * 256) {
         float acc = 0.f;
-        for (int z = 0; z < slices; ++z) acc += p.part[z * per_slice + i];
+        int z = 0;
+        for (; z + 8 <= slices; z += 8) {        // eight loads in flight, added in slice order (the launch is latency-bound: <= 2 blocks per CU)
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = p.part[(z + u) * per_slice + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; z < slices; ++z) acc += p.part[z * per_slice + i];
         const long long bn = i / plane, o = i - bn * plane;
         const int n = (int)(bn % p.N), b = (int)(bn / p.N);
         const float so = p.so ? p.so[(size_t)b * p.N + n] : 1.f, bias = p.bias ? p.bias[n] : 0.f;
