@@ -52,6 +52,8 @@ SIGNATURES = {
     'gc_conv2d_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp]),
     'gc_conv2d_fused_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp]),
     'gc_conv2d_f32_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
+    'gc_small_gemm_ok': (_i32, [_i32, _i32, _i32, _i64, _i64]),
+    'gc_small_gemm_f32': (_i32, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _f32, _f32, _vp, _i32, _i32, _i32, _vp]),
     'gc_conv2d_fused_f32_ws': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
     'gc_conv2d_fused_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, ctypes.POINTER(ConvEpilogue), _vp, _vp, _sz, _vp]),
     'gc_conv2d_bf16x3_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),

@@ -296,6 +296,29 @@ class HipBackend:
                    'gc_resize_bilinear_f32')
         return out
 
+    def small_gemm_ok(self, a, b):
+        """True when alpha * (a @ b) + beta * bias is taken by gc_small_gemm_f32 (inner extent <= 8, output <= 2^19 elements)."""
+        if not (a.is_cuda and b.is_cuda and a.dtype == torch.float32 and b.dtype == torch.float32 and a.dim() == 2 and b.dim() == 2):
+            return False
+        return bool(_lib.load().gc_small_gemm_ok(a.shape[0], a.shape[1], b.shape[1], b.stride(0), b.stride(1)))
+
+    def small_gemm(self, a, b, bias, beta, alpha):
+        """alpha * (a [M, K] @ b [K, N]) + beta * bias [N]; a and b may be transposed views (strides are passed on)."""
+        dev = a.device
+        if bias is not None:
+            _lib.require_cuda_f32(bias)
+        m, k, n = a.shape[0], a.shape[1], b.shape[1]
+        out = torch.empty((m, n), dtype=torch.float32, device=dev)
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = _lib.load().gc_small_gemm_f32(_lib.ptr(a), a.stride(0), a.stride(1), _lib.ptr(b), b.stride(0), b.stride(1), _lib.ptr(bias),
+                                               float(beta), float(alpha), _lib.ptr(out), m, k, n, _lib.stream_of(a))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_small_gemm_f32')
+        return out
+
     def rows_sum_div(self, partial, den=None):
         """[..., J] -> [...]: sum over the last dim, divided by ``den`` (same leading shape; a zero divisor counts as one)."""
         dev = _lib.require_cuda_f32(partial, den)

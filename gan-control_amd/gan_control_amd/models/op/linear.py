@@ -6,8 +6,12 @@ the way forward, but autograd's formulas for addmm / mm multiply by alpha in a s
 way back (and again in the second-order passes of the path-length regulariser).  The Functions here keep the scale inside the GEMM call in
 every direction and are closed under differentiation.
 """
+import os
+
 import torch
 from torch import autograd
+
+_SMALL_GEMM = os.environ.get('GANCONTROL_SMALL_GEMM', '1') != '0'
 
 _ZERO = {}
 
@@ -20,6 +24,19 @@ def _zero1(like):
     return t
 
 
+def _addmm(bias, a, b, beta, alpha):
+    """beta * bias + alpha * (a @ b): gc_small_gemm_f32 when the INNER extent is tiny (the weight gradients of the style path, rank-B
+    updates: a GEMM library is all latency there), torch.addmm otherwise (and on the CPU)."""
+    if a.is_cuda:
+        from . import _backend
+        be = _backend.get()
+        if _SMALL_GEMM and getattr(be, 'small_gemm_ok', None) is not None and be.small_gemm_ok(a, b) and (bias is None or (bias.dim() == 1 and bias.is_contiguous() and bias.dtype == torch.float32)):
+            return be.small_gemm(a, b, bias, beta, alpha)
+    if bias is None:
+        return torch.addmm(_zero1(a), a, b, beta=0, alpha=alpha)
+    return torch.addmm(bias, a, b, beta=beta, alpha=alpha)
+
+
 class _ScaledMM(autograd.Function):
     """alpha * (a @ b) as ONE GEMM call (the scale rides in the GEMM's alpha); closed under differentiation, so the backward and the
     second-order passes of the 34 EqualLinear layers of G are GEMM calls only -- autograd's own formulas for addmm / mm issue a separate
@@ -29,7 +46,7 @@ class _ScaledMM(autograd.Function):
     def forward(ctx, a, b, alpha):
         ctx.save_for_backward(a, b)
         ctx.alpha = alpha
-        return torch.addmm(_zero1(a), a, b, beta=0, alpha=alpha)
+        return _addmm(None, a, b, 0.0, alpha)
 
     @staticmethod
     def backward(ctx, g):
@@ -46,7 +63,7 @@ class _EqualLinearFn(autograd.Function):
     def forward(ctx, x, weight, bias, alpha, beta):
         ctx.save_for_backward(x, weight)
         ctx.alpha, ctx.beta = alpha, beta
-        return torch.addmm(bias, x, weight.t(), beta=beta, alpha=alpha)
+        return _addmm(bias, x, weight.t(), beta, alpha)
 
     @staticmethod
     def backward(ctx, g):

@@ -195,6 +195,18 @@ typedef struct gc_conv_desc {
                           * convolution output are never 16-byte aligned, and their partial-line stores bound that kernel. */
 } gc_conv_desc;
 
+/* Products with a tiny INNER extent (the weight gradients of the style path: EqualLinear gan_model.py:171-202 on [B, 512] latents, the
+ * modulation / demodulation algebra of ModulatedConv2d gan_model.py:284-293 -- g[B, C]^T @ x[B, 512], a rank-B update):
+ *
+ *   out[M, N] (dense, row-major) = alpha * (a[M, K] @ b[K, N]) + beta * bias[N]        K <= 8
+ *
+ * a and b are addressed through element strides (transposed views need no copy); bias may be NULL.
+ * torch.addmm(bias, a, b, beta=beta, alpha=alpha) for the shape where a library GEMM is all latency.
+ * gc_small_gemm_ok() says whether a shape is taken (1: K <= 8 and M * N <= 2^19) or should go to a GEMM library (0). */
+int gc_small_gemm_ok(int M, int K, int N, int64_t sb0, int64_t sb1);
+int gc_small_gemm_f32(const float* a, int64_t sa0, int64_t sa1, const float* b, int64_t sb0, int64_t sb1,
+                      const float* bias, float beta, float alpha, float* out, int M, int K, int N, gc_stream_t stream);
+
 /* The row pitch (floats, a multiple of 32) the convolution of `d` in arithmetic `mode` (0 f32, 1 bf16x3, 2 bf16) can write its output with
  * when that pays -- the fused transposed 3x3 convolution with an odd output width -- or 0: write dense rows. */
 int gc_conv2d_out_pitch(const gc_conv_desc* d, int mode);

@@ -968,3 +968,50 @@ def test_bf16_mode_network_and_iteration():
             assert a == a and abs(a - b) <= 0.1 * max(1.0, abs(b)), (k, a, b)
     finally:
         hip.conv_mode = prev
+
+
+SMALL_GEMM_CASES = [
+    # (M, K, N, a transposed view, b layout 'kn' (n contiguous) / 'nk' (k contiguous), bias): inner extent <= 8
+    (512, 4, 512, True, 'kn', False), (256, 8, 512, True, 'kn', False),       # EqualLinear weight gradients g^T @ x
+    (32, 8, 512, True, 'kn', False), (64, 3, 100, False, 'kn', True), (4, 4, 4, False, 'kn', True), (70, 1, 33, False, 'nk', True), (3, 2, 1, True, 'nk', False),
+]
+
+
+@pytest.mark.parametrize('case', SMALL_GEMM_CASES)
+def test_small_gemm(case):
+    """gc_small_gemm_f32 == alpha * (a @ b) + beta * bias in fp64, through transposed views (strides, no copies)."""
+    hip, _ = _be()
+    m, k, n, a_t, b_layout, with_bias = case
+    gen = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    a = (torch.randn(k, m, generator=gen).to(DEV).t() if a_t else torch.randn(m, k, generator=gen).to(DEV))
+    b = (torch.randn(n, k, generator=gen).to(DEV).t() if b_layout == 'nk' else torch.randn(k, n, generator=gen).to(DEV))
+    bias = torch.randn(n, generator=gen).to(DEV) if with_bias else None
+    assert hip.small_gemm_ok(a, b)
+    out = hip.small_gemm(a, b, bias, 0.01, 0.37)
+    ref = 0.37 * (a.double() @ b.double()) + (0.01 * bias.double() if with_bias else 0.0)
+    assert out.shape == (m, n) and rel_err(out, ref) < 2e-6
+    assert torch.equal(out, hip.small_gemm(a, b, bias, 0.01, 0.37))          # deterministic
+    assert not hip.small_gemm_ok(torch.randn(4, 512, device=DEV), torch.randn(512, 512, device=DEV))        # skinny products stay on the GEMM library
+
+
+def test_equal_linear_small_gemm_autograd():
+    """equal_linear / scaled_mm on the small-product kernels: values, first and second derivatives against plain fp64 ATen."""
+    from gan_control_amd.models.op.linear import equal_linear, scaled_mm
+    gen = torch.Generator().manual_seed(3)
+    x = torch.randn(4, 512, generator=gen).to(DEV).requires_grad_(True)
+    w = (torch.randn(96, 512, generator=gen) * 0.05).to(DEV).requires_grad_(True)
+    b = torch.randn(96, generator=gen).to(DEV).requires_grad_(True)
+    v = torch.randn(4, 96, generator=gen).to(DEV)
+    u = torch.randn(4, 512, generator=gen).to(DEV)
+
+    def run(xx, ww, bb, lin):
+        y = lin(xx, ww, bb)
+        gx, = torch.autograd.grad((y * v.to(y.dtype)).sum() + (y ** 2).sum(), xx, create_graph=True)
+        gw, gb, gx2 = torch.autograd.grad((gx * u.to(y.dtype)).sum(), [ww, bb, xx], allow_unused=True)
+        return y, gx, gw, gx2
+
+    got = run(x, w, b, lambda xx, ww, bb: equal_linear(xx, ww, bb, 0.3, 0.01) + scaled_mm(xx, ww.t(), 0.2))
+    xd, wd, bd = (t.detach().double().requires_grad_(True) for t in (x, w, b))
+    ref = run(xd, wd, bd, lambda xx, ww, bb: 0.01 * bb + 0.3 * (xx @ ww.t()) + 0.2 * (xx @ ww.t()))
+    for g_, r_ in zip(got, ref):
+        assert rel_err(g_, r_) < 5e-6
