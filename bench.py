@@ -1,8 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- images/sec of the full G+D training step on synthetic FFHQ-shaped batches.
 
-One process per GPU.  ``python bench.py`` runs N=1; for N>1 the driver launches it with
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (RCCL).
+One process per GPU.  ``python bench.py`` runs N=1.  For N>1 either the driver launches it with
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` (RCCL), or -- when WORLD_SIZE is
+not set -- ``python bench.py --gpus N`` launches exactly that command itself as a CHILD process before anything here
+touches the GPU, relays the child's JSON line and exits with its code (the reference's train_generator.py:12-19 is one
+command too).
 
 A "step" is one iteration of the reference loop (generator_trainer.py:351-353):
 discriminator_update + generator_update with d_every=1, g_reg_every=4, d_reg_every=16,
@@ -18,12 +21,23 @@ Rank 0 prints ONE JSON line with the contract fields plus
   "roofline":      the dominant kernel's achieved TFLOP/s (algorithmic flops / HIP-event time on the
                    launch stream, measured inside the timed region) against the fp32 MFMA peak,
   "cpu_baseline":  the oracle (CPU restatement of the reference FUSED=False path) timed on the
-                   host cores on a bounded sample of the same workload.
+                   host cores on a bounded sample of the same workload,
+  "families":      per kernel family (stride-1 conv, transposed conv, stride-2 conv, weight gradients, FIR, activation /
+                   plane reductions, RGB-side pointwise kernels, weight re-layouts, ATen) ms and launches per step with the
+                   achieved rate against its roofline -- from one UNTIMED pass of 16 iterations under torch.profiler
+                   after the timed region,
+  "step_roofline": algorithmic convolution TFLOP per step (tallied launch by launch over that pass) / ms_per_step,
+  "phases_fired":  how many lazy-regulariser passes fell inside the timed window,
+  "comm":          (N > 1) gradient bytes handed to RCCL per step and the compute-stream stall they caused.
 """
 import argparse
 import json
 import os
+import re
+import socket
+import subprocess
 import sys
+import tempfile
 import time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
@@ -38,7 +52,7 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: bf16 MFMA, dense (the s
 PEAK_HBM_GBS = 8000.0             # MI355X_MICROARCH.md: HBM3E spec peak
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=32)
@@ -52,7 +66,122 @@ def parse():
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--timer', default='roofline', choices=['roofline', 'all'], help='which launches get HIP-event brackets in the timed region')
     ap.add_argument('--cpu-baseline-size', type=int, default=None, help='resolution of the CPU sample (default: --size)')
-    return ap.parse_args()
+    ap.add_argument('--no-families', action='store_true', help='skip the untimed profiler pass behind "families" / "step_roofline"')
+    return ap.parse_args(argv)
+
+
+def self_launch(args, argv, entry):
+    """``bench.py --gpus N`` outside torch.distributed.run: start the N-rank job as a child and relay it.
+
+    Runs before any GPU call or torch.cuda query of this process (re-exec'ing a process that has initialised the GPU takes
+    the machine down on this pool; a child process is safe)."""
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), entry] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this host driver
+    env.setdefault('NCCL_DEBUG', 'VERSION')                 # RCCL prints its version line once: evidence of which library ran
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif proc.returncode == 0:
+        print('bench.py: the %d-rank child printed no JSON line' % args.gpus, file=sys.stderr)
+        return 1
+    return proc.returncode
+
+
+# kernel name -> family.  Stride-1 convolutions include the input gradients of stride-1 layers (the same kernels); the input gradient of
+# a transposed convolution is a stride-2 convolution and vice versa.  Two spellings arrive here: the profiler's demangled names
+# (`conv_bf16x3_kernel<1, 4, 2, 1, 1, 2, 3>(...)`: template arguments ..., UP, DOWN, KS) and the backend's tally names
+# (`conv_bf16x3_kernel<1,4,2,1>|up1,down2,k3`: geometry after the bar).
+_GEOM_TAG = re.compile(r'\|up(\d+),down(\d+)')
+_TEMPLATE = re.compile(r'(conv_bf16x3_kernel|conv_mfma_kernel)<([^>]*)>')
+_SIMPLE = (
+    ('rccl', re.compile(r'rccl|nccl', re.I)),
+    ('wgrad', re.compile(r'wgrad_')),
+    ('pointwise', re.compile(r'pw_(narrow|widen|wgrad)')),
+    ('convt', re.compile(r'convt_fused')),
+    ('fir', re.compile(r'fir44|firK|generic_kernel|affine_warp|reflect_pad')),
+    ('bias_act', re.compile(r'bias_act|plane_dot|channel_sum|rows_sum_div')),
+    ('weights', re.compile(r'weight_layout|pack_weights')),
+    ('style', re.compile(r'outer_kernel|style_')),
+)
+
+
+def family_of(name):
+    for fam, rx in _SIMPLE:
+        if rx.search(name):
+            return fam
+    if 'conv_' not in name and 'splitk_finish' not in name:
+        return 'aten'
+    up = down = 1
+    m = _GEOM_TAG.search(name)
+    if m:
+        up, down = int(m.group(1)), int(m.group(2))
+    else:
+        m = _TEMPLATE.search(name)
+        if m:
+            t = [int(v) for v in m.group(2).replace(' ', '').split(',')]
+            if len(t) >= 7:
+                up, down = t[-3], t[-2]
+        elif 'conv_f32_small_kernel<' in name:
+            t = [int(v) for v in name.split('conv_f32_small_kernel<')[1].split('>')[0].replace(' ', '').split(',')]
+            down = t[3] if len(t) >= 4 else 1
+    return 'convt' if up > 1 else ('conv_s2' if down > 1 else 'conv_s1')
+
+
+def family_table(trainer, it, real, backend, precision, steps, KernelTimer, world, use_dist):
+    """One untimed pass of ``steps`` iterations (a whole cadence cycle of the lazy regularisers) under torch.profiler: device time
+    and launches per kernel family from the profiler's kernel records, algorithmic work per family from the backend's launch
+    tallies (flops for the convolutions, bytes for the FIR / activation kernels that report them)."""
+    import torch
+    from torch.profiler import profile, ProfilerActivity
+    tally = KernelTimer(only=None)
+    backend.timer = tally
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(steps):
+            trainer.train_iteration(it, real)
+            it += 1
+        torch.cuda.synchronize()
+    backend.timer = None
+    path = os.path.join(tempfile.mkdtemp(prefix='gc_bench_'), 'trace.json')
+    prof.export_chrome_trace(path)
+    events = json.load(open(path))['traceEvents']
+    os.remove(path)
+    fam = {}
+    for e in events:
+        if e.get('cat') == 'kernel' and 'dur' in e:
+            d = fam.setdefault(family_of(e['name']), {'us': 0.0, 'launches': 0})
+            d['us'] += e['dur']
+            d['launches'] += 1
+    work = {}
+    for name, _, _, w in tally.records:
+        f = 'wgrad' if name.startswith('wgrad') else ('bias_act' if name.startswith('bias_act') else family_of(name))
+        work[f] = work.get(f, 0.0) + w
+    mfma_peak = PEAK_FP32_MFMA_TFLOPS if precision == 'f32' else PEAK_BF16_MFMA_TFLOPS
+    out = {}
+    for f, d in sorted(fam.items(), key=lambda kv: -kv[1]['us']):
+        row = {'ms_per_step': round(d['us'] / 1e3 / steps, 3), 'launches_per_step': round(d['launches'] / steps, 1), 'achieved': None, 'peak': None,
+               'unit': None, 'frac': None}
+        w = work.get(f)
+        if w and d['us'] > 0:
+            if f in ('conv_s1', 'conv_s2', 'convt', 'wgrad'):
+                row.update(achieved=round(w / (d['us'] * 1e-6) / 1e12, 1), peak=mfma_peak, unit='TFLOP/s')
+            elif f in ('fir',):
+                row.update(achieved=round(w / (d['us'] * 1e-6) / 1e9, 1), peak=PEAK_HBM_GBS, unit='GB/s')
+            if row['achieved'] is not None:
+                row['frac'] = round(row['achieved'] / row['peak'], 4)
+        out[f] = row
+    conv_flops = sum(work.get(f, 0.0) for f in ('conv_s1', 'conv_s2', 'convt', 'wgrad', 'pointwise'))
+    return out, conv_flops / steps, it
 
 
 def cpu_baseline(size):
@@ -70,7 +199,25 @@ def cpu_baseline(size):
         avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    cores = min(avail, 32)       # MKL-DNN grouped convs stop scaling (and thrash) far below a 256-thread host
+    # How many threads?  Measured, not asserted: one D step (forward + backward: 89 % of a CPU iteration is convolution forward /
+    # backward) of the oracle at 256x256, batch 1, at each candidate count; the fastest runs the sample.  The sweep
+    # goes into the JSON line ("thread_sweep"); profiles/cpu_threads_r03.json holds a longer one at the sample's own resolution.
+    sweep = {}
+    torch.manual_seed(0)
+    cal = 256
+    g = Generator(cal, 512, 8, channel_multiplier=2, conv_transpose=True)
+    d = Discriminator(cal, channel_multiplier=2)
+    o = OracleStep(g.state_dict(), d.state_dict(), cal, 1)
+    gen = torch.Generator().manual_seed(0)
+    real = torch.rand(1, 3, cal, cal, generator=gen) * 2 - 1
+    z = torch.randn(1, 512, generator=gen)
+    for n in sorted({c for c in (8, 16, 32, 64, 128, avail // 2, avail) if 1 <= c <= avail}):
+        torch.set_num_threads(n)
+        o.d_step(real, z)                 # first call at this count: thread pool start-up, primitive caches
+        t0 = time.perf_counter()
+        o.d_step(real, z)
+        sweep[n] = time.perf_counter() - t0
+    cores = min(sweep, key=sweep.get)
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     g = Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True)
@@ -92,32 +239,57 @@ def cpu_baseline(size):
     per_iter = phases['d_step'] + phases['g_step'] + phases['r1_step'] / 16 + phases['pl_step'] / 4
     plain = phases['d_step'] + phases['g_step']
     return {'value': 1.0 / per_iter, 'unit': 'images/sec', 'cores': cores, 'host_cores': host_cores, 'kind': 'port',
+            'thread_sweep': {'workload': 'oracle D step (forward + backward) at 256x256, batch 1, seconds', 'seconds': {str(k): round(v, 3) for k, v in sweep.items()}},
             'phase_seconds': {k: round(v, 2) for k, v in phases.items()},
             'value_without_regularisers': 1.0 / plain,
             'sample': f'one call of each phase (D step, R1, G step, path length) at {size}x{size}, batch 1, fp32, oracle/step.py OracleStep on '
-                      f'{cores} of {host_cores} host threads, {sum(phases.values()):.1f} s; images/sec = 1 / (t_D + t_G + t_R1/16 + t_PL/4), '
+                      f'{cores} of {host_cores} host threads (the fastest of the thread sweep in this line), {sum(phases.values()):.1f} s; images/sec = 1 / (t_D + t_G + t_R1/16 + t_PL/4), '
                       f'the cadence of the GPU step (the lazy regularisers are {100 * (per_iter / plain - 1):.0f} % of the CPU iteration)'}
 
 
-def main():
-    args = parse()
+# Tests only (tests/bench_emulated_entry.py): the launcher / rank plumbing of this file exercised on CPUs over gloo with the emulated
+# C ABI installed by the test entry.  Never set by bench.py itself: without it the bench refuses to run without a GPU.
+_TEST_CPU = {'enabled': False}
+
+
+def _sync():
+    if not _TEST_CPU['enabled']:
+        torch.cuda.synchronize()
+
+
+def main(argv=None, entry=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        # nothing above this line has touched the GPU (importing torch does not)
+        raise SystemExit(self_launch(args, argv, entry or os.path.abspath(__file__)))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)')
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
-    torch.cuda.set_device(local_rank)
+    cpu_test = _TEST_CPU['enabled']
+    if not cpu_test:
+        if not torch.cuda.is_available():
+            raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+        torch.cuda.set_device(local_rank)
     if world > 1:
         torch.set_num_threads(4)          # N ranks share the host: do not let each spawn one intra-op thread per core
     use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('GANCONTROL_FORCE_DDP') == '1')
+    rccl = None
     if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29511')
-        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        if cpu_test:
+            dist.init_process_group('gloo', rank=rank, world_size=world)
+        else:
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', local_rank))
+        rccl = {'ranks': dist.get_world_size(), 'backend': dist.get_backend()}
+        if not cpu_test:
+            try:
+                rccl['version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())     # RCCL reports through the nccl interface
+            except Exception as e:       # noqa: BLE001
+                rccl['version'] = 'unavailable (%s)' % type(e).__name__
 
     from gan_control_amd import _lib
     _lib.load()                                   # fail loudly without the HIP library
@@ -125,18 +297,23 @@ def main():
     from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
     from gan_control_amd.utils.profiling import KernelTimer
 
-    if args.precision:
+    if cpu_test:
+        args.no_kernel_timer = args.no_families = args.no_fp32_leg = True
+    elif args.precision:
         _backend.get().conv_mode = args.precision
-    precision = _backend.get().conv_mode
+    precision = getattr(_backend.get(), 'conv_mode', 'emulated')
     cfg = default_config(args.size, args.batch_per_gpu * world)
-    trainer = GeneratorTrainer(cfg, device=f'cuda:{local_rank}', seed=0)
+    dev = 'cpu' if cpu_test else f'cuda:{local_rank}'
+    trainer = GeneratorTrainer(cfg, device=dev, seed=0)
     real = trainer.synthetic_batch()              # resident in HBM before the timed region
+    for red in (trainer.g_reducer, trainer.d_reducer):
+        red.measure = use_dist and not cpu_test
 
     def barrier():
-        torch.cuda.synchronize()
+        _sync()
         if use_dist:
             dist.barrier()
-        torch.cuda.synchronize()
+        _sync()
 
     def roofline_of(timer_summary, elapsed_s):
         convs = {k: v for k, v in timer_summary.items() if k.startswith('conv_')}
@@ -163,7 +340,7 @@ def main():
     timer = None
     if rank == 0 and not args.no_kernel_timer:
         if discover is not None:
-            torch.cuda.synchronize()
+            _sync()
             found = discover.summary()
             names = {'fir44_tile_kernel'}
             if found:
@@ -173,6 +350,9 @@ def main():
             timer = KernelTimer(only=None)
         _backend.get().timer = timer
     barrier()
+    for red in (trainer.g_reducer, trainer.d_reducer):
+        red.comm_summary(reset=True)              # drop what warm-up tallied
+    first_timed = it
     t0 = time.perf_counter()
     for _ in range(args.steps):
         trainer.train_iteration(it, real)
@@ -180,8 +360,19 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     _backend.get().timer = None
+    tc = cfg['training_config']
+    timed = range(first_timed, first_timed + args.steps)
+    phases_fired = {'d': sum(1 for i in timed if i % tc['d_every'] == 0), 'g': args.steps,
+                    'r1': sum(1 for i in timed if i % tc['d_reg_every'] == 0), 'pl': sum(1 for i in timed if i % tc['g_reg_every'] == 0),
+                    'cadence': {'r1_every': tc['d_reg_every'], 'pl_every': tc['g_reg_every']}}
+    comm = None
+    if use_dist and not cpu_test:
+        parts = [red.comm_summary() for red in (trainer.g_reducer, trainer.d_reducer)]
+        comm = {'bytes_per_step': sum(c['bytes'] for c in parts) / args.steps, 'exposed_ms_per_step': sum(c['exposed_ms'] for c in parts) / args.steps,
+                'note': 'gradient payload handed to the all-reduce per rank and step; exposed = compute-stream stall at GradientReducer.finish() '
+                        '(HIP events either side of the waits), i.e. communication that backward did not hide'}
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
@@ -194,7 +385,7 @@ def main():
         _backend.get().conv_mode = 'f32'
         disc32 = KernelTimer(only=('conv',)) if (rank == 0 and not args.no_kernel_timer) else None
         _backend.get().timer = disc32
-        for _ in range(args.warmup):
+        while it % 16 != first_timed % 16 or it < first_timed + args.steps + args.warmup:      # same phase alignment as the first timed region
             trainer.train_iteration(it, real)
             it += 1
         timer32 = None
@@ -212,7 +403,7 @@ def main():
         el32 = time.perf_counter() - t0
         _backend.get().timer = None
         _backend.get().conv_mode = precision
-        t = torch.tensor([el32], dtype=torch.float64, device='cuda')
+        t = torch.tensor([el32], dtype=torch.float64, device=dev)
         if use_dist:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el32 = float(t.item())
@@ -220,6 +411,19 @@ def main():
                       'steps': args.steps, 'warmup': args.warmup, 'dtype': 'f32'}
         if timer32 is not None:
             fp32_exact['roofline'] = roofline_of(timer32.summary(), el32)
+
+    # Untimed: the whole picture per kernel family (one cadence cycle of 16 iterations under torch.profiler on rank 0; the other ranks
+    # run the same iterations so the collectives line up).
+    families = step_flops = None
+    if not args.no_families and not args.no_kernel_timer:
+        cycle = 16
+        if rank == 0:
+            families, step_flops, it = family_table(trainer, it, real, _backend.get(), precision, cycle, KernelTimer, world, use_dist)
+        else:
+            for _ in range(cycle):
+                trainer.train_iteration(it, real)
+                it += 1
+        barrier()
 
     if rank == 0:
         images = args.steps * args.batch_per_gpu * world
@@ -231,7 +435,19 @@ def main():
                                    'Adam, EMA), %d images/GPU, fp32 storage, conv arithmetic %s' % (args.size, args.size, args.batch_per_gpu, precision),
                        'global_batch': args.batch_per_gpu * world, 'parallelism': 'dp%d' % world},
             'losses': {k: round(v, 5) for k, v in stats.items()},
+            'phases_fired': phases_fired,
         }
+        if rccl is not None:
+            out['rccl'] = rccl
+        if comm is not None:
+            out['comm'] = comm
+        if families is not None:
+            out['families'] = families
+            peak = PEAK_FP32_MFMA_TFLOPS if precision == 'f32' else PEAK_BF16_MFMA_TFLOPS
+            ach = step_flops / (elapsed / args.steps) / 1e12
+            out['step_roofline'] = {'tflop_per_step': round(step_flops / 1e12, 3), 'achieved': round(ach, 1), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                                    'note': 'algorithmic convolution + weight-gradient flops of one iteration (launch tallies over a 16-iteration cadence cycle, '
+                                            'per GPU) / ms_per_step of the timed region; families: untimed profiler pass, ms are device time per step'}
         if timer is not None:
             summ = timer.summary()
             convs = {k: v for k, v in summ.items() if k.startswith('conv_')}

@@ -52,6 +52,8 @@ def broadcast_module(module, src=0):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+    from ..models.op import weight_cache
+    weight_cache.invalidate(module.parameters())     # written through .data: drop whatever was derived from the old values
 
 
 def all_reduce_mean_(t):
@@ -112,6 +114,9 @@ class GradientReducer:
         self._phase = None
         self._fired = set()
         self.report = {}          # phase -> {'hook': buckets launched from a hook, 'finish': buckets launched in finish()}
+        self.max_gap = (64 << 10) // 4   # elements: gaps up to 64 KiB ride along in one collective
+        self.measure = False      # bench.py: tally payload bytes and the exposed (not overlapped) wait of every finish()
+        self.bytes_reduced, self._stalls = 0, []
 
     def remove(self):
         for h in self._handles:
@@ -164,7 +169,9 @@ class GradientReducer:
             return
         g0 = ready[0].grad
         if b.flat is None or b.flat.device != g0.device or b.flat.dtype != g0.dtype:
-            b.flat = torch.empty(b.numel, dtype=g0.dtype, device=g0.device)
+            # zero-filled ONCE: a gap between two reduced gradients (a parameter this pass gives no gradient) rides along in the
+            # collective and must never hold uninitialised memory (a NaN there would trip any NaN-checking debug mode)
+            b.flat = torch.zeros(b.numel, dtype=g0.dtype, device=g0.device)
         views = [b.view(p) for p in ready]
         src = [p.grad for p in ready]
         moved = [(v, s) for v, s in zip(views, src) if v.data_ptr() != s.data_ptr()]     # accumulation passes already live in the buffer
@@ -172,14 +179,22 @@ class GradientReducer:
             torch._foreach_copy_([v for v, _ in moved], [s for _, s in moved])
         for p, v in zip(ready, views):
             p.grad = v
-        # the slice that spans every ready gradient; gaps (parameters without a gradient in this pass) ride along unused
-        lo = min(b.offsets[p] for p in ready)
-        hi = max(b.offsets[p] + p.numel() for p in ready)
-        b.work = self._reduce(b.flat[lo:hi])
+        # Reduce the spans that hold gradients.  Small gaps (the additive biases R1 / path-length leave without a gradient: a few KiB)
+        # ride along -- one collective is cheaper than two -- larger ones (a whole layer without a gradient) split the span.
+        spans = []
+        for lo, hi in sorted((b.offsets[p], b.offsets[p] + p.numel()) for p in ready):
+            if spans and lo - spans[-1][1] <= self.max_gap:
+                spans[-1][1] = max(spans[-1][1], hi)
+            else:
+                spans.append([lo, hi])
+        b.work = [self._reduce(b.flat[lo:hi]) for lo, hi in spans]
+        self.bytes_reduced += sum(hi - lo for lo, hi in spans) * b.flat.element_size()
 
     def finish(self):
         """Launch what the hooks did not (unknown pass, stragglers), wait for every bucket."""
         if not self.enabled:
+            self._fired = set()
+            self._armed = False
             return
         hook = fin = 0
         for b in self.buckets:
@@ -188,18 +203,36 @@ class GradientReducer:
                 fin += b.work is not None
             else:
                 hook += 1
+        ev = None
+        if self.measure and torch.cuda.is_available():
+            # how long the compute stream stalls for the collectives that backward did not hide: events either side of the waits
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         late = []
         for b in self.buckets:
             if b.work is not None:
-                b.work.wait()
+                for w in b.work:
+                    w.wait()
                 b.work = None
             for p in b.late:
                 if p.grad is not None:
                     late.append(self._reduce(p.grad))
+                    self.bytes_reduced += p.grad.numel() * p.grad.element_size()
         for w in late:
             w.wait()
+        if ev is not None:
+            ev[1].record()
+            self._stalls.append(ev)
         if self._phase is not None:
             self._expected[self._phase] = set(self._fired)
         self.report[self._phase] = {'hook': hook, 'finish': fin, 'late': len(late)}
         self._fired = set()
-        self.enabled = False
+        self.enabled = self._armed = False        # gradient hooks of a backward outside begin() .. finish() are not this reducer's business
+
+    def comm_summary(self, reset=True):
+        """{'bytes': payload handed to the collectives, 'exposed_ms': compute-stream stall in finish()} since the last reset
+        (``measure`` must be on; call after a device synchronise)."""
+        out = {'bytes': self.bytes_reduced, 'exposed_ms': sum(a.elapsed_time(b) for a, b in self._stalls)}
+        if reset:
+            self.bytes_reduced, self._stalls = 0, []
+        return out

@@ -144,8 +144,11 @@ class GeneratorTrainer:
         self.g_ema = Generator(mc['size'], mc['latent_size'], mc['n_mlp'], **kw).to(self.device)
         self.discriminator = Discriminator(mc['size'], channel_multiplier=mc['channel_multiplier'], in_channels=mc['img_channels']).to(self.device)
         self.g_ema.eval()
+        from ..models.op import weight_cache
         for m in (self.generator, self.g_ema, self.discriminator):
             ddp.broadcast_module(m)
+            # derived weight forms are cached for these three: the optimisers' post-step hook invalidates G and D, accumulate() the EMA
+            weight_cache.register(m)
         accumulate(self.g_ema, self.generator, 0)
         g_ratio = tc['g_reg_every'] / (tc['g_reg_every'] + 1)
         d_ratio = tc['d_reg_every'] / (tc['d_reg_every'] + 1)

@@ -1,0 +1,54 @@
+"""bench.py --gpus N launches its own one-process-per-GPU job (no GPU needed for the plumbing: gloo + the emulated C ABI)."""
+import json
+import os
+import subprocess
+import sys
+
+from conftest import REPO
+
+ENTRY = os.path.join(REPO, 'tests', 'bench_emulated_entry.py')
+ARGS = ['--steps', '2', '--warmup', '1', '--size', '16', '--batch-per-gpu', '4', '--no-cpu-baseline']
+
+
+def _env():
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['OMP_NUM_THREADS'] = '2'
+    return env
+
+
+def test_gpus_2_self_launches_two_ranks():
+    """The parent never joins the job: it starts torch.distributed.run as a child, relays ONE JSON line and the exit code."""
+    out = subprocess.run([sys.executable, ENTRY, '--gpus', '2'] + ARGS, env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['rccl']['ranks'] == 2 and line['rccl']['backend'] == 'gloo'
+    assert line['config']['global_batch'] == 8 and line['config']['parallelism'] == 'dp2' and line['scaling'] == 'weak'
+    assert line['steps'] == 2 and line['warmup'] == 1 and line['value'] > 0
+    assert abs(line['value'] - 2 * 8 / (line['ms_per_step'] * 2e-3)) < 1e-6 * line['value']          # whole-job images / max-over-ranks time
+    assert line['phases_fired'] == {'d': 2, 'g': 2, 'r1': 0, 'pl': 0, 'cadence': {'r1_every': 16, 'pl_every': 4}}      # iterations 1, 2
+
+
+def test_child_failure_reaches_the_caller():
+    """A failing rank makes the launcher exit non-zero (no JSON line, no silent success)."""
+    out = subprocess.run([sys.executable, ENTRY, '--gpus', '2', '--size', '24'] + ARGS[:4] + ['--batch-per-gpu', '4', '--no-cpu-baseline'],
+                         env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode != 0
+    assert not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_world_size_mismatch_is_refused():
+    env = _env()
+    env.update(WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    out = subprocess.run([sys.executable, ENTRY, '--gpus', '2'] + ARGS, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and 'WORLD_SIZE=1' in (out.stderr + out.stdout)
+
+
+def test_bench_refuses_to_run_without_a_gpu_or_the_test_switch():
+    import torch
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '1', '--warmup', '0', '--no-cpu-baseline'],
+                         env=_env(), capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and 'no CPU fallback' in (out.stderr + out.stdout)

@@ -74,6 +74,66 @@ def test_gradient_reducer_matches_full_batch():
         assert torch.allclose(got[n], p.grad, atol=1e-6), n
 
 
+def _changing_set_worker(rank, world, port, out):
+    """A phase whose gradient set changes between iterations, a backward OUTSIDE begin() .. finish(), and a gap large enough to split a
+    bucket's span: every reduced gradient must still equal the full-batch one and nothing stale may be reduced."""
+    _setup(rank, world, port)
+    from gan_control_amd.trainers.ddp import GradientReducer
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(6, 40), torch.nn.Linear(6, 40), torch.nn.Linear(6, 40)
+    net = torch.nn.ModuleList([a, b, c])
+    red = GradientReducer(net, bucket_bytes=1 << 20)          # one bucket: a | b | c in one flat buffer
+    red.max_gap = 8                                           # elements: b's weight (240) is a "large" gap here
+    assert len(red.buckets) == 1
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(5))[rank::world]
+    results = {}
+    uses = [(a, b, c), (a, c), (a, c), (a, b, c), (c,)]      # the set shrinks, stays, grows, shrinks again
+    for it, used in enumerate(uses):
+        net.zero_grad(set_to_none=True)
+        if it == 2:
+            # a stray backward between two bracketed passes (an evaluation-time gradient, say): its hooks must not count
+            b(x).sum().backward()
+            assert b.weight.grad is not None
+            net.zero_grad(set_to_none=True)
+            assert not red._fired, 'hooks fired outside begin() .. finish() were recorded'
+        red.begin(sync=True, phase='p')
+        sum(m(x).square().mean() for m in used).backward()
+        red.finish()
+        assert red._expected['p'] == {p for m in used for p in m.parameters()}, it
+        assert not red._armed and not red._fired
+        if it == 1:
+            # a and c reduced, b (in the middle of the buffer) not: two spans, and b's slot still holds what iteration 0 left there
+            assert red.report['p']['late'] == 0
+        results[it] = {n: (None if p.grad is None else p.grad.clone()) for n, p in net.named_parameters()}
+    flat = red.buckets[0].flat
+    assert torch.isfinite(flat).all()
+    if rank == 0:
+        torch.save(results, out)
+    dist.destroy_process_group()
+
+
+def test_reducer_with_a_changing_gradient_set():
+    port = 27500 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'c.pt')
+        mp.spawn(_changing_set_worker, args=(2, port, out), nprocs=2, join=True)
+        got = torch.load(out)
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(6, 40), torch.nn.Linear(6, 40), torch.nn.Linear(6, 40)
+    net = torch.nn.ModuleList([a, b, c])
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(5))
+    uses = [(a, b, c), (a, c), (a, c), (a, b, c), (c,)]
+    for it, used in enumerate(uses):
+        net.zero_grad(set_to_none=True)
+        # mean over ranks of per-rank means == full-batch mean (equal shard sizes)
+        sum(m(x).square().mean() for m in used).backward()
+        for n, p in net.named_parameters():
+            if p.grad is None:
+                assert got[it][n] is None, (it, n)
+            else:
+                assert torch.allclose(got[it][n], p.grad, atol=1e-6), (it, n)
+
+
 def _inputs():
     import op_checks as oc
     gen = torch.Generator().manual_seed(77)

@@ -91,17 +91,39 @@ def _fused_step_conv_check(device):
     finally:
         weight_cache.ENABLED = prev
     assert torch.equal(y_cached, y_fresh), 'stale derived weights after a fused optimiser step (version counter %d -> %d)' % (version, conv.weight._version)
-    # the EMA writes through .data (trainers/utils.py::accumulate, like the reference's): same requirement
-    ema = torch.nn.Conv2d(5, 6, 3, bias=False).to(device)
-    before = fwd(ema.weight).detach()
-    accumulate(ema, conv, 0.5)
-    after = fwd(ema.weight).detach()
+    assert weight_cache.stats['hit'] + weight_cache.stats['miss'] > 0, 'a parameter an optimiser has stepped must be cached'
+    # the EMA writes through .data (trainers/utils.py::accumulate, like the reference's): same requirement.  Registered (this
+    # package's trainer does that; its accumulate() invalidates) and NOT registered (somebody else's training loop, the
+    # reference's own accumulate(): `par.data.mul_().add_()`, trainers/utils.py:8-12 -- such a tensor must never be cached).
+    for registered in (True, False):
+        ema = torch.nn.Conv2d(5, 6, 3, bias=False).to(device)
+        if registered:
+            weight_cache.register(ema)
+        before = fwd(ema.weight).detach()
+        bypass0 = weight_cache.stats['bypass']
+        if registered:
+            accumulate(ema, conv, 0.5)
+        else:
+            for p_ema, p in zip(ema.parameters(), conv.parameters()):
+                p_ema.data.mul_(0.5).add_(p.data, alpha=0.5)
+        after = fwd(ema.weight).detach()
+        assert registered or weight_cache.stats['bypass'] > bypass0, 'an unmanaged tensor was cached'
+        weight_cache.ENABLED, prev = False, weight_cache.ENABLED
+        try:
+            fresh = fwd(ema.weight).detach()
+        finally:
+            weight_cache.ENABLED = prev
+        assert torch.equal(after, fresh) and not torch.equal(after, before)
+    # a parameter whose storage was swapped (module.to(), load_state_dict(assign=True)) is dropped on sight
+    weight_cache.register(conv)
+    y0 = fwd(conv.weight).detach()
+    conv.weight.data = (conv.weight.data * 3.0).clone()
     weight_cache.ENABLED, prev = False, weight_cache.ENABLED
     try:
-        fresh = fwd(ema.weight).detach()
+        fresh = fwd(conv.weight).detach()
     finally:
         weight_cache.ENABLED = prev
-    assert torch.equal(after, fresh) and not torch.equal(after, before)
+    assert torch.equal(fwd(conv.weight).detach(), fresh) and not torch.equal(fresh, y0)
     weight_cache.clear()
 
 
@@ -142,6 +164,7 @@ def test_weight_cache_reuse_and_invalidation(emu_backend):
     weight_cache.clear()
     gen = torch.Generator().manual_seed(0)
     w = torch.nn.Parameter(torch.randn(6, 5, 3, 3, generator=gen))
+    weight_cache.register(w)
     x = torch.randn(2, 5, 8, 8, generator=gen, requires_grad=True)
 
     def run():
