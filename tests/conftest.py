@@ -254,5 +254,25 @@ def emu_backend():
     _backend._install_for_tests(prev)
 
 
+@pytest.fixture
+def bf16x3_mode():
+    """The split-bf16 convolution arithmetic (bench.py's default) for the duration of a -m gpu test."""
+    from gan_control_amd.models.op import _backend
+    hip = _backend.get()
+    prev, hip.conv_mode = hip.conv_mode, 'bf16x3'
+    yield
+    hip.conv_mode = prev
+
+
+@pytest.fixture
+def bf16_mode():
+    """Plain bf16 products (bench.py --precision bf16, BASELINE config[1]'s literal arithmetic)."""
+    from gan_control_amd.models.op import _backend
+    hip = _backend.get()
+    prev, hip.conv_mode = hip.conv_mode, 'bf16'
+    yield
+    hip.conv_mode = prev
+
+
 def have_gpu():
     return torch.cuda.is_available()

@@ -174,6 +174,23 @@ def build_models(size, device, fc_groups=None):
     return g.to(device), d.to(device)
 
 
+def network_errors(size, device):
+    """The quantities check_network asserts, returned instead (used to derive the tolerance of the plain-bf16 mode from measurement)."""
+    import torch.nn.functional as F
+    r = group(NET, f's{size}')
+    g, d = build_models(size, device)
+    batch = int(r['batch'])
+    noise = seeded_noise(size, batch, int(r['noise_seed']), device)
+    with torch.no_grad():
+        img, lat = g([r['z'].to(device)], noise=noise, return_latents=True)
+        logits, _ = d(img)
+    amax = float(r['img_absmax'])
+    px = img.reshape(-1)[r['px_idx'].to(device)]
+    return {'thumb': rel_err(F.adaptive_avg_pool2d(img, min(16, size)), r['thumb']), 'pixels': (px.cpu() - r['px_val']).abs().max().item() / amax,
+            'mean': abs(float(img.mean()) - float(r['img_mean'])) / amax, 'std': abs(float(img.std()) - float(r['img_std'])) / amax,
+            'logits': rel_err(logits, r['logits']), 'w0': rel_err(lat[:, 0, :16], r['w0'])}
+
+
 def check_network(size, device, tol=TOL):
     r = group(NET, f's{size}')
     g, d = build_models(size, device)

@@ -31,7 +31,15 @@ def step_inputs(s, size, batch):
     return {'real': real, 'z_d': z_d, 'z_g': z_g, 'z_pl': z_pl, 'pl_noise': pl_noise}
 
 
-def _check_grads(module, s, prefix, ref_total, tol, param_tol=None):
+class _Measure(dict):
+    """check_step(measure=_Measure()): record every error next to its name instead of asserting (how the tolerances of a new arithmetic
+    mode are derived: run once in measure mode, assert 2 x the measured values from then on)."""
+
+    def note(self, key, err):
+        self[key] = max(self.get(key, 0.0), float(err))
+
+
+def _check_grads(module, s, prefix, ref_total, tol, param_tol=None, measure=None):
     """Gradients of one backward pass against the reference's: the set of parameters that have one, the global norm and the
     norm of every single parameter's gradient (``<prefix>/names``, ``<prefix>/vals``)."""
     got = {n: p.grad for n, p in module.named_parameters() if p.grad is not None}
@@ -41,7 +49,10 @@ def _check_grads(module, s, prefix, ref_total, tol, param_tol=None):
     if ref_total is None:
         ref_total = float(torch.tensor(refs, dtype=torch.float64).norm())
     total = float(torch.stack([g.double().pow(2).sum() for g in got.values()]).sum().sqrt())
-    assert abs(total - ref_total) <= tol * ref_total, (prefix, total, ref_total)
+    if measure is not None:
+        measure.note(prefix + ':global', abs(total - ref_total) / ref_total)
+    else:
+        assert abs(total - ref_total) <= tol * ref_total, (prefix, total, ref_total)
     # A parameter whose gradient is below 0.1 % of the pass's norm is bounded absolutely: such gradients (e.g. what reaches D's
     # activation biases under R1 only through the minibatch-stddev channel, ~1e-4 of the total) sit below the rounding noise of the pass.
     floor = 1e-3 * ref_total
@@ -57,16 +68,18 @@ def _check_grads(module, s, prefix, ref_total, tol, param_tol=None):
             continue
         err = abs(val - ref) / max(ref, floor)
         worst = max(worst, err)
-        assert err <= param_tol, (prefix, n, val, ref)
+        assert measure is not None or err <= param_tol, (prefix, n, val, ref)
     if scalars:
         a, b = torch.tensor(scalars, dtype=torch.float64).unbind(1)
         err = float((a - b).norm() / b.norm().clamp_min(floor))
         worst = max(worst, err)
-        assert err <= param_tol, (prefix, 'scalar parameters', scalars)
+        assert measure is not None or err <= param_tol, (prefix, 'scalar parameters', scalars)
+    if measure is not None:
+        measure.note(prefix + ':param', worst)
     return worst
 
 
-def check_step(device, tol=2e-3, name='step', param_tol=None):
+def check_step(device, tol=2e-3, name='step', param_tol=None, measure=None):
     """One full iteration (D step, R1, G step, path-length, EMA) of the product trainer against the iteration captured from
     the reference.  ``name`` selects the fixture: 'step' (32x32, batch 4), 'step_512' (512x512, batch 4), 'step_1024'
     (1024x1024, batch 2).
@@ -84,6 +97,15 @@ def check_step(device, tol=2e-3, name='step', param_tol=None):
     the global norms: a single parameter's gradient is a sum over batch x pixels that cancels to ~1/700 of its terms on the worst
     parameter, which amplifies the arithmetic's rounding error (fp32: 3e-7 -> 2e-4 measured; split-bf16: 5e-6 -> 4e-3 measured)."""
     pt = param_tol if param_tol is not None else tol
+    m = measure
+
+    def within(key, err, bound, detail):
+        if m is not None:
+            m.note(key, err / 1.0)
+            m.setdefault('_bounds', {})[key] = bound
+        else:
+            assert err <= bound, (key, err, bound, detail)
+
     from gan_control_amd.trainers.utils import requires_grad, accumulate
     s = load_golden(name)
     size, batch = [int(v) for v in s['cfg']]
@@ -101,7 +123,7 @@ def check_step(device, tol=2e-3, name='step', param_tol=None):
     worst = {}
     requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
     tr.discriminator_step([[t('z_d')]], [real], noise=noise(batch, 0))
-    worst['d'] = _check_grads(tr.discriminator, s, 'gradnorm/d', float(s['stat/d_grad_norm']), tol, pt)
+    worst['d'] = _check_grads(tr.discriminator, s, 'gradnorm/d', float(s['stat/d_grad_norm']), tol, pt, m)
     tr.discriminator_regularize_step([real])
     requires_grad(tr.generator, True); requires_grad(tr.discriminator, False)
     tr.generator_step([[t('z_g')]], noise=noise(batch, 1))
@@ -119,21 +141,21 @@ def check_step(device, tol=2e-3, name='step', param_tol=None):
     reset()
     requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
     tr.discriminator_regularize_step([real])
-    worst['r1'] = _check_grads(tr.discriminator, s, 'iso/r1', None, 3 * tol, 3 * pt)
+    worst['r1'] = _check_grads(tr.discriminator, s, 'iso/r1', None, 3 * tol, 3 * pt, m)
     ref = float(s['iso/stat/d_r1_loss'])
-    assert abs(float(tr.stats['d_r1_loss']) - ref) <= tol * max(1e-3, abs(ref)), ('iso d_r1_loss', float(tr.stats['d_r1_loss']), ref)
+    within('iso d_r1_loss', abs(float(tr.stats['d_r1_loss']) - ref) / max(1e-3, abs(ref)), tol, ref)
     reset()
     requires_grad(tr.generator, True); requires_grad(tr.discriminator, False)
     tr.generator_step([[t('z_g')]], noise=noise(batch, 1))
-    worst['g'] = _check_grads(tr.generator, s, 'iso/g', None, tol, pt)
+    worst['g'] = _check_grads(tr.generator, s, 'iso/g', None, tol, pt, m)
     ref = float(s['iso/stat/g_adv_loss'])
-    assert abs(float(tr.stats['g_adv_loss']) - ref) <= tol * max(1.0, abs(ref)), ('iso g_adv_loss', float(tr.stats['g_adv_loss']), ref)
+    within('iso g_adv_loss', abs(float(tr.stats['g_adv_loss']) - ref) / max(1.0, abs(ref)), tol, ref)
     reset()
     tr.generator_regularize_step(noise=noise(batch // 2, 2), pl_noise=t('pl_noise'), z=[t('z_pl')])
-    worst['pl'] = _check_grads(tr.generator, s, 'iso/pl', None, 3 * tol, 3 * pt)
+    worst['pl'] = _check_grads(tr.generator, s, 'iso/pl', None, 3 * tol, 3 * pt, m)
     ref = float(s['iso/stat/g_path_loss'])
-    assert abs(float(tr.stats['g_path_loss']) - ref) <= tol * max(1.0, abs(ref)), ('iso g_path_loss', float(tr.stats['g_path_loss']), ref)
-    assert rel_err(tr.stats['path_lengths'], torch.from_numpy(s['iso/stat/path_lengths'])) <= tol
+    within('iso g_path_loss', abs(float(tr.stats['g_path_loss']) - ref) / max(1.0, abs(ref)), tol, ref)
+    within('iso path_lengths', rel_err(tr.stats['path_lengths'], torch.from_numpy(s['iso/stat/path_lengths'])), tol, None)
     print(name, 'worst per-parameter gradient-norm error per pass:', {k: '%.2e' % v for k, v in worst.items()})
     tr.stats = seq
     # the path-length pass of the SEQUENTIAL iteration runs on a generator that has just taken a sign-like Adam step (every one of its
@@ -141,18 +163,32 @@ def check_step(device, tol=2e-3, name='step', param_tol=None):
     # free of that noise, is held to tol
     for k, f in (('d_loss', 1), ('d_r1_loss', 1), ('g_adv_loss', 1), ('g_path_loss', 3), ('g_mean_path_length', 3)):
         ref = float(s[f'stat/{k}'])
-        assert abs(float(tr.stats[k]) - ref) <= f * tol * max(1.0, abs(ref)), (k, float(tr.stats[k]), ref)
-    assert rel_err(tr.stats['path_lengths'], t('stat/path_lengths')) <= 3 * tol
-    # parameters after the four Adam updates (first Adam steps move every weight by ~lr, so an absolute bound)
-    bad = 0
-    total = 0
+        within('seq ' + k, abs(float(tr.stats[k]) - ref) / max(1.0, abs(ref)), f * tol, ref)
+    within('seq path_lengths', rel_err(tr.stats['path_lengths'], t('stat/path_lengths')), 3 * tol, None)
+    # Parameters after the four Adam updates (first Adam steps move every weight by ~lr, so an absolute bound).  Adam's first steps are
+    # sign-like: a sampled element can only land elsewhere (by 2 * lr) if one of the gradients that stepped it is within the arithmetic's
+    # error of zero.  The fixture holds, per sampled element, min over its passes of |gradient element| / RMS(gradient tensor)
+    # (`param/<net>/grad_ratio`, oracle/make_golden.py::golden_step): the budget of outliers is the NUMBER OF SAMPLES whose ratio is below
+    # the per-parameter gradient tolerance of this mode (3 * param_tol: the double-backward passes' bound) -- not a flat percentage.
+    bad, total, budget, offenders = 0, 0, 0, []
     for tag in ('g', 'd', 'g_ema'):
         params = after[tag]
-        for name, val in zip(s[f'param/{tag}/names'], s[f'param/{tag}/vals']):
+        ratios = s[f'param/{tag}/grad_ratio']
+        for name, val, ratio in zip(s[f'param/{tag}/names'], s[f'param/{tag}/vals'], ratios):
             key, idx = str(name).rsplit('#', 1)
             total += 1
+            near_zero = float(ratio) < 3 * pt
+            budget += near_zero
             if abs(float(params[key].detach().reshape(-1)[int(idx)]) - float(val)) > 1e-3:
                 bad += 1
-    # sign flips of ~zero gradients under Adam's sign-like first steps may move a few samples by 2*lr
-    assert bad <= total * 0.01, f'{bad} of {total} sampled parameters differ'
+                if not near_zero:
+                    offenders.append((tag, str(name), float(ratio)))
+    if m is not None:
+        m['param outliers'] = bad
+        m['param outliers with a gradient above the noise'] = len(offenders)
+        m['param budget (samples whose gradient is within 3 * param_tol of zero)'] = budget
+        m['param samples'] = total
+    else:
+        assert not offenders, f'sampled parameters differ although their gradients are well above the arithmetic\'s error: {offenders[:5]}'
+        assert bad <= budget, f'{bad} of {total} sampled parameters differ; only {budget} have a gradient near zero'
     return tr

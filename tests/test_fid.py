@@ -95,3 +95,61 @@ def test_sample_features_through_the_hip_generator():
     mb, cb = pfid.feature_statistics(b.numpy())
     # noise injection is random per call: statistics are close, not identical; the distance is small next to the feature scale
     assert pfid.calc_fid(ma, ca, mb, cb) < 0.5 * (np.trace(ca) + 1e-6)
+
+
+@pytest.mark.gpu
+def test_fid_of_the_composed_hip_pipeline_against_the_oracle():
+    """BASELINE's second metric end to end, on procedural weights (the FID checkpoint and the real-image statistics are external
+    downloads): HIP generator -> HIP InceptionV3 (299 x 299 resize, pool3) -> feature statistics -> calc_fid between two seeded sample
+    sets of 200 images each, against the same number reached through oracle/networks.py -> oracle/inception.py -> oracle/fid.py on the
+    same latents and noise maps on the host.  The test prints the measured errors; asserted: 1e-3 on the features (the bound of
+    tests/test_inception.py for the HIP feature network) and 1e-3 on the distance."""
+    import math
+    from gan_control_amd.models.gan_model import Generator
+    from gan_control_amd.fid_utils.inception import InceptionV3
+    from oracle import networks, inception as oinc
+    size, n_per_set, batch = 64, 200, 40
+    g = Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True)
+    g_sd = networks.procedural_fill_(g.state_dict())
+    g.load_state_dict(g_sd)
+    g = g.cuda().eval()
+    net = InceptionV3(output_blocks=[3], normalize_input=False)              # the reference's evaluation call (tracker.py:322-329)
+    i_sd = oinc.procedural_inception_fill_(net.state_dict())
+    net.load_state_dict(i_sd)
+    net = net.cuda().eval()
+    gen = torch.Generator().manual_seed(50)
+    num_layers = (int(math.log2(size)) - 2) * 2 + 1
+    plan = pfid._batch_plan(n_per_set, batch)
+    sets = []
+    for s in range(2):
+        zs = [torch.randn(b, 512, generator=gen) * (1.0 if s == 0 else 0.7) for b in plan]       # the second set is a narrower distribution
+        noises = [[torch.randn(b, 1, 2 ** ((i + 5) // 2), 2 ** ((i + 5) // 2), generator=gen) for i in range(num_layers)] for b in plan]
+        sets.append((zs, noises))
+    fids = {}
+    feats = {}
+    for side in ('hip', 'oracle'):
+        stats = []
+        for s, (zs, noises) in enumerate(sets):
+            it = iter(range(len(plan)))
+
+            def gen_fn(z_unused, zs=zs, noises=noises, it=it):
+                k = next(it)
+                if side == 'hip':
+                    return g([zs[k].cuda()], noise=[n.cuda() for n in noises[k]])[0]
+                with torch.no_grad():
+                    return networks.generator_forward(g_sd, [zs[k]], size, noise=noises[k])[0]
+
+            if side == 'hip':
+                f = pfid.sample_features(g, net, batch, n_per_set, device='cuda', generator_fn=gen_fn)
+            else:
+                fnet = lambda img: oinc.inception_features(i_sd, img, (3,), True, False)
+                f = pfid.sample_features(None, fnet, batch, n_per_set, device='cpu', generator_fn=gen_fn)
+            assert f.shape == (n_per_set, 2048)
+            feats[side, s] = f
+            stats.append(pfid.feature_statistics(f.numpy()))
+        (m1, c1), (m2, c2) = stats
+        fids[side] = pfid.calc_fid(m1, c1, m2, c2) if side == 'hip' else ofid.frechet_distance(m1, c1, m2, c2)
+    e_feat = max(float((feats['hip', s] - feats['oracle', s]).abs().max() / feats['oracle', s].abs().max()) for s in range(2))
+    e_fid = abs(fids['hip'] - fids['oracle']) / abs(fids['oracle'])
+    print('composed FID: hip %.6f oracle %.6f (rel %.2e); features rel %.2e' % (fids['hip'], fids['oracle'], e_fid, e_feat))
+    assert fids['oracle'] > 0 and e_feat < 1e-3 and e_fid < 1e-3, (fids, e_feat, e_fid)

@@ -433,14 +433,6 @@ def test_step_golden():
     step_checks.check_step(DEV)
 
 
-@pytest.fixture
-def bf16x3_mode():
-    hip, _ = _be()
-    prev, hip.conv_mode = hip.conv_mode, 'bf16x3'
-    yield
-    hip.conv_mode = prev
-
-
 BF16_CASES = CONV_CASES + [
     (2, 64, 64, 40, 70, 3, 1, 1, 1), (1, 130, 140, 33, 65, 3, 1, 1, 1), (1, 32, 32, 70, 40, 3, 1, 1, 1), (2, 48, 24, 36, 36, 1, 1, 1, 0),
     (1, 64, 130, 65, 129, 3, 1, 2, 0), (2, 40, 20, 71, 67, 3, 1, 2, 0), (2, 16, 24, 63, 63, 1, 1, 2, 0),
