@@ -29,6 +29,11 @@ class ConvEpilogue(ctypes.Structure):
     _fields_ = [('bias', _vp), ('noise', _vp), ('noise_w', _vp), ('slope', _f32), ('gain', _f32), ('activate', _i32), ('residual', _vp)]
 
 
+class GlinGroup(ctypes.Structure):
+    """Mirror of ``gc_glin_group``."""
+    _fields_ = [('x', _vp), ('w', _vp), ('bias', _vp), ('y', _vp), ('n', _i32), ('k', _i32), ('x_stride', _i64), ('alpha', _f32), ('beta', _f32)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every exported symbol
 SIGNATURES = {
     'gc_abi_version': (_i32, []),
@@ -76,6 +81,9 @@ SIGNATURES = {
     'gc_conv2d_wgrad_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_affine_warp_bilinear_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 7 + [_vp]),
     'gc_reflect_pad_f32': (_i32, [_vp, _vp] + [_i32] * 8 + [_vp]),
+    'gc_grouped_linear_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
+    'gc_grouped_linear_bwd_x_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
+    'gc_grouped_linear_bwd_w_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
     'gc_weight_layout_f32': (_i32, [_vp, _vp, _i32, _i32, _i32, ctypes.POINTER(_i64 * 3), ctypes.POINTER(_i64 * 3), _i32, _f32, _vp]),
 }
 

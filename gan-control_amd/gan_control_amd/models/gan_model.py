@@ -22,8 +22,44 @@ _FORK_TORGB = os.environ.get('GANCONTROL_FORK_TORGB', '0') == '1'         # off 
 from .op import _backend
 from .op import (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, upfirdn2d_bias_act, conv2d_gradfix, modulated_conv2d,
                  modulated_conv2d_act)
-from .op.modulated_conv import demod_coefficients
+from .op.modulated_conv import demod_coefficients, _WeightSq, _eps_vector
 from .op.linear import scaled_mm, equal_linear
+from .op import style as style_op
+# The style path (26 modulations, 18 demodulation sums per forward pass) as grouped launches over layer-major flat tensors (op/style.py).
+# GANCONTROL_FUSED_STYLE=0: one GEMM call per layer, as in round 2.
+_FUSED_STYLE = os.environ.get('GANCONTROL_FUSED_STYLE', '1') != '0'
+import weakref
+_STYLE_PLANS = weakref.WeakKeyDictionary()      # Generator -> _StylePlan (kept out of the module: holds ctypes tables, not state)
+
+
+class _StylePlan:
+    """Which modulated convolution reads which latent, in which group of the grouped launches.  Groups are ordered demodulated layers
+    first (so that the demodulation step reads a contiguous prefix of the modulation output), ToRGB layers last."""
+
+    def __init__(self, layers, style_dim):
+        order = [j for j, (m, _) in enumerate(layers) if m.demodulate] + [j for j, (m, _) in enumerate(layers) if not m.demodulate]
+        self.layers = [layers[j][0] for j in order]                    # group order
+        self.latent_index = [layers[j][1] for j in order]
+        self.group_of_exec = {j: g for g, j in enumerate(order)}
+        self.n_demod = sum(1 for m in self.layers if m.demodulate)
+        self.s_cols = [m.in_channel for m in self.layers]
+        self.d_cols = [m.out_channel for m in self.layers[:self.n_demod]]
+        self.mod_plan = style_op.Plan([style_op.GroupSpec(m.in_channel, style_dim, m.modulation.scale, m.modulation.lr_mul, g * style_dim)
+                                       for g, m in enumerate(self.layers)])
+        specs, at = [], 0
+        for m in self.layers[:self.n_demod]:
+            specs.append(style_op.GroupSpec(m.out_channel, m.in_channel, m.scale * m.scale, 1.0, at))
+            at += m.in_channel
+        self.demod_in_cols = at
+        self.demod_plan = style_op.Plan(specs, in_cols=at)
+        self.ok = style_op._supported(self.mod_plan) and style_op._supported(self.demod_plan)
+        self._idx = {}
+
+    def idx(self, device):
+        t = self._idx.get(device)
+        if t is None:
+            t = self._idx[device] = torch.tensor(self.latent_index, dtype=torch.long, device=device)
+        return t
 # The style path (26 modulation GEMMs, 18 demodulation GEMMs and the elementwise algebra around them: ~150 launches of a few
 # microseconds on [B, 512] tensors per generator pass, three times that in its backward and second-order passes) on a SIDE STREAM:
 # it depends on the latents and the weights only, so it runs next to the convolutions instead of between them.  Autograd runs
@@ -403,7 +439,9 @@ class Generator(nn.Module):
         out = self.input(latent)
         # one unbind instead of 26 slices: its backward is a single stack, a slice's backward is a zero-fill + add of the whole latent
         lat = latent.unbind(1)
-        mods = self._style_path(lat)
+        mods = self._style_path_grouped(latent) if _FUSED_STYLE else None
+        if mods is None:
+            mods = self._style_path(lat)
         out = self.conv1(out, lat[0], noise=noise[0], mod=mods(0))
         # every StyledConv output feeds ToRGB and the next up-sampling layer: ToRGB forks it (see ToRGB.forward)
         rgb = (lambda m, x, w, sk, md: m(x, w, sk, fork=True, mod=md)) if _FORK_TORGB else (lambda m, x, w, sk, md: (m(x, w, sk, mod=md), x))
@@ -432,14 +470,45 @@ class Generator(nn.Module):
             o += batch * n
         return out
 
-    def _style_path(self, lat):
-        """(s, d) of every modulated convolution in execution order -- conv1, to_rgb1, then (up-sampling conv, conv, to_rgb) per
-        resolution -- computed ahead of the image path on the side stream.  Returns ``mods(j)``: the pair of layer j, after making the
-        current stream wait for it."""
+    def _style_layers(self):
+        """[(ModulatedConv2d, index of the latent it reads)] in execution order: conv1, to_rgb1, then (up-sampling conv, conv, to_rgb) per resolution."""
         layers, idx = [(self.conv1.conv, 0), (self.to_rgb1.conv, 1)], 1
         for up_conv, conv, to_rgb in zip(self.convs[::2], self.convs[1::2], self.to_rgbs):
             layers += [(up_conv.conv, idx), (conv.conv, idx + 1), (to_rgb.conv, idx + 2)]
             idx += 2
+        return layers
+
+    def _style_path_grouped(self, latent):
+        """(s, d) of every modulated convolution from FIVE launches: gather the latents per layer (index_select), all modulations
+        (grouped_linear), square, all demodulation sums (grouped_linear), rsqrt.  Returns ``mods(j)`` as _style_path does, or None when
+        the shapes are not the grouped kernels' (style_dim or a channel count not a multiple of 4)."""
+        plan = _STYLE_PLANS.get(self)
+        if plan is None:
+            plan = _STYLE_PLANS[self] = _StylePlan(self._style_layers(), self.style_dim)
+        if not plan.ok or latent.dim() != 3 or latent.dtype != torch.float32:
+            return None
+        b = latent.shape[0]
+        x = latent.transpose(0, 1).index_select(0, plan.idx(latent.device))                    # [groups, B, style_dim]
+        s_flat = style_op.grouped_linear(x.reshape(-1), b, plan.mod_plan, [m.modulation.weight for m in plan.layers],
+                                         [m.modulation.bias for m in plan.layers])
+        s_blocks = style_op.blocks(s_flat, b, plan.s_cols)
+        d_blocks = []
+        if plan.n_demod:
+            u = s_flat[:b * plan.demod_in_cols].square()
+            wsq = [_WeightSq.apply(m.weight.view(m.weight.shape[1:])) for m in plan.layers[:plan.n_demod]]
+            q = style_op.grouped_linear(u, b, plan.demod_plan, wsq, [_eps_vector(latent, m.out_channel, m.eps) for m in plan.layers[:plan.n_demod]])
+            d_blocks = style_op.blocks(q.rsqrt(), b, plan.d_cols)
+
+        def mods(j):
+            g = plan.group_of_exec[j]
+            return s_blocks[g], (d_blocks[g] if g < plan.n_demod else None)
+        return mods
+
+    def _style_path(self, lat):
+        """(s, d) of every modulated convolution in execution order -- conv1, to_rgb1, then (up-sampling conv, conv, to_rgb) per
+        resolution -- computed ahead of the image path on the side stream.  Returns ``mods(j)``: the pair of layer j, after making the
+        current stream wait for it."""
+        layers = self._style_layers()
         dev = lat[0].device
         if not (_STYLE_STREAM and dev.type == 'cuda'):
             pairs = [m.styles(lat[i]) for m, i in layers]

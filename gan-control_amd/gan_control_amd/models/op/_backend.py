@@ -319,6 +319,79 @@ class HipBackend:
         _lib.check(rc, 'gc_small_gemm_f32')
         return out
 
+    # -- the style path: every dense layer of one kind in ONE launch (op/style.py) ----------------------------------------
+    @staticmethod
+    def _glin_table(plan, batch, tag):
+        """The gc_glin_group table of a plan for one batch size: extents / scales / offsets are fixed, only pointers change per call."""
+        key = (tag, batch)
+        hit = plan.cache.get(key)
+        if hit is None:
+            n = len(plan.specs)
+            table = (_lib.GlinGroup * n)()
+            xoff, yoff = [], []
+            at = 0
+            for i, sp in enumerate(plan.specs):
+                g = table[i]
+                g.n, g.k, g.x_stride, g.alpha, g.beta = sp.n, sp.k, sp.k, sp.alpha, sp.beta
+                xoff.append(4 * batch * sp.xcol)
+                yoff.append(4 * batch * at)
+                at += sp.n
+            hit = plan.cache[key] = (table, xoff, yoff)
+        return hit
+
+    def grouped_linear(self, x, batch, plan, weights, biases):
+        """y (flat, blocks [batch, n_g] in group order) = alpha_g * x_g @ w_g^T + beta_g * bias_g; see gc_grouped_linear_f32."""
+        dev = _lib.require_cuda_f32(x, *weights, *[b for b in biases if b is not None])
+        y = torch.empty(batch * plan.out_cols, dtype=x.dtype, device=dev)
+        table, xoff, yoff = self._glin_table(plan, batch, 'fwd')
+        xp, yp = x.data_ptr(), y.data_ptr()
+        for i in range(len(plan.specs)):
+            g = table[i]
+            g.x, g.y, g.w, g.bias = xp + xoff[i], yp + yoff[i], weights[i].data_ptr(), (biases[i].data_ptr() if biases[i] is not None else None)
+        with (self._guard(dev) or contextlib.nullcontext()):
+            rc = _lib.load().gc_grouped_linear_f32(table, len(plan.specs), batch, _lib.stream_of(x))
+        _lib.check(rc, 'gc_grouped_linear_f32')
+        return y
+
+    def grouped_linear_bwd_x(self, gy, batch, plan, weights):
+        """gx (flat, the plan's input layout) = alpha_g * gy_g @ w_g; input blocks no group reads are zero."""
+        dev = _lib.require_cuda_f32(gy, *weights)
+        gx = (torch.empty if plan.covers_input else torch.zeros)(batch * plan.in_cols, dtype=gy.dtype, device=dev)
+        table, xoff, yoff = self._glin_table(plan, batch, 'bwd_x')
+        xp, yp = gx.data_ptr(), gy.data_ptr()
+        for i in range(len(plan.specs)):
+            g = table[i]
+            g.x, g.y, g.w, g.bias = xp + xoff[i], yp + yoff[i], weights[i].data_ptr(), None
+        with (self._guard(dev) or contextlib.nullcontext()):
+            rc = _lib.load().gc_grouped_linear_bwd_x_f32(table, len(plan.specs), batch, _lib.stream_of(gy))
+        _lib.check(rc, 'gc_grouped_linear_bwd_x_f32')
+        return gx
+
+    def grouped_linear_bwd_w(self, gy, x, batch, plan, has_bias):
+        """([gw_g [n_g, k_g]], [gbias_g [n_g] | None]): views of two flat buffers written by one launch."""
+        dev = _lib.require_cuda_f32(gy, x)
+        specs = plan.specs
+        gw_flat = torch.empty(sum(sp.n * sp.k for sp in specs), dtype=gy.dtype, device=dev)
+        gb_flat = torch.empty(sum(sp.n for sp, hb in zip(specs, has_bias) if hb), dtype=gy.dtype, device=dev) if any(has_bias) else None
+        table, xoff, yoff = self._glin_table(plan, batch, 'bwd_w')
+        xp, yp = x.data_ptr(), gy.data_ptr()
+        gws, gbs, wo, bo = [], [], 0, 0
+        for i, sp in enumerate(specs):
+            g = table[i]
+            gw = gw_flat[wo:wo + sp.n * sp.k].view(sp.n, sp.k)
+            wo += sp.n * sp.k
+            gb = None
+            if has_bias[i]:
+                gb = gb_flat[bo:bo + sp.n]
+                bo += sp.n
+            g.x, g.y, g.w, g.bias = xp + xoff[i], yp + yoff[i], gw.data_ptr(), (gb.data_ptr() if gb is not None else None)
+            gws.append(gw)
+            gbs.append(gb)
+        with (self._guard(dev) or contextlib.nullcontext()):
+            rc = _lib.load().gc_grouped_linear_bwd_w_f32(table, len(specs), batch, _lib.stream_of(gy))
+        _lib.check(rc, 'gc_grouped_linear_bwd_w_f32')
+        return gws, gbs
+
     def rows_sum_div(self, partial, den=None):
         """[..., J] -> [...]: sum over the last dim, divided by ``den`` (same leading shape; a zero divisor counts as one)."""
         dev = _lib.require_cuda_f32(partial, den)

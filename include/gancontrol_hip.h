@@ -364,6 +364,34 @@ int gc_reflect_pad_f32(const float* x, float* y, int planes, int in_h, int in_w,
                        int adjoint, gc_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Grouped dense layers of the style path: every EqualLinear of one kind in ONE launch.
+ *
+ * Replaces, per generator pass, the 26 `self.modulation(style)` calls of ModulatedConv2d.forward (gan_model.py:281-283; EqualLinear
+ * :171-202: F.linear(input, weight * scale, bias * lr_mul)) and the 18 demodulation sums `rsqrt((weight ** 2).sum([2, 3, 4]) + 1e-8)`
+ * (:284-293; here `scale^2 * (s^2) @ (sum_taps W^2)^T + eps`), and their ATen backward / double-backward GEMMs.
+ *
+ * Group g:   y_g[b, j] = alpha_g * sum_k x_g[b, k] * w_g[j, k] + beta_g * bias_g[j]        b < batch, j < n_g, k < k_g
+ *   x_g: rows x_stride floats apart (>= k), w_g: [n, k] row-major (the EqualLinear parameter layout), bias_g: [n] or NULL, y_g: [batch, n]
+ *   contiguous.  k and x_stride multiples of 4, x / w 16-byte aligned.  Any number of groups (the table is cut into launches of 32).
+ * The three entry points are each other's derivatives and share the table type; the comments give the role of each pointer:
+ *   gc_grouped_linear_f32        reads x, w, bias          writes y
+ *   gc_grouped_linear_bwd_x_f32  reads y (= dL/dy), w      writes x (= dL/dx = alpha * gy @ w)
+ *   gc_grouped_linear_bwd_w_f32  reads y (= dL/dy), x      writes w (= dL/dw = alpha * gy^T @ x) and, when non-NULL, bias (= beta * sum_b gy)
+ * Fixed summation order: bit-identical from run to run. */
+typedef struct gc_glin_group {
+    float* x;
+    float* w;
+    float* bias;
+    float* y;
+    int32_t n, k;
+    int64_t x_stride;
+    float alpha, beta;
+} gc_glin_group;
+int gc_grouped_linear_f32(const gc_glin_group* groups, int n_groups, int batch, gc_stream_t stream);
+int gc_grouped_linear_bwd_x_f32(const gc_glin_group* groups, int n_groups, int batch, gc_stream_t stream);
+int gc_grouped_linear_bwd_w_f32(const gc_glin_group* groups, int n_groups, int batch, gc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * f-2  Forward pass of the FID feature network (inference, fp32): src/gan_control/fid_utils/inception.py:17-165 over
  * overwrite_inception.py.  Replaces BasicConv2d.forward (conv -> BatchNorm(eval) -> ReLU, overwrite_inception.py:424-434), the
  * F.avg_pool2d / F.max_pool2d calls of the Inception blocks (inception.py:204-305, overwrite_inception.py:252-341), the

@@ -18,7 +18,7 @@ def apply_affine(img, G, taps):
     pad_k = (len_k + 1) // 2
     # get_padding, non_leaking.py:266-285
     Ginv = torch.inverse(G)
-    ext = Ginv[:, :2, :] @ torch.tensor([(-1.0, -1, 1), (-1, 1, 1), (1, -1, 1), (1, 1, 1)]).t()
+    ext = Ginv[:, :2, :] @ torch.tensor([(-1.0, -1, 1), (-1, 1, 1), (1, -1, 1), (1, 1, 1)], dtype=Ginv.dtype).t()
     size = torch.tensor((w_o, h_o))
     lo = ((ext.min(-1).values + 1) * size).clamp(max=0).abs().ceil().max(0).values.to(torch.int64).tolist()
     hi = (ext.max(-1).values * size - size).clamp(min=0).ceil().max(0).values.to(torch.int64).tolist()

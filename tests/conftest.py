@@ -75,6 +75,38 @@ class EmulatedBackend:
     def upfirdn2d_act(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, bias, noise, noise_w, slope, gain):
         return self.bias_act(self.upfirdn2d(x, taps, 1, 1, pad_x0, pad_y0, out_h, out_w, flip), bias, noise, noise_w, slope, gain)
 
+    # -- grouped dense layers (include/gancontrol_hip.h: gc_grouped_linear_*): flat layer-major tensors, see op/style.py
+    @staticmethod
+    def _xblock(x, batch, sp):
+        return x[batch * sp.xcol: batch * (sp.xcol + sp.k)].view(batch, sp.k)
+
+    def grouped_linear(self, x, batch, plan, weights, biases):
+        out = []
+        for sp, w, b in zip(plan.specs, weights, biases):
+            y = sp.alpha * (self._xblock(x, batch, sp) @ w.t())
+            if b is not None:
+                y = y + sp.beta * b
+            out.append(y.reshape(-1))
+        return torch.cat(out) if out else x.new_zeros(0)
+
+    def grouped_linear_bwd_x(self, gy, batch, plan, weights):
+        gx = gy.new_zeros(batch * plan.in_cols)
+        at = 0
+        for sp, w in zip(plan.specs, weights):
+            g = gy[batch * at: batch * (at + sp.n)].view(batch, sp.n)
+            self._xblock(gx, batch, sp).copy_(sp.alpha * (g @ w))
+            at += sp.n
+        return gx
+
+    def grouped_linear_bwd_w(self, gy, x, batch, plan, has_bias):
+        gws, gbs, at = [], [], 0
+        for sp, hb in zip(plan.specs, has_bias):
+            g = gy[batch * at: batch * (at + sp.n)].view(batch, sp.n)
+            gws.append(sp.alpha * (g.t() @ self._xblock(x, batch, sp)))
+            gbs.append(sp.beta * g.sum(0) if hb else None)
+            at += sp.n
+        return gws, gbs
+
     def bias_act(self, x, bias, noise, noise_w, slope, gain):
         shape = [1, -1] + [1] * (x.ndim - 2)
         v = x
