@@ -131,6 +131,35 @@ __global__ __launch_bounds__(256) void pack_weights_kernel(const float* __restri
     }
 }
 
+// The same split for MANY weight tensors in one launch (gc_conv2d_pack_weights_bf16x3_grouped): a block finds its tensor in a table.
+constexpr int MAXPG = 48;
+struct PackGroup { const float* w; uint4* wh; uint4* wl; int taps, K, N, kgroups, first; };
+struct PackGroupArgs { PackGroup g[MAXPG]; int n_groups; };
+
+__global__ __launch_bounds__(256) void pack_weights_grouped_kernel(PackGroupArgs a) {
+    int gi = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.n_groups; ++i) gi = ((int)blockIdx.x >= a.g[i].first) ? i : gi;
+    const PackGroup& G = a.g[gi];
+    const size_t total = (size_t)G.taps * G.kgroups * G.N;
+    const size_t u = (size_t)(blockIdx.x - G.first) * 256 + threadIdx.x;
+    if (u >= total) return;
+    const int n = (int)(u % G.N);
+    const size_t rest = u / G.N;
+    const int kg = (int)(rest % G.kgroups), t = (int)(rest / G.kgroups);
+    bf16x8 h, l;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int k = kg * 8 + q;
+        const float v = k < G.K ? G.w[((size_t)t * G.K + k) * G.N + n] : 0.f;
+        const __bf16 hh = (__bf16)v;
+        h[q] = hh;
+        l[q] = (__bf16)(v - (float)hh);
+    }
+    G.wh[u] = *reinterpret_cast<uint4*>(&h);
+    G.wl[u] = *reinterpret_cast<uint4*>(&l);
+}
+
 // Eight values with one scale EACH (a channel-last patch unit: eight channels of one pixel) -> hi / lo bf16 units.  Plain v_mul_f32 /
 // v_sub_f32 by asm: left to itself the compiler pairs neighbouring channels into v_pk_mul_f32 / v_pk_add_f32, and packed fp32 does not
 // run under another wave's MFMA (profiles/pmc_r01.md, co-issue table) -- in the wave-specialised kernel the staging wave shares its SIMD
@@ -1771,6 +1800,32 @@ extern "C" int gc_conv2d_pack_weights_bf16x3(const gc_conv_desc* d, const float*
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)std::min<size_t>((units + 255) / 256, 4096)), dim3(256), 0, (hipStream_t)stream,
                        w, wh, wh + units, taps, d->in_ch, d->out_ch, kgroups);
     return gc::check_launch("gc_conv2d_pack_weights_bf16x3");
+}
+
+extern "C" int gc_conv2d_pack_weights_bf16x3_grouped(const gc_wpack_group* groups, int n_groups, gc_stream_t stream) {
+    if (n_groups < 0 || (n_groups > 0 && !groups)) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_pack_weights_bf16x3_grouped: bad group table");
+    for (int first = 0; first < n_groups; first += MAXPG) {
+        PackGroupArgs a;
+        a.n_groups = std::min(MAXPG, n_groups - first);
+        long long blocks = 0;
+        for (int i = 0; i < a.n_groups; ++i) {
+            const gc_wpack_group& g = groups[first + i];
+            int rc = validate(&g.desc, "gc_conv2d_pack_weights_bf16x3_grouped", false);
+            if (rc) return rc;
+            const size_t need = gc_conv2d_bf16x3_packed_bytes(&g.desc);
+            if (need == 0) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_pack_weights_bf16x3_grouped: group %d runs on the fp32 kernel and takes no packed weights", first + i);
+            if (!g.w || !g.packed || g.packed_bytes < need || (reinterpret_cast<uintptr_t>(g.packed) & 15))
+                return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_pack_weights_bf16x3_grouped: group %d: buffer %zu < %zu bytes (or null / not 16-byte aligned)", first + i, (size_t)g.packed_bytes, need);
+            const int kgroups = (g.desc.in_ch + 7) / 8, taps = g.desc.kh * g.desc.kw;
+            const size_t units = (size_t)taps * kgroups * g.desc.out_ch;
+            uint4* wh = static_cast<uint4*>(g.packed);
+            a.g[i] = PackGroup{g.w, wh, wh + units, taps, g.desc.in_ch, g.desc.out_ch, kgroups, (int)blocks};
+            blocks += (long long)((units + 255) / 256);
+            if (blocks > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_pack_weights_bf16x3_grouped: too many blocks");
+        }
+        if (blocks) hipLaunchKernelGGL(pack_weights_grouped_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return gc::check_launch("gc_conv2d_pack_weights_bf16x3_grouped");
 }
 #endif
 

@@ -12,6 +12,7 @@
 // in the memory order of `dst`, so both sides are coalesced.  The layout pairs the model uses are compiled with constant
 // index arithmetic (weight_layout_kernel<read order, write order, taps>); anything else takes a plain gather kernel.
 #include <algorithm>
+#include <vector>
 
 #include "common.h"
 
@@ -66,10 +67,9 @@ struct TileLds {
 };
 
 template <int RORD, int WORD, int TT>
-__global__ __launch_bounds__(256) void weight_layout_kernel(LayoutArgs a) {
+__device__ __forceinline__ void layout_tile(const LayoutArgs& a, int bx, int by, int bz, float* tile) {
     using L = TileLds<RORD, TT>;
-    __shared__ float tile[L::SIZE];
-    const int k0 = blockIdx.x * TILE, n0 = blockIdx.y * TILE, t0 = blockIdx.z * TT;
+    const int k0 = bx * TILE, n0 = by * TILE, t0 = bz * TT;
     const int ke = min(TILE, a.K - k0), ne = min(TILE, a.N - n0), te = min(TT, a.T - t0);
     constexpr int TOTAL = TT * TILE * TILE, PER = TOTAL / 256;
     // all loads of the lane first (36 in flight for 3x3 taps): a weight tensor is at most a few hundred tiles, so the
@@ -97,6 +97,37 @@ __global__ __launch_bounds__(256) void weight_layout_kernel(LayoutArgs a) {
             a.dst[td * a.dt + (k0 + k) * a.dk + (n0 + n) * a.dn] = a.scale * tile[L::at(t, k, n)];
         }
     }
+}
+
+template <int RORD, int WORD, int TT>
+__global__ __launch_bounds__(256) void weight_layout_kernel(LayoutArgs a) {
+    __shared__ float tile[TileLds<RORD, TT>::SIZE];
+    layout_tile<RORD, WORD, TT>(a, blockIdx.x, blockIdx.y, blockIdx.z, tile);
+}
+
+// The same pass over MANY tensors in one launch (gc_weight_layout_grouped_f32): after every optimiser step all ~25 convolution weights of a
+// network change together and each is needed as kernel layout and as input-gradient layout -- ~50 launches of 4 - 6 us whose work is
+// a few hundred tiles each.  One tap per block (the variants the two forward-side re-layouts use); a block finds its tensor in a table.
+constexpr int MAXLG = 32;
+struct LayoutGroupArgs {
+    LayoutArgs g[MAXLG];
+    int first[MAXLG + 1];        // prefix sum of blocks
+    int n_groups;
+};
+
+template <int RORD, int WORD>
+__global__ __launch_bounds__(256) void weight_layout_grouped_kernel(LayoutGroupArgs a) {
+    __shared__ float tile[TileLds<RORD, 1>::SIZE];
+    int gi = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.n_groups; ++i) gi = ((int)blockIdx.x >= a.first[i]) ? i : gi;
+    const LayoutArgs& L = a.g[gi];
+    int r = blockIdx.x - a.first[gi];
+    const int kb = (L.K + TILE - 1) / TILE, nb = (L.N + TILE - 1) / TILE;
+    const int bx = r % kb; r /= kb;
+    const int by = r % nb;
+    const int bz = r / nb;
+    layout_tile<RORD, WORD, 1>(L, bx, by, bz, tile);
 }
 
 // any other pair of layouts: one element per lane, gathered reads (correct for every stride triple, not fast)
@@ -143,21 +174,67 @@ void launch_tt(const LayoutArgs& a, hipStream_t s) {
     }
 }
 
-}  // namespace
+template <int RORD, int WORD>
+void launch_grouped(const LayoutArgs* list, int count, hipStream_t s) {
+    for (int first = 0; first < count; first += MAXLG) {
+        LayoutGroupArgs a;
+        a.n_groups = std::min(MAXLG, count - first);
+        int blocks = 0;
+        for (int i = 0; i < a.n_groups; ++i) {
+            a.g[i] = list[first + i];
+            a.first[i] = blocks;
+            blocks += gc::ceil_div(a.g[i].K, TILE) * gc::ceil_div(a.g[i].N, TILE) * a.g[i].T;
+        }
+        a.first[a.n_groups] = blocks;
+        hipLaunchKernelGGL((weight_layout_grouped_kernel<RORD, WORD>), dim3((unsigned)blocks), dim3(256), 0, s, a);
+    }
+}
 
-extern "C" int gc_weight_layout_f32(const float* src, float* dst, int taps, int k, int n,
-                                    const int64_t src_stride[3], const int64_t dst_stride[3],
-                                    int flip_taps, float scale, gc_stream_t stream) {
-    if (!src || !dst || !src_stride || !dst_stride) return gc::fail(GC_ERR_BAD_ARG, "gc_weight_layout_f32: null pointer");
-    if (taps <= 0 || k <= 0 || n <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_weight_layout_f32: non-positive extent");
+int fill_args(LayoutArgs& a, const float* src, float* dst, int taps, int k, int n, const int64_t src_stride[3], const int64_t dst_stride[3],
+              int flip_taps, float scale, const char* what) {
+    if (!src || !dst || !src_stride || !dst_stride) return gc::fail(GC_ERR_BAD_ARG, "%s: null pointer", what);
+    if (taps <= 0 || k <= 0 || n <= 0) return gc::fail(GC_ERR_BAD_ARG, "%s: non-positive extent", what);
     for (int i = 0; i < 3; ++i)
-        if (src_stride[i] < 0 || dst_stride[i] < 0) return gc::fail(GC_ERR_BAD_ARG, "gc_weight_layout_f32: negative stride");
-    if (gc::ceil_div(n, TILE) > 65535 || gc::ceil_div(taps, 9) > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "gc_weight_layout_f32: extent too large");
-    LayoutArgs a;
+        if (src_stride[i] < 0 || dst_stride[i] < 0) return gc::fail(GC_ERR_BAD_ARG, "%s: negative stride", what);
+    if (gc::ceil_div(n, TILE) > 65535 || gc::ceil_div(taps, 9) > 65535) return gc::fail(GC_ERR_UNSUPPORTED, "%s: extent too large", what);
     a.src = src; a.dst = dst; a.T = taps; a.K = k; a.N = n;
     a.st = src_stride[0]; a.sk = src_stride[1]; a.sn = src_stride[2];
     a.dt = dst_stride[0]; a.dk = dst_stride[1]; a.dn = dst_stride[2];
     a.flip = flip_taps ? 1 : 0; a.scale = scale;
+    return GC_OK;
+}
+
+}  // namespace
+
+extern "C" int gc_weight_layout_grouped_f32(const gc_wlayout_group* groups, int n_groups, gc_stream_t stream) {
+    if (n_groups < 0 || (n_groups > 0 && !groups)) return gc::fail(GC_ERR_BAD_ARG, "gc_weight_layout_grouped_f32: bad group table");
+    hipStream_t s = (hipStream_t)stream;
+    // the two forward-side re-layouts (parameter -> kernel layout, kernel layout -> input-gradient weights) are batched; anything else
+    // goes through the single-tensor entry point, group by group (same results either way: the tile routine is shared)
+    std::vector<LayoutArgs> fwd, fwd_t, adj;
+    for (int i = 0; i < n_groups; ++i) {
+        const gc_wlayout_group& g = groups[i];
+        LayoutArgs a;
+        int rc = fill_args(a, g.src, g.dst, g.taps, g.k, g.n, g.src_stride, g.dst_stride, g.flip_taps, g.scale, "gc_weight_layout_grouped_f32");
+        if (rc) return rc;
+        const int ro = order_of(g.src_stride, g.taps, g.k, g.n), wo = order_of(g.dst_stride, g.taps, g.k, g.n);
+        if (ro == NKT && wo == TKN) fwd.push_back(a);
+        else if (ro == KNT && wo == TKN) fwd_t.push_back(a);
+        else if (ro == TKN && wo == TNK) adj.push_back(a);
+        else if ((rc = gc_weight_layout_f32(g.src, g.dst, g.taps, g.k, g.n, g.src_stride, g.dst_stride, g.flip_taps, g.scale, stream))) return rc;
+    }
+    if (!fwd.empty()) launch_grouped<NKT, TKN>(fwd.data(), (int)fwd.size(), s);
+    if (!fwd_t.empty()) launch_grouped<KNT, TKN>(fwd_t.data(), (int)fwd_t.size(), s);
+    if (!adj.empty()) launch_grouped<TKN, TNK>(adj.data(), (int)adj.size(), s);
+    return gc::check_launch("gc_weight_layout_grouped_f32");
+}
+
+extern "C" int gc_weight_layout_f32(const float* src, float* dst, int taps, int k, int n,
+                                    const int64_t src_stride[3], const int64_t dst_stride[3],
+                                    int flip_taps, float scale, gc_stream_t stream) {
+    LayoutArgs a;
+    int rc = fill_args(a, src, dst, taps, k, n, src_stride, dst_stride, flip_taps, scale, "gc_weight_layout_f32");
+    if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
     const int ro = order_of(src_stride, taps, k, n), wo = order_of(dst_stride, taps, k, n);
     if (ro == NKT && wo == TKN)      launch_tt<NKT, TKN>(a, s);     // parameter -> kernel layout

@@ -34,6 +34,16 @@ class GlinGroup(ctypes.Structure):
     _fields_ = [('x', _vp), ('w', _vp), ('bias', _vp), ('y', _vp), ('n', _i32), ('k', _i32), ('x_stride', _i64), ('alpha', _f32), ('beta', _f32)]
 
 
+class WLayoutGroup(ctypes.Structure):
+    """Mirror of ``gc_wlayout_group``."""
+    _fields_ = [('src', _vp), ('dst', _vp), ('taps', _i32), ('k', _i32), ('n', _i32), ('flip_taps', _i32), ('src_stride', _i64 * 3), ('dst_stride', _i64 * 3), ('scale', _f32)]
+
+
+class WPackGroup(ctypes.Structure):
+    """Mirror of ``gc_wpack_group``."""
+    _fields_ = [('desc', ConvDesc), ('w', _vp), ('packed', _vp), ('packed_bytes', _sz)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every exported symbol
 SIGNATURES = {
     'gc_abi_version': (_i32, []),
@@ -84,6 +94,8 @@ SIGNATURES = {
     'gc_grouped_linear_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
     'gc_grouped_linear_bwd_x_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
     'gc_grouped_linear_bwd_w_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
+    'gc_weight_layout_grouped_f32': (_i32, [ctypes.POINTER(WLayoutGroup), _i32, _vp]),
+    'gc_conv2d_pack_weights_bf16x3_grouped': (_i32, [ctypes.POINTER(WPackGroup), _i32, _vp]),
     'gc_weight_layout_f32': (_i32, [_vp, _vp, _i32, _i32, _i32, ctypes.POINTER(_i64 * 3), ctypes.POINTER(_i64 * 3), _i32, _f32, _vp]),
 }
 

@@ -446,6 +446,39 @@ class HipBackend:
         _lib.check(rc, 'gc_plane_dot_pitched_f32')
         return self.rows_sum_div(partial, None if den is None else den.contiguous())
 
+    def weight_prep_batch(self, kind, items):
+        """The grouped forms of weight_layout / the bf16 pack for weight_cache's batched refill: one launch per kind.
+        items: 'layout' -> (src, taps, k, n, src_stride, dst_shape, dst_stride, flip, scale); 'pack' -> (w_t, conv-desc fields)."""
+        if not items:
+            return []
+        lib = _lib.load()
+        dev = items[0][0].device
+        outs = []
+        with (self._guard(dev) or contextlib.nullcontext()):
+            if kind == 'layout':
+                table = (_lib.WLayoutGroup * len(items))()
+                for g, (src, taps, k, n, src_stride, dst_shape, dst_stride, flip, scale) in zip(table, items):
+                    _lib.require_cuda_f32(src)
+                    dst = torch.empty(dst_shape, dtype=src.dtype, device=dev)
+                    g.src, g.dst, g.taps, g.k, g.n, g.flip_taps, g.scale = src.data_ptr(), dst.data_ptr(), taps, k, n, int(bool(flip)), float(scale)
+                    for i in range(3):
+                        g.src_stride[i], g.dst_stride[i] = src_stride[i], dst_stride[i]
+                    outs.append(dst)
+                _lib.check(lib.gc_weight_layout_grouped_f32(table, len(items), _lib.stream_of(items[0][0])), 'gc_weight_layout_grouped_f32')
+            elif kind == 'pack':
+                table = (_lib.WPackGroup * len(items))()
+                for g, (w_t, fields) in zip(table, items):
+                    _lib.require_cuda_f32(w_t)
+                    desc = _lib.ConvDesc(*fields)
+                    pbytes = lib.gc_conv2d_bf16x3_packed_bytes(desc)
+                    buf = torch.empty(pbytes // 4, dtype=torch.float32, device=dev)
+                    g.desc, g.w, g.packed, g.packed_bytes = desc, w_t.data_ptr(), buf.data_ptr(), pbytes
+                    outs.append(buf)
+                _lib.check(lib.gc_conv2d_pack_weights_bf16x3_grouped(table, len(items), _lib.stream_of(items[0][0])), 'gc_conv2d_pack_weights_bf16x3_grouped')
+            else:
+                raise ValueError(kind)
+        return outs
+
     def weight_layout(self, src, taps, k, n, src_stride, dst_shape, dst_stride, flip, scale):
         """dst[t',k,n] = scale * src[t,k,n] between two strided weight layouts; see gc_weight_layout_f32."""
         dev = _lib.require_cuda_f32(src)
@@ -577,7 +610,7 @@ class HipBackend:
                     with (self._guard(dev) or contextlib.nullcontext()):
                         _lib.check(lib.gc_conv2d_pack_weights_bf16x3(desc, _lib.ptr(w_t), _lib.ptr(buf), pbytes, _lib.stream_of(w_t)), 'gc_conv2d_pack_weights_bf16x3')
                     return buf
-                packed = weight_cache.derive(w_t, ('pack_bf16x3',), pack)
+                packed = weight_cache.derive(w_t, ('pack_bf16x3',), pack, recipe=('pack', tuple(getattr(desc, f) for f, _ in _lib.ConvDesc._fields_)))
                 sbytes = lib.gc_conv2d_bf16x3_splitk_bytes(desc)          # K slices of a small-plane launch
                 ws = torch.empty(sbytes // 4, dtype=torch.float32, device=dev) if sbytes else None
             else:
@@ -651,6 +684,7 @@ class HipBackend:
 
 
 _active = HipBackend()
+weight_cache.batch_runner = lambda: getattr(_active, 'weight_prep_batch', None)
 
 
 def get():

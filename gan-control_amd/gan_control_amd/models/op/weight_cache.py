@@ -24,6 +24,13 @@ Which roots are cached at all: only tensors with a KNOWN invalidation channel --
 * parameters handed to ``register()`` by code that promises to call ``invalidate()`` after writing them behind the version
   counter (this package's trainer registers G, D and the EMA copy; its ``accumulate`` invalidates the EMA).
 
+Batched refill: a parameter registered as part of a MODULE (``register(module)``) shares a group with the module's other parameters.  The
+cache remembers, per parameter, which derived forms were asked for and how they are made (``recipe``); when the first form of a new
+weight version is requested it recomputes ALL remembered forms of ALL parameters of the group with the backend's grouped kernels
+(gc_weight_layout_grouped_f32, gc_conv2d_pack_weights_bf16x3_grouped): a handful of launches per network and optimiser step instead of
+~4 per layer.  The grouped kernels share their per-element arithmetic with the single-tensor ones: bit-identical values.
+``GANCONTROL_WEIGHT_BATCH=0`` turns the batching off.
+
 Everything else -- an EMA network updated by somebody else's ``par.data.mul_().add_()`` (the reference's own ``accumulate``,
 trainers/utils.py:8-12), a leaf tensor a caller passes in -- is recomputed on every call.  A root whose storage moved
 (``module.to()``, ``load_state_dict(assign=True)``) is dropped on sight.
@@ -34,11 +41,16 @@ import weakref
 import torch
 
 ENABLED = os.environ.get('GANCONTROL_WEIGHT_CACHE', '1') != '0'
+BATCHED = os.environ.get('GANCONTROL_WEIGHT_BATCH', '1') != '0'
 
 _roots = {}      # id(root) -> [weakref(root), version, {key: tensor}, data_ptr of the root]
 _managed = {}    # id(tensor) -> weakref: roots with a known invalidation channel (see the module docstring)
 _derived = {}    # data_ptr of a cached tensor -> (id(root), key)
-stats = {'hit': 0, 'miss': 0, 'bypass': 0}
+_group_of = {}   # id(root) -> group id (parameters registered together as one module)
+_group_members = {}   # group id -> [weakref(root)]
+_recipes = {}    # id(root) -> {key: recipe}: every derived form ever asked of this root and how to make it (survives invalidation)
+stats = {'hit': 0, 'miss': 0, 'bypass': 0, 'batched': 0}
+batch_runner = None   # set by op/_backend.py: () -> callable(kind, items) -> [tensor] of the active backend, or None
 
 
 def _drop(rid):
@@ -64,22 +76,89 @@ def _root_of(src):
         m = _managed.get(rid)
         if m is None or m() is not root:
             return None                   # nobody promised to tell the cache when this tensor changes: recompute
-        entry = _roots.get(rid)
-        if entry is None or entry[0]() is not root:
-            _drop(rid)
-            _roots[rid] = entry = [weakref.ref(root, lambda _, rid=rid: _drop(rid)), root._version, {}, root.data_ptr()]
-        elif entry[1] != root._version or entry[3] != root.data_ptr():
-            for t in entry[2].values():
-                _derived.pop(t.data_ptr(), None)
-            entry[1], entry[2], entry[3] = root._version, {}, root.data_ptr()
+        _ensure_entry(root)
         return (rid, (src.storage_offset(), tuple(src.shape)))
     return None
 
 
-def derive(src, op, make):
+def _ensure_entry(root):
+    """The (fresh or still valid) cache entry of a managed root."""
+    rid = id(root)
+    entry = _roots.get(rid)
+    if entry is None or entry[0]() is not root:
+        _drop(rid)
+        _roots[rid] = entry = [weakref.ref(root, lambda _, rid=rid: _forget(rid)), root._version, {}, root.data_ptr()]
+    elif entry[1] != root._version or entry[3] != root.data_ptr():
+        for t in entry[2].values():
+            _derived.pop(t.data_ptr(), None)
+        entry[1], entry[2], entry[3] = root._version, {}, root.data_ptr()
+    return entry
+
+
+def _forget(rid):
+    _drop(rid)
+    _recipes.pop(rid, None)
+    _group_of.pop(rid, None)
+
+
+def _refill_group(gid):
+    """Recompute every remembered form of every parameter of group ``gid`` that is missing, level by level (forms of the parameter, forms of
+    those forms, ...), each level's re-layouts in one grouped launch and its packs in another."""
+    run = batch_runner() if batch_runner is not None else None
+    if run is None:
+        return
+    todo = []
+    for ref in _group_members.get(gid, ()):
+        root = ref()
+        if root is None or root.numel() == 0 or not root.is_contiguous():
+            continue
+        m = _managed.get(id(root))
+        if m is None or m() is not root:
+            continue
+        bucket = _ensure_entry(root)[2]
+        for key, recipe in _recipes.get(id(root), {}).items():
+            if key not in bucket:
+                todo.append((len(key), id(root), root, key, recipe))
+    if len(todo) < 2:
+        return
+    for depth in sorted({t[0] for t in todo}):
+        level = [t for t in todo if t[0] == depth]
+        for kind in ('layout', 'pack'):
+            items, owners = [], []
+            for _, rid, root, key, recipe in level:
+                if recipe[0] != kind:
+                    continue
+                bucket = _roots[rid][2]
+                if len(key) == 3:                       # parent = a contiguous view of the parameter: (storage offset, shape)
+                    off, shape = key[0], key[1]
+                    n = 1
+                    for d in shape:
+                        n *= d
+                    src = root.detach().reshape(-1)[off - root.storage_offset(): off - root.storage_offset() + n].view(shape)
+                else:
+                    src = bucket.get(key[:-1])
+                    if src is None:
+                        continue                        # its parent could not be made in this pass: the caller's own make() will do it
+                items.append((src,) + tuple(recipe[1:]))
+                owners.append((rid, key))
+            if not items:
+                continue
+            outs = run(kind, items)
+            for (rid, key), out in zip(owners, outs):
+                if out is not None and out.numel() > 0 and out.data_ptr() not in _derived:
+                    _roots[rid][2][key] = out
+                    _derived[out.data_ptr()] = (rid, key)
+                    stats['batched'] += 1
+
+
+
+def derive(src, op, make, recipe=None):
     """``make()`` -- a tensor computed from ``src`` alone by the operation named ``op`` (hashable) -- cached for as
     long as the root of ``src`` keeps its version.  Returns the cached tensor itself: callers must not modify it, and an
-    autograd Function must return an alias (``.detach()``), not this object."""
+    autograd Function must return an alias (``.detach()``), not this object.
+
+    ``recipe`` = ('layout', taps, k, n, src_stride, dst_shape, dst_stride, flip, scale) | ('pack', conv-desc fields): how the backend's
+    grouped kernels make the same tensor, which lets a miss refill the whole parameter group at once (module docstring)."""
     where = _root_of(src) if ENABLED else None
     if where is None:
         stats['bypass'] += 1
@@ -88,6 +167,15 @@ def derive(src, op, make):
     key = prefix + (op,)
     bucket = _roots[rid][2]
     out = bucket.get(key)
+    if out is None and recipe is not None:
+        _recipes.setdefault(rid, {})[key] = recipe
+        gid = _group_of.get(rid)
+        if BATCHED and gid is not None:
+            _refill_group(gid)
+            bucket = _roots[rid][2]
+            out = bucket.get(key)
+            if out is not None:
+                return out
     if out is None:
         stats['miss'] += 1
         out = make()
@@ -108,8 +196,11 @@ def register(obj):
     """Mark parameters as cacheable: ``obj`` is a module, a tensor or an iterable of tensors.  The caller promises that every write
     that does not go through an optimiser step or bump the autograd version counter (``.data`` arithmetic, fused kernels of its own,
     collectives on ``.data``) is followed by ``invalidate()`` on the written tensors."""
+    gid = None
     if isinstance(obj, torch.nn.Module):
-        obj = obj.parameters()
+        gid = id(obj)
+        obj = list(obj.parameters())
+        _group_members[gid] = [weakref.ref(t) for t in obj]
     elif torch.is_tensor(obj):
         obj = (obj,)
     for t in obj:
@@ -117,11 +208,16 @@ def register(obj):
         m = _managed.get(tid)
         if m is None or m() is not t:
             _managed[tid] = weakref.ref(t, lambda _, tid=tid: _managed.pop(tid, None))
+        if gid is not None:
+            _group_of[tid] = gid
 
 
 def unregister_all():
     """Forget every registration and every cached tensor (tests)."""
     _managed.clear()
+    _group_of.clear()
+    _group_members.clear()
+    _recipes.clear()
     clear()
 
 

@@ -21,8 +21,9 @@ class _Relayout(Function):
         ctx.scale = scale
         # once per (weight, optimiser step): the result is cached on the weight's version counter (weight_cache.py); .detach() = a
         # fresh alias for autograd to attach this node to
-        out = weight_cache.derive(src, ('layout', taps, k, n, tuple(src_stride), tuple(dst_shape), tuple(dst_stride), bool(flip), float(scale)),
-                                  lambda: _backend.get().weight_layout(src.contiguous(), taps, k, n, src_stride, dst_shape, dst_stride, flip, scale))
+        key = ('layout', taps, k, n, tuple(src_stride), tuple(dst_shape), tuple(dst_stride), bool(flip), float(scale))
+        out = weight_cache.derive(src, key, lambda: _backend.get().weight_layout(src.contiguous(), taps, k, n, src_stride, dst_shape, dst_stride, flip, scale),
+                                  recipe=key)
         return out.detach()
 
     @staticmethod

@@ -363,6 +363,27 @@ int gc_affine_warp_bilinear_f32(const float* x, const float* mat, float* y, int 
 int gc_reflect_pad_f32(const float* x, float* y, int planes, int in_h, int in_w, int left, int right, int top, int bottom,
                        int adjoint, gc_stream_t stream);
 
+/* The derived weight forms of a whole network in a few launches.  After an optimiser step every convolution weight of a network is needed
+ * again as kernel layout, as input-gradient layout and (split-bf16 mode) as hi / lo packs of both: ~4 launches of 4 - 6 us per layer and
+ * weight version when done one tensor at a time (gc_weight_layout_f32, gc_conv2d_pack_weights_bf16x3).  The grouped entry points take a
+ * table of the same arguments and produce bit-identical results (the per-element arithmetic is shared). */
+typedef struct gc_wlayout_group {
+    const float* src;
+    float* dst;
+    int32_t taps, k, n, flip_taps;
+    int64_t src_stride[3], dst_stride[3];
+    float scale;
+} gc_wlayout_group;
+int gc_weight_layout_grouped_f32(const gc_wlayout_group* groups, int n_groups, gc_stream_t stream);
+
+typedef struct gc_wpack_group {
+    gc_conv_desc desc;        /* as for gc_conv2d_pack_weights_bf16x3 */
+    const float* w;           /* [kh, kw, in_ch, out_ch] */
+    void* packed;             /* gc_conv2d_bf16x3_packed_bytes(&desc) bytes, 16-byte aligned */
+    size_t packed_bytes;
+} gc_wpack_group;
+int gc_conv2d_pack_weights_bf16x3_grouped(const gc_wpack_group* groups, int n_groups, gc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Grouped dense layers of the style path: every EqualLinear of one kind in ONE launch.
  *

@@ -224,6 +224,12 @@ class EmulatedBackend:
         torch.as_strided(dst.reshape(-1), (taps, k, n), tuple(dst_stride)).copy_(view * scale)
         return dst
 
+    def weight_prep_batch(self, kind, items):
+        """The grouped re-layout (gc_weight_layout_grouped_f32): the same values as one weight_layout call per item."""
+        if kind != 'layout':
+            raise ValueError(kind)
+        return [self.weight_layout(*it) for it in items]
+
     def affine_warp(self, x, mat, in_h, in_w, out_h, out_w, adjoint):
         def fwd(img):
             ox = torch.arange(out_w, dtype=img.dtype).view(1, 1, out_w)

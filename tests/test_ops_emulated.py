@@ -132,12 +132,15 @@ def test_weight_cache_survives_fused_optimizer_and_data_writes(emu_backend):
 
 
 def test_training_with_and_without_weight_cache(emu_backend):
-    """Three full iterations (fused Adam, EMA) with the cache of derived weight forms on and off: the same parameters, bit for bit."""
+    """Three full iterations (fused Adam, EMA) with the cache of derived weight forms on (batched refill of a whole network's forms per
+    optimiser step), on without batching, and off: the same parameters, bit for bit."""
     from gan_control_amd.models.op import weight_cache
     out = []
-    for enabled in (True, False):
+    for enabled, batched in ((True, True), (True, False), (False, False)):
         weight_cache.clear()
         weight_cache.ENABLED, prev = enabled, weight_cache.ENABLED
+        weight_cache.BATCHED, prev_b = batched, weight_cache.BATCHED
+        before = weight_cache.stats['batched']
         try:
             from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
             tr = GeneratorTrainer(default_config(16, 4), device='cpu', seed=0, fused_adam=True)
@@ -145,10 +148,11 @@ def test_training_with_and_without_weight_cache(emu_backend):
             for i in range(3):
                 tr.train_iteration(i, real)
             out.append({k: v.clone() for k, v in list(tr.generator.state_dict().items()) + list(tr.discriminator.state_dict().items())})
+            assert (weight_cache.stats['batched'] > before) == batched, 'batched refill %s' % ('did not run' if batched else 'ran although switched off')
         finally:
-            weight_cache.ENABLED = prev
+            weight_cache.ENABLED, weight_cache.BATCHED = prev, prev_b
     for k in out[0]:
-        assert torch.equal(out[0][k], out[1][k]), k
+        assert torch.equal(out[0][k], out[1][k]) and torch.equal(out[0][k], out[2][k]), k
     weight_cache.clear()
 
 

@@ -643,6 +643,37 @@ def test_weight_cache_survives_fused_optimizer_and_data_writes_gpu():
     _fused_step_conv_check(DEV)
 
 
+@pytest.mark.parametrize('mode', ['bf16x3', 'f32'])
+def test_batched_weight_forms_are_bit_identical_gpu(mode):
+    """Three iterations with the derived weight forms of a whole network refilled by the grouped kernels (gc_weight_layout_grouped_f32,
+    gc_conv2d_pack_weights_bf16x3_grouped), one form at a time, and without any cache: the same parameters, bit for bit."""
+    from gan_control_amd.models.op import weight_cache
+    from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
+    hip, _ = _be()
+    prev_mode, hip.conv_mode = hip.conv_mode, mode
+    out = []
+    try:
+        for enabled, batched in ((True, True), (True, False), (False, False)):
+            weight_cache.clear()
+            weight_cache.ENABLED, prev = enabled, weight_cache.ENABLED
+            weight_cache.BATCHED, prev_b = batched, weight_cache.BATCHED
+            before = weight_cache.stats['batched']
+            try:
+                tr = GeneratorTrainer(default_config(64, 4), device=DEV, seed=0)
+                real = tr.synthetic_batch()
+                for i in range(3):
+                    tr.train_iteration(i, real)
+                out.append({k: v.clone() for k, v in list(tr.generator.state_dict().items()) + list(tr.discriminator.state_dict().items())})
+                assert (weight_cache.stats['batched'] > before) == batched
+            finally:
+                weight_cache.ENABLED, weight_cache.BATCHED = prev, prev_b
+    finally:
+        hip.conv_mode = prev_mode
+    for k in out[0]:
+        assert torch.equal(out[0][k], out[1][k]) and torch.equal(out[0][k], out[2][k]), k
+    weight_cache.clear()
+
+
 def _pitched(t, pitch):
     """A row-pitched copy of a dense [B, C, H, W] tensor: the layout gc_conv_desc.out_pitch / gc_upfirdn2d_pitched_f32 write, with
     garbage in the padding columns (nothing may read them)."""
