@@ -58,6 +58,11 @@
 #ifndef GC_CT_ABL
 #define GC_CT_ABL 0           // dev ablations of convt_fused_bf16x3_kernel (wrong results): 1 no stores, 2 no MFMAs, 4 no global loads
 #endif
+#ifndef GC_CT_DMA
+#define GC_CT_DMA 0           // 1: convt_fused_bf16x3_kernel copies the pre-split weight slab of a chunk HBM -> LDS by LDS-DMA instead of through registers.
+                              // Measured SLOWER at >= 256 input channels (512 -> 256 @64^2, B = 4: 211 -> 239 us; 256 -> 128 @128^2: 183 -> 191; neutral at <= 128): with
+                              // one weight stage the DMA is issued after the barrier that ends the MFMA phase and its latency is exposed before the next one.
+#endif
 #ifndef GC_WS_DMA_STAGER
 #define GC_WS_DMA_STAGER 0     // 1: the staging waves issue the weight LDS-DMA -- measured SLOWER (512 -> 512 @64^2: 177 -> 203 us): the DMA wait lands on the staging waves' critical path
 #endif
@@ -1387,7 +1392,7 @@ struct TCfg {
 // EPI: 0 = store the accumulators as they are (input-gradient launches), 1 = out_scale only (modulated up-sampling
 // convolution), 2 = the full fused epilogue.  The epilogue is ~6 VALU instructions per output element on 256 elements per
 // lane; compiled out where the launch does not need it (bare stores are 10 % faster at <= 128 input channels).
-template <int WG_OC, int WG_PX, int WPX, int TPW, int EPI>
+template <int WG_OC, int WG_PX, int WPX, int TPW, int EPI, bool WDMA = false>
 __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) {
     using C = TCfg<WG_OC, WG_PX, WPX, TPW>;
     static_assert(WG_OC * WG_PX == 4, "4 waves per workgroup");
@@ -1434,7 +1439,33 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     const int chan = p.in_h * p.in_w;
     const int iy0 = qy0 - 1, ix0 = qx0 - 1;
 
-    uint4 wreg_h[C::NWU], wreg_l[C::NWU];
+    // WDMA: the weight slab never touches a register.  Its rows ([tap][kg] x OCT units, contiguous in HBM and in LDS) are copied by
+    // LDS-DMA into the SINGLE weight stage right after the barrier that ends the MFMA phase -- every wave has read its fragments by then --
+    // and land while the patch of the next chunk is converted and written; vmcnt(0) before the second barrier.  40 registers and
+    // 10 ds_write_b128 per lane and chunk less than the register path (launch_t takes this path when N and K need no masking).
+    uint4 wreg_h[WDMA ? 1 : C::NWU], wreg_l[WDMA ? 1 : C::NWU];
+#ifdef GC_SINGLE
+    constexpr int DROWS = 9 * KG;
+#else
+    constexpr int DROWS = 2 * 9 * KG;
+#endif
+    constexpr int RPI = 64 / OCT, DINSTR = DROWS / RPI;
+    static_assert(!WDMA || (DROWS % RPI == 0 && (9 * KG) % RPI == 0), "row groups do not straddle the hi / lo halves");
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto dma_weights = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < (DINSTR + 3) / 4; ++j) {
+            const int q = wave_u + 4 * j;
+            if (4 * j + 3 < DINSTR || q < DINSTR) {
+                const int r0 = q * RPI;
+                const int half = r0 / (9 * KG), rr0 = r0 % (9 * KG);
+                const int rr = rr0 + lane / OCT;
+                const int t = rr / KG, kg = rr % KG;
+                const uint4* src = (half ? a.wl : a.wh) + ((size_t)(t * a.kgroups + k0 / 8 + kg) * p.N + n0 + lane % OCT);
+                glds16(src, (half ? wl_l : wl_h) + rr0 * OCT);
+            }
+        }
+    };
     // Patch staging as in conv_bf16x3_kernel: a lane fetches FOUR consecutive pixels of a channel with one 16-byte load (eight
     // channels = eight loads) and transposes them in registers into four channel-last units.  The texture-address unit spends
     // ~16 cycles per wave-level load whatever its width; with 24 dword loads per lane per chunk that was more than the MFMAs of a
@@ -1452,16 +1483,18 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     const __amdgpu_buffer_rsrc_t rwh = make_rsrc(a.wh, wbytes), rwl = make_rsrc(a.wl, wbytes);
     auto prefetch = [&](int k0) {
         const int t_ = tid;
+        if (!WDMA) {
 #pragma unroll
-        for (int j = 0; j < C::NWU; ++j) {
-            const int u = t_ + 256 * j;
-            const int oc = u % OCT, rest = u / OCT;
-            const int kgl = rest % KG, tap = rest / KG;
-            const int kg = k0 / 8 + kgl, n = n0 + oc;
-            const bool ok = u < C::WUNITS && kg < a.kgroups && n < p.N;
-            const unsigned gb = ok ? (unsigned)((tap * a.kgroups + kg) * p.N + n) * 16u : OOB;
-            wreg_h[j] = (GC_CT_ABL & 4) ? make_uint4(gb, gb, gb, gb) : buf_load_u128(rwh, gb, 0);
-            wreg_l[j] = (GC_CT_ABL & 4) ? make_uint4(gb, gb, gb, gb) : buf_load_u128(rwl, gb, 0);
+            for (int j = 0; j < C::NWU; ++j) {
+                const int u = t_ + 256 * j;
+                const int oc = u % OCT, rest = u / OCT;
+                const int kgl = rest % KG, tap = rest / KG;
+                const int kg = k0 / 8 + kgl, n = n0 + oc;
+                const bool ok = u < C::WUNITS && kg < a.kgroups && n < p.N;
+                const unsigned gb = ok ? (unsigned)((tap * a.kgroups + kg) * p.N + n) * 16u : OOB;
+                wreg_h[j] = (GC_CT_ABL & 4) ? make_uint4(gb, gb, gb, gb) : buf_load_u128(rwh, gb, 0);
+                wreg_l[j] = (GC_CT_ABL & 4) ? make_uint4(gb, gb, gb, gb) : buf_load_u128(rwl, gb, 0);
+            }
         }
         const int iy = iy0 + t_row, ix = ix0 + t_col;
         const bool ok = t_used > 0 && iy >= 0 && iy < p.in_h && ix >= 0 && ix < p.in_w;
@@ -1475,10 +1508,14 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     auto commit = [&](int k0) {
         wait_staged_loads();
         const int t_ = tid;
+        if (WDMA) {
+            if (!(GC_CT_ABL & 4)) dma_weights(k0);          // in flight during the conversion below
+        } else {
 #pragma unroll
-        for (int j = 0; j < C::NWU; ++j) {
-            const int u = t_ + 256 * j;
-            if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; GC_LO(wl_l[u] = wreg_l[j];) }
+            for (int j = 0; j < C::NWU; ++j) {
+                const int u = t_ + 256 * j;
+                if (u < C::WUNITS) { wl_h[u] = wreg_h[j]; GC_LO(wl_l[u] = wreg_l[j];) }
+            }
         }
         const float4 sa = *reinterpret_cast<const float4*>(&s_si[k0 + kgl_p * 8]), sb = *reinterpret_cast<const float4*>(&s_si[k0 + kgl_p * 8 + 4]);
         const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
@@ -1499,6 +1536,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
                 GC_LO(p_l[ubase + i] = l;)
             }
         }
+        if (WDMA) wait_staged_loads();           // the LDS-DMA rows of this wave have landed (untracked by the compiler: counted by hand)
     };
 
     prefetch(0);
@@ -1614,6 +1652,14 @@ int launch_t(Bf16Args a, hipStream_t s) {
     if (gc::probing()) return gc::probe_name("convt_fused_bf16x3_kernel<%d,%d,%d,%d>|up2,down1,k3", WG_OC, WG_PX, WPX, TPW);
     dim3 grid((unsigned)gx, gc::ceil_div(a.c.N, C::OCT));
     const int epi = (a.c.bias || a.c.noise || a.c.act || a.c.residual) ? 2 : (a.c.so ? 1 : 0);
+    // LDS-DMA copies whole rows unmasked: every output-channel block and every 16-channel chunk must be complete
+    const bool dma = GC_CT_DMA && a.c.N % C::OCT == 0 && a.c.K % KCB == 0;
+    if (dma) {
+        if (epi == 2)      hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 2, true>), grid, dim3(256), 0, s, a);
+        else if (epi == 1) hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 1, true>), grid, dim3(256), 0, s, a);
+        else               hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 0, true>), grid, dim3(256), 0, s, a);
+        return gc::check_launch("gc_conv2d_bf16x3_f32(fused transposed, weight DMA)");
+    }
     if (epi == 2)      hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 2>), grid, dim3(256), 0, s, a);
     else if (epi == 1) hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 1>), grid, dim3(256), 0, s, a);
     else               hipLaunchKernelGGL((convt_fused_bf16x3_kernel<WG_OC, WG_PX, WPX, TPW, 0>), grid, dim3(256), 0, s, a);

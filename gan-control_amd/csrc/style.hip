@@ -180,6 +180,52 @@ __global__ __launch_bounds__(256) void style_glin_bwd_w_kernel(GArgs a) {
     if (q == 0 && G.bias) const_cast<float*>(G.bias)[j] = G.beta * sb;
 }
 
+// ---- sum over the taps of W^2 (the weight half of the demodulation coefficient) for many weight tensors, and its gradient ----------
+constexpr int MAXWS = 48;
+struct WsqGroup { const float* w; const float* g; float* out; int rows, taps, first; };
+struct WsqArgs { WsqGroup g[MAXWS]; int n_groups; };
+
+template <bool BWD>
+__global__ __launch_bounds__(256) void style_wsq_kernel(WsqArgs a) {
+    int gi = 0;
+#pragma unroll 1
+    for (int i = 1; i < a.n_groups; ++i) gi = ((int)blockIdx.x >= a.g[i].first) ? i : gi;
+    const WsqGroup& G = a.g[gi];
+    const int r = (blockIdx.x - G.first) * 256 + threadIdx.x;
+    if (r >= G.rows) return;
+    const float* w = G.w + (long long)r * G.taps;
+    if (!BWD) {
+        float s = 0.f;
+        for (int t = 0; t < G.taps; ++t) s = fmaf(w[t], w[t], s);
+        G.out[r] = s;
+    } else {
+        const float g2 = 2.f * G.g[r];
+        float* o = G.out + (long long)r * G.taps;
+        for (int t = 0; t < G.taps; ++t) o[t] = g2 * w[t];
+    }
+}
+
+int launch_wsq(const gc_wsq_group* groups, int n_groups, gc_stream_t stream, bool bwd, const char* what) {
+    if (n_groups < 0 || (n_groups > 0 && !groups)) return gc::fail(GC_ERR_BAD_ARG, "%s: bad group table", what);
+    for (int first = 0; first < n_groups; first += MAXWS) {
+        WsqArgs a;
+        a.n_groups = std::min(MAXWS, n_groups - first);
+        long long blocks = 0;
+        for (int i = 0; i < a.n_groups; ++i) {
+            const gc_wsq_group& g = groups[first + i];
+            if (!g.w || !g.out || (bwd && !g.g)) return gc::fail(GC_ERR_BAD_ARG, "%s: group %d has a null operand", what, first + i);
+            if (g.rows <= 0 || g.taps <= 0) return gc::fail(GC_ERR_BAD_ARG, "%s: group %d has extents rows = %d, taps = %d", what, first + i, g.rows, g.taps);
+            a.g[i] = WsqGroup{g.w, g.g, g.out, g.rows, g.taps, (int)blocks};
+            blocks += gc::ceil_div(g.rows, 256);
+            if (blocks > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "%s: too many blocks", what);
+        }
+        if (!blocks) continue;
+        if (bwd) hipLaunchKernelGGL(style_wsq_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+        else     hipLaunchKernelGGL(style_wsq_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    }
+    return gc::check_launch(what);
+}
+
 enum { K_FWD = 0, K_BWD_X = 1, K_BWD_W = 2 };
 
 int launch(const gc_glin_group* groups, int n_groups, int batch, gc_stream_t stream, int kind, const char* what) {
@@ -241,4 +287,12 @@ extern "C" int gc_grouped_linear_bwd_x_f32(const gc_glin_group* groups, int n_gr
 
 extern "C" int gc_grouped_linear_bwd_w_f32(const gc_glin_group* groups, int n_groups, int batch, gc_stream_t stream) {
     return launch(groups, n_groups, batch, stream, K_BWD_W, "gc_grouped_linear_bwd_w_f32");
+}
+
+extern "C" int gc_weight_sq_grouped_f32(const gc_wsq_group* groups, int n_groups, gc_stream_t stream) {
+    return launch_wsq(groups, n_groups, stream, false, "gc_weight_sq_grouped_f32");
+}
+
+extern "C" int gc_weight_sq_bwd_grouped_f32(const gc_wsq_group* groups, int n_groups, gc_stream_t stream) {
+    return launch_wsq(groups, n_groups, stream, true, "gc_weight_sq_bwd_grouped_f32");
 }

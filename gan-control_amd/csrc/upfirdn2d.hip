@@ -26,13 +26,22 @@ struct FirEpilogue {
     float slope, gain; int channels;
 };
 
+// GC_FIR_NT vertically consecutive tiles per workgroup in one software pipeline (the 16-byte loads of tile t + 1 issued before the
+// arithmetic and the stores of tile t, committed to LDS after them).  Measured with 4 tiles per workgroup (round 3, same-box A/B,
+// tools/kbench.py): SLOWER -- [4, 32, 1025^2] 212 -> 252 us (5.07 -> 4.26 TB/s), [4, 64, 513^2] 111 -> 128 us, [4, 128, 257^2] 54 -> 64 us: the
+// eight workgroups a CU holds already overlap each other's load / compute / store phases, and a quarter of the workgroups with two more
+// barriers per tile only lengthens the tail.  One tile per workgroup stays the default.
+#ifndef GC_FIR_NT
+#define GC_FIR_NT 1
+#endif
+
 template <bool VEC, bool EPI>
 __global__ __launch_bounds__(256) void fir44_tile_kernel(
     const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
     int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip, FirEpilogue ep, int in_pitch, int out_pitch) {
     __shared__ __attribute__((aligned(16))) float patch[PH * PITCH];
     const int tid = threadIdx.x;
-    const int ox0 = blockIdx.x * TW, oy0 = blockIdx.y * TH;
+    const int ox0 = blockIdx.x * TW;
     const size_t plane = blockIdx.z;
     const float* xp = x + plane * (size_t)in_h * in_pitch;      // in_pitch floats between input rows (in_w when dense)
     float* yp = y + plane * (size_t)out_h * out_pitch;          // out_pitch floats between output rows (out_w when dense)
@@ -47,106 +56,126 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
     // stage the patch: a lane fetches 4 consecutive floats of one input row with one 16-byte load (rows are only 4-byte
     // aligned for 1025-wide planes: fine for gfx9) -- 5 loads per lane instead of 19 dword loads; groups that touch an
     // image border fall back to guarded scalar loads.  All loads are issued before the first LDS write.
-    const int iy0 = oy0 - pad_y0, ix0 = ox0 - pad_x0;
+    const int ix0 = ox0 - pad_x0;
     constexpr int GPR = PITCH / 4;                           // 16-byte groups per patch row
     constexpr int NLD = (PH * GPR + 255) / 256;
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     float4 stage[NLD];
+    auto fetch = [&](int oy0) {
+        const int iy0 = oy0 - pad_y0;
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int idx = tid + 256 * j;
-        const int r = idx / GPR, c = (idx - r * GPR) * 4;
-        const int iy = iy0 + r, ix = ix0 + c;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (idx < PH * GPR && iy >= 0 && iy < in_h) {
-            const float* src = xp + (size_t)iy * in_pitch + ix;
-            if (ix >= 0 && ix + 3 < in_w) {
-                const f4u t = *reinterpret_cast<const f4u*>(src);
-                v = make_float4(t.x, t.y, t.z, t.w);
-            } else {
-                if (ix >= 0 && ix < in_w) v.x = src[0];
-                if (ix + 1 >= 0 && ix + 1 < in_w) v.y = src[1];
-                if (ix + 2 >= 0 && ix + 2 < in_w) v.z = src[2];
-                if (ix + 3 >= 0 && ix + 3 < in_w) v.w = src[3];
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + 256 * j;
+            const int r = idx / GPR, c = (idx - r * GPR) * 4;
+            const int iy = iy0 + r, ix = ix0 + c;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (idx < PH * GPR && iy >= 0 && iy < in_h) {
+                const float* src = xp + (size_t)iy * in_pitch + ix;
+                if (ix >= 0 && ix + 3 < in_w) {
+                    const f4u t = *reinterpret_cast<const f4u*>(src);
+                    v = make_float4(t.x, t.y, t.z, t.w);
+                } else {
+                    if (ix >= 0 && ix < in_w) v.x = src[0];
+                    if (ix + 1 >= 0 && ix + 1 < in_w) v.y = src[1];
+                    if (ix + 2 >= 0 && ix + 2 < in_w) v.z = src[2];
+                    if (ix + 3 >= 0 && ix + 3 < in_w) v.w = src[3];
+                }
             }
+            stage[j] = v;
         }
-        stage[j] = v;
-    }
+    };
+    auto commit = [&]() {
 #pragma unroll
-    for (int j = 0; j < NLD; ++j) {
-        const int idx = tid + 256 * j;
-        if (idx < PH * GPR) *reinterpret_cast<float4*>(&patch[idx * 4]) = stage[j];
-    }
-    __syncthreads();
+        for (int j = 0; j < NLD; ++j) {
+            const int idx = tid + 256 * j;
+            if (idx < PH * GPR) *reinterpret_cast<float4*>(&patch[idx * 4]) = stage[j];
+        }
+    };
 
     const int cg = tid & 31, rg = tid >> 5;   // 32 column groups x 8 row groups of 4x4 outputs
-    float acc[4][4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
-
-#pragma unroll
-    for (int i = 0; i < 7; ++i) {
-        const float* row = &patch[(rg * 4 + i) * PITCH + cg * 4];
-        const float4 lo = *reinterpret_cast<const float4*>(row);
-        const float v4 = row[4], v5 = row[5], v6 = row[6];
-        const float v[7] = {lo.x, lo.y, lo.z, lo.w, v4, v5, v6};
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int a = i - r;
-            if (a < 0 || a > 3) continue;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int b = 0; b < 4; ++b) acc[r][j] = fmaf(T[a][b], v[j + b], acc[r][j]);
-        }
-    }
-
     const int ox = ox0 + cg * 4;
-    if (EPI) {
-        // every noise value of the micro-tile is fetched before the first store (a load between stores costs a full
-        // memory round trip: vmcnt counts the stores too)
-        const int c = (int)(plane % ep.channels);
-        const size_t b = plane / ep.channels;
-        const float bv = ep.bias ? ep.bias[c] : 0.f, nw = ep.noise ? ep.noise_w[0] : 0.f;
-        float nz[4][4];
+    const int ty0 = blockIdx.y * GC_FIR_NT;
+    const int tiles_y = (out_h + TH - 1) / TH;
+    const int nt = min(GC_FIR_NT, tiles_y - ty0);
+    fetch(ty0 * TH);
+    commit();
+    __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+        const int oy0 = (ty0 + t) * TH;
+        const bool more = t + 1 < nt;
+        if (more) fetch(oy0 + TH);            // in flight during the arithmetic and the stores below
+
+        float acc[4][4];
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int oy = oy0 + rg * 4 + r;
-                nz[r][j] = (ep.noise && oy < out_h && ox + j < out_w) ? ep.noise[(b * out_h + oy) * out_w + ox + j] : 0.f;
-            }
+            for (int j = 0; j < 4; ++j) acc[r][j] = 0.f;
+
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
+        for (int i = 0; i < 7; ++i) {
+            const float* row = &patch[(rg * 4 + i) * PITCH + cg * 4];
+            const float4 lo = *reinterpret_cast<const float4*>(row);
+            const float v4 = row[4], v5 = row[5], v6 = row[6];
+            const float v[7] = {lo.x, lo.y, lo.z, lo.w, v4, v5, v6};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float v = fmaf(nw, nz[r][j], acc[r][j]) + bv;
-                acc[r][j] = (v > 0.f ? v : v * ep.slope) * ep.gain;
-            }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int oy = oy0 + rg * 4 + r;
-        if (oy >= out_h) break;
-        float* dst = yp + (size_t)oy * out_pitch + ox;
-        if (VEC) {
-            if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
-            else {
+            for (int r = 0; r < 4; ++r) {
+                const int a = i - r;
+                if (a < 0 || a > 3) continue;
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    if (ox + j < out_w) dst[j] = acc[r][j];          // the ragged end of a pitched odd-width row
-            }
-        } else if (ox + 3 < out_w) {
-            // odd widths (1025, 513, ...): rows are only 4-byte aligned, which a 16-byte store accepts on gfx9 (as the
-            // 16-byte loads of the weight-gradient kernels do): one store instruction instead of four
-            typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
-            *reinterpret_cast<f4u*>(dst) = f4u{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
-        } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (ox + j < out_w) dst[j] = acc[r][j];
+                    for (int b = 0; b < 4; ++b) acc[r][j] = fmaf(T[a][b], v[j + b], acc[r][j]);
+            }
+        }
+
+        if (EPI) {
+            // every noise value of the micro-tile is fetched before the first store (a load between stores costs a full
+            // memory round trip: vmcnt counts the stores too)
+            const int c = (int)(plane % ep.channels);
+            const size_t b = plane / ep.channels;
+            const float bv = ep.bias ? ep.bias[c] : 0.f, nw = ep.noise ? ep.noise_w[0] : 0.f;
+            float nz[4][4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int oy = oy0 + rg * 4 + r;
+                    nz[r][j] = (ep.noise && oy < out_h && ox + j < out_w) ? ep.noise[(b * out_h + oy) * out_w + ox + j] : 0.f;
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = fmaf(nw, nz[r][j], acc[r][j]) + bv;
+                    acc[r][j] = (v > 0.f ? v : v * ep.slope) * ep.gain;
+                }
+        }
+        if (more) {
+            __syncthreads();              // every lane has read its window of this tile
+            commit();                     // waits for the loads issued above; no store is outstanding yet
+            __syncthreads();
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int oy = oy0 + rg * 4 + r;
+            if (oy >= out_h) break;
+            float* dst = yp + (size_t)oy * out_pitch + ox;
+            if (VEC) {
+                if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (ox + j < out_w) dst[j] = acc[r][j];          // the ragged end of a pitched odd-width row
+                }
+            } else if (ox + 3 < out_w) {
+                // odd widths (1025, 513, ...): rows are only 4-byte aligned, which a 16-byte store accepts on gfx9 (as the
+                // 16-byte loads of the weight-gradient kernels do): one store instruction instead of four
+                *reinterpret_cast<f4u*>(dst) = f4u{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (ox + j < out_w) dst[j] = acc[r][j];
+            }
         }
     }
 }
@@ -513,7 +542,7 @@ int upfirdn2d_impl(const float* x, const float* taps, float* y,
     if (ep && !fast) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_act_f32: the fused epilogue needs the 4x4, up = down = 1 tile kernel (planes >= 64 x 16)");
     if ((in_pitch != in_w || out_pitch != out_w) && !fast) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_pitched_f32: a pitched input needs the 4x4, up = down = 1 tile kernel (planes >= 64 x 16)");
     if (fast) {
-        dim3 grid(gc::ceil_div(out_w, TW), gc::ceil_div(out_h, TH), planes);
+        dim3 grid(gc::ceil_div(out_w, TW), gc::ceil_div(gc::ceil_div(out_h, TH), GC_FIR_NT), planes);
         const bool vec = (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);      // rows start on 16-byte boundaries
         const FirEpilogue none{nullptr, nullptr, nullptr, 1.f, 1.f, 1};
 #define GC_FIR(V, E) hipLaunchKernelGGL((fir44_tile_kernel<V, E>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, ep ? *ep : none, in_pitch, out_pitch)

@@ -44,6 +44,11 @@ class WPackGroup(ctypes.Structure):
     _fields_ = [('desc', ConvDesc), ('w', _vp), ('packed', _vp), ('packed_bytes', _sz)]
 
 
+class WsqGroup(ctypes.Structure):
+    """Mirror of ``gc_wsq_group``."""
+    _fields_ = [('w', _vp), ('g', _vp), ('out', _vp), ('rows', _i32), ('taps', _i32)]
+
+
 # name -> (restype, argtypes); kept in one table so tests can check every exported symbol
 SIGNATURES = {
     'gc_abi_version': (_i32, []),
@@ -94,6 +99,8 @@ SIGNATURES = {
     'gc_grouped_linear_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
     'gc_grouped_linear_bwd_x_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
     'gc_grouped_linear_bwd_w_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
+    'gc_weight_sq_grouped_f32': (_i32, [ctypes.POINTER(WsqGroup), _i32, _vp]),
+    'gc_weight_sq_bwd_grouped_f32': (_i32, [ctypes.POINTER(WsqGroup), _i32, _vp]),
     'gc_weight_layout_grouped_f32': (_i32, [ctypes.POINTER(WLayoutGroup), _i32, _vp]),
     'gc_conv2d_pack_weights_bf16x3_grouped': (_i32, [ctypes.POINTER(WPackGroup), _i32, _vp]),
     'gc_weight_layout_f32': (_i32, [_vp, _vp, _i32, _i32, _i32, ctypes.POINTER(_i64 * 3), ctypes.POINTER(_i64 * 3), _i32, _f32, _vp]),

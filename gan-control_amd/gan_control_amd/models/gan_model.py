@@ -22,7 +22,7 @@ _FORK_TORGB = os.environ.get('GANCONTROL_FORK_TORGB', '0') == '1'         # off 
 from .op import _backend
 from .op import (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, upfirdn2d_bias_act, conv2d_gradfix, modulated_conv2d,
                  modulated_conv2d_act)
-from .op.modulated_conv import demod_coefficients, _WeightSq, _eps_vector
+from .op.modulated_conv import demod_coefficients, weight_sq_all, _eps_vector
 from .op.linear import scaled_mm, equal_linear
 from .op import style as style_op
 # The style path (26 modulations, 18 demodulation sums per forward pass) as grouped launches over layer-major flat tensors (op/style.py).
@@ -55,10 +55,15 @@ class _StylePlan:
         self.ok = style_op._supported(self.mod_plan) and style_op._supported(self.demod_plan)
         self._idx = {}
 
-    def idx(self, device):
-        t = self._idx.get(device)
+    def selector(self, device, n_latent):
+        """[groups, n_latent] one-hot rows: ``selector @ latents`` is the per-layer gather as ONE GEMM call.  Exact (every product is 1 * x or
+        0 * x) and -- unlike index_select, whose backward scatters with atomics -- deterministic in both directions: the gradient of a
+        latent read by several layers is summed in the GEMM's fixed order."""
+        t = self._idx.get((device, n_latent))
         if t is None:
-            t = self._idx[device] = torch.tensor(self.latent_index, dtype=torch.long, device=device)
+            t = torch.zeros(len(self.latent_index), n_latent, dtype=torch.float32)
+            t[torch.arange(len(self.latent_index)), torch.tensor(self.latent_index)] = 1.0
+            t = self._idx[(device, n_latent)] = t.to(device)
         return t
 # The style path (26 modulation GEMMs, 18 demodulation GEMMs and the elementwise algebra around them: ~150 launches of a few
 # microseconds on [B, 512] tensors per generator pass, three times that in its backward and second-order passes) on a SIDE STREAM:
@@ -479,7 +484,7 @@ class Generator(nn.Module):
         return layers
 
     def _style_path_grouped(self, latent):
-        """(s, d) of every modulated convolution from FIVE launches: gather the latents per layer (index_select), all modulations
+        """(s, d) of every modulated convolution from FIVE launches: gather the latents per layer (a one-hot GEMM), all modulations
         (grouped_linear), square, all demodulation sums (grouped_linear), rsqrt.  Returns ``mods(j)`` as _style_path does, or None when
         the shapes are not the grouped kernels' (style_dim or a channel count not a multiple of 4)."""
         plan = _STYLE_PLANS.get(self)
@@ -488,14 +493,16 @@ class Generator(nn.Module):
         if not plan.ok or latent.dim() != 3 or latent.dtype != torch.float32:
             return None
         b = latent.shape[0]
-        x = latent.transpose(0, 1).index_select(0, plan.idx(latent.device))                    # [groups, B, style_dim]
+        if latent.shape[1] <= max(plan.latent_index):
+            return None
+        x = plan.selector(latent.device, latent.shape[1]) @ latent.transpose(0, 1).reshape(latent.shape[1], -1)      # [groups, B * style_dim]
         s_flat = style_op.grouped_linear(x.reshape(-1), b, plan.mod_plan, [m.modulation.weight for m in plan.layers],
                                          [m.modulation.bias for m in plan.layers])
         s_blocks = style_op.blocks(s_flat, b, plan.s_cols)
         d_blocks = []
         if plan.n_demod:
             u = s_flat[:b * plan.demod_in_cols].square()
-            wsq = [_WeightSq.apply(m.weight.view(m.weight.shape[1:])) for m in plan.layers[:plan.n_demod]]
+            wsq = weight_sq_all([m.weight for m in plan.layers[:plan.n_demod]])
             q = style_op.grouped_linear(u, b, plan.demod_plan, wsq, [_eps_vector(latent, m.out_channel, m.eps) for m in plan.layers[:plan.n_demod]])
             d_blocks = style_op.blocks(q.rsqrt(), b, plan.d_cols)
 

@@ -475,8 +475,30 @@ class HipBackend:
                     g.desc, g.w, g.packed, g.packed_bytes = desc, w_t.data_ptr(), buf.data_ptr(), pbytes
                     outs.append(buf)
                 _lib.check(lib.gc_conv2d_pack_weights_bf16x3_grouped(table, len(items), _lib.stream_of(items[0][0])), 'gc_conv2d_pack_weights_bf16x3_grouped')
+            elif kind == 'wsq':
+                table = (_lib.WsqGroup * len(items))()
+                for g, (w,) in zip(table, items):
+                    _lib.require_cuda_f32(w)
+                    out = torch.empty(w.shape[:2], dtype=w.dtype, device=dev)
+                    g.w, g.g, g.out, g.rows, g.taps = w.data_ptr(), None, out.data_ptr(), w.shape[0] * w.shape[1], w.numel() // (w.shape[0] * w.shape[1])
+                    outs.append(out)
+                _lib.check(lib.gc_weight_sq_grouped_f32(table, len(items), _lib.stream_of(items[0][0])), 'gc_weight_sq_grouped_f32')
             else:
                 raise ValueError(kind)
+        return outs
+
+    def weight_sq_bwd(self, weights, grads):
+        """[2 * w * g[:, :, None, None]] for every (w [N, K, kh, kw], g [N, K]) pair: one launch (gc_weight_sq_bwd_grouped_f32)."""
+        dev = _lib.require_cuda_f32(*weights, *grads)
+        table = (_lib.WsqGroup * len(weights))()
+        outs = []
+        for t, w, g in zip(table, weights, grads):
+            out = torch.empty_like(w)
+            t.w, t.g, t.out, t.rows, t.taps = w.data_ptr(), g.data_ptr(), out.data_ptr(), w.shape[0] * w.shape[1], w.numel() // (w.shape[0] * w.shape[1])
+            outs.append(out)
+        with (self._guard(dev) or contextlib.nullcontext()):
+            rc = _lib.load().gc_weight_sq_bwd_grouped_f32(table, len(weights), _lib.stream_of(weights[0]))
+        _lib.check(rc, 'gc_weight_sq_bwd_grouped_f32')
         return outs
 
     def weight_layout(self, src, taps, k, n, src_stride, dst_shape, dst_stride, flip, scale):

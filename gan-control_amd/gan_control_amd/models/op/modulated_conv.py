@@ -30,6 +30,15 @@ from .weight_layout import kernel_layout
 from .upfirdn2d import upfirdn2d, _dense_or_pitched
 
 
+def _wsq_value(w):
+    """sum over the taps of w^2, [OC, IC]: the backend's kernel (the one the batched refill of weight_cache uses, so that a value does not
+    depend on how it was refilled) or, on a backend without it, ATen."""
+    run = getattr(_backend.get(), 'weight_prep_batch', None)
+    if run is not None and w.is_contiguous():
+        return run('wsq', [(w.detach(),)])[0]
+    return w.detach().pow(2).sum([2, 3])
+
+
 class _WeightSq(Function):
     """[OC, IC, k, k] -> sum over the taps of W^2, [OC, IC].  The value only changes with the weight, so it is computed once per weight
     version (weight_cache) instead of in every forward pass of every iteration phase; the backward is the closed form 2 g W."""
@@ -38,12 +47,42 @@ class _WeightSq(Function):
     def forward(ctx, w):
         from . import weight_cache
         ctx.save_for_backward(w)
-        return weight_cache.derive(w, ('wsq',), lambda: w.detach().pow(2).sum([2, 3])).detach()
+        return weight_cache.derive(w, ('wsq',), lambda: _wsq_value(w), recipe=('wsq',)).detach()
 
     @staticmethod
     def backward(ctx, g):
         w, = ctx.saved_tensors
         return (2.0 * g)[:, :, None, None] * w
+
+
+class _WeightSqAll(Function):
+    """_WeightSq of every demodulated layer at once: the values come out of the cache of derived weight forms (refilled for the whole
+    network by one grouped launch per optimiser step), the gradients 2 g W of all layers are ONE launch (gc_weight_sq_bwd_grouped_f32)
+    instead of two ATen passes per layer.  With grad mode on inside backward (orders above two) the ATen formula runs."""
+
+    @staticmethod
+    def forward(ctx, *ws):
+        from . import weight_cache
+        ctx.save_for_backward(*ws)
+        return tuple(weight_cache.derive(w, ('wsq',), lambda w=w: _wsq_value(w), recipe=('wsq',)).detach() for w in ws)
+
+    @staticmethod
+    def backward(ctx, *gs):
+        ws = ctx.saved_tensors
+        be = _backend.get()
+        if torch.is_grad_enabled() or getattr(be, 'weight_sq_bwd', None) is None or not all(w.is_contiguous() for w in ws):
+            return tuple((2.0 * g)[:, :, None, None] * w if ctx.needs_input_grad[i] else None for i, (g, w) in enumerate(zip(gs, ws)))
+        idx = [i for i in range(len(ws)) if ctx.needs_input_grad[i]]
+        outs = be.weight_sq_bwd([ws[i] for i in idx], [gs[i].contiguous() for i in idx]) if idx else []
+        res = [None] * len(ws)
+        for i, o in zip(idx, outs):
+            res[i] = o
+        return tuple(res)
+
+
+def weight_sq_all(weights):
+    """[sum over the taps of W^2, [OC, IC]] for every [1, OC, IC, k, k] (or [OC, IC, k, k]) weight of the list."""
+    return list(_WeightSqAll.apply(*[w.view(w.shape[-4:]) for w in weights]))
 
 
 def demod_coefficients(weight, s, scale, eps=1e-8):

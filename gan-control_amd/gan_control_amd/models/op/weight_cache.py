@@ -123,7 +123,7 @@ def _refill_group(gid):
         return
     for depth in sorted({t[0] for t in todo}):
         level = [t for t in todo if t[0] == depth]
-        for kind in ('layout', 'pack'):
+        for kind in ('layout', 'pack', 'wsq'):
             items, owners = [], []
             for _, rid, root, key, recipe in level:
                 if recipe[0] != kind:
@@ -157,7 +157,7 @@ def derive(src, op, make, recipe=None):
     long as the root of ``src`` keeps its version.  Returns the cached tensor itself: callers must not modify it, and an
     autograd Function must return an alias (``.detach()``), not this object.
 
-    ``recipe`` = ('layout', taps, k, n, src_stride, dst_shape, dst_stride, flip, scale) | ('pack', conv-desc fields): how the backend's
+    ``recipe`` = ('layout', taps, k, n, src_stride, dst_shape, dst_stride, flip, scale) | ('pack', conv-desc fields) | ('wsq',): how the backend's
     grouped kernels make the same tensor, which lets a miss refill the whole parameter group at once (module docstring)."""
     where = _root_of(src) if ENABLED else None
     if where is None:

@@ -412,6 +412,19 @@ int gc_grouped_linear_f32(const gc_glin_group* groups, int n_groups, int batch, 
 int gc_grouped_linear_bwd_x_f32(const gc_glin_group* groups, int n_groups, int batch, gc_stream_t stream);
 int gc_grouped_linear_bwd_w_f32(const gc_glin_group* groups, int n_groups, int batch, gc_stream_t stream);
 
+/* sum over the taps of W^2 -- the weight half of ModulatedConv2d's demodulation `rsqrt(weight.pow(2).sum([2, 3, 4]) + 1e-8)`
+ * (gan_model.py:289-290), which only changes with the weight -- for many weight tensors in one launch, and its gradient:
+ *   gc_weight_sq_grouped_f32      out[r] = sum_t w[r, t]^2                 r < rows (= out_ch * in_ch), t < taps;   g unused
+ *   gc_weight_sq_bwd_grouped_f32  out[r, t] = 2 * w[r, t] * g[r] */
+typedef struct gc_wsq_group {
+    const float* w;
+    const float* g;
+    float* out;
+    int32_t rows, taps;
+} gc_wsq_group;
+int gc_weight_sq_grouped_f32(const gc_wsq_group* groups, int n_groups, gc_stream_t stream);
+int gc_weight_sq_bwd_grouped_f32(const gc_wsq_group* groups, int n_groups, gc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * f-2  Forward pass of the FID feature network (inference, fp32): src/gan_control/fid_utils/inception.py:17-165 over
  * overwrite_inception.py.  Replaces BasicConv2d.forward (conv -> BatchNorm(eval) -> ReLU, overwrite_inception.py:424-434), the

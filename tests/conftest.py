@@ -226,9 +226,14 @@ class EmulatedBackend:
 
     def weight_prep_batch(self, kind, items):
         """The grouped re-layout (gc_weight_layout_grouped_f32): the same values as one weight_layout call per item."""
+        if kind == 'wsq':
+            return [w.pow(2).sum([2, 3]) for (w,) in items]
         if kind != 'layout':
             raise ValueError(kind)
         return [self.weight_layout(*it) for it in items]
+
+    def weight_sq_bwd(self, weights, grads):
+        return [(2.0 * g)[:, :, None, None] * w for w, g in zip(weights, grads)]
 
     def affine_warp(self, x, mat, in_h, in_w, out_h, out_w, adjoint):
         def fwd(img):
