@@ -29,6 +29,33 @@ int probe_name(const char* fmt, ...) {
     return GC_OK;
 }
 
+size_t device_lds_limit() {
+    static size_t cached[16] = {0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 160 * 1024; }
+    const int slot = dev & 15;
+    if (cached[slot] == 0) {
+        // On AMD parts one workgroup may take the whole LDS of its CU once the kernel asks for it (hipFuncAttributeMaxDynamicSharedMemorySize);
+        // "per block" reports the default static limit (64 KiB), "per multiprocessor" the LDS of a CU (160 KiB on gfx950, 64 KiB before).
+        int per_block = 0, per_cu = 0;
+        if (hipDeviceGetAttribute(&per_block, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) { (void)hipGetLastError(); per_block = 0; }
+        if (hipDeviceGetAttribute(&per_cu, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev) != hipSuccess) { (void)hipGetLastError(); per_cu = 0; }
+        const int v = per_block > per_cu ? per_block : per_cu;
+        cached[slot] = v > 0 ? (size_t)v : (size_t)160 * 1024;
+    }
+    return cached[slot];
+}
+
+int allow_dynamic_lds(const void* kernel, size_t bytes, bool (&done)[16], const char* what) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return fail(GC_ERR_HIP, "%s: no current device", what);
+    if (done[dev & 15]) return GC_OK;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(GC_ERR_HIP, "%s: cannot reserve %zu bytes of LDS: %s", what, bytes, hipGetErrorString(e)); }
+    done[dev & 15] = true;
+    return GC_OK;
+}
+
 }  // namespace gc
 
 extern "C" int gc_conv2d_variant_name(const gc_conv_desc* d, int mode, char* name, int name_bytes) {

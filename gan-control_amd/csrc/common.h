@@ -25,6 +25,12 @@ inline int check_launch(const char* what) {
     return GC_OK;
 }
 
+// Per-block LDS limit of the CURRENT device in bytes (hipDeviceAttributeMaxSharedMemoryPerBlock, cached per device); 160 KiB -- the gfx950
+// figure -- where no device can be asked (the build container's no-launch probes and workspace queries).
+size_t device_lds_limit();
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per (kernel, device); GC_OK or GC_ERR_HIP.
+int allow_dynamic_lds(const void* kernel, size_t bytes, bool (&done)[16], const char* what);
+
 inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 

@@ -711,7 +711,8 @@ inline size_t small_lds_bytes(const gc_conv_desc* d, int nch) {
     const size_t plane = (size_t)(d->in_h + 2 * d->pad_y) * (d->in_w + 2 * d->pad_x);
     return ((size_t)d->kh * d->kw * SMALL_KC * 64 + (size_t)nch * SMALL_KC * ((size_t)d->batch * plane + 1)) * sizeof(float);
 }
-constexpr size_t SMALL_LDS_MAX = 160 * 1024;
+// what one workgroup may use: the device's per-block limit (160 KiB on gfx950; a part with less sends these shapes to conv_mfma_kernel's split over K)
+inline size_t small_lds_max() { return std::min<size_t>(160 * 1024, gc::device_lds_limit()); }
 
 // shapes the small-plane kernel takes: 1x1 / 3x3 taps at stride 1 with "same" padding or at stride 2 without padding, >= 64 input and
 // output channels (any count), output planes <= 8 x 8 with at most 512 pixels over all samples, dense rows, and a patch that fits the
@@ -728,12 +729,12 @@ inline bool small_eligible(const gc_conv_desc* d) {
     if (d->in_ch < 64 || d->out_ch < 64) return false;
     if (d->out_w > 8 || d->out_h > 8) return false;
     const long long pixels = (long long)d->batch * d->out_h * d->out_w;
-    return pixels >= 1 && pixels <= 512 && small_lds_bytes(d, 1) <= SMALL_LDS_MAX;
+    return pixels >= 1 && pixels <= 512 && small_lds_bytes(d, 1) <= small_lds_max();
 }
 
 // channel chunks per workgroup: two (32 channels x 32 output channels) when the partial sums of 16-channel slices would outweigh the weights
 inline int small_chunks(const gc_conv_desc* d) {
-    if (d->in_ch % (2 * SMALL_KC) != 0 || small_lds_bytes(d, 2) > SMALL_LDS_MAX) return 1;
+    if (d->in_ch % (2 * SMALL_KC) != 0 || small_lds_bytes(d, 2) > small_lds_max()) return 1;
 #ifdef GC_SMALL_NCH
     return GC_SMALL_NCH;
 #endif
@@ -746,12 +747,12 @@ template <int KS, int DOWN>
 int launch_small(const gc_conv_desc* d, const SmallArgs& sa, hipStream_t s) {
     const size_t lds = small_lds_bytes(d, small_chunks(d));
     if (small_chunks(d) == 2) {
-        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 1, 2, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)attr;
+        static bool done[16] = {false};
+        if (int rc = gc::allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 1, 2, DOWN>), small_lds_max(), done, "gc_conv2d_f32(small planes)")) return rc;
         hipLaunchKernelGGL((conv_f32_small_kernel<KS, 1, 2, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 32)), dim3(SMALL_THREADS), lds, s, sa);
     } else {
-        static bool attr = ((void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 2, 1, DOWN>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
-        (void)attr;
+        static bool done[16] = {false};
+        if (int rc = gc::allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 2, 1, DOWN>), small_lds_max(), done, "gc_conv2d_f32(small planes)")) return rc;
         hipLaunchKernelGGL((conv_f32_small_kernel<KS, 2, 1, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 64)), dim3(SMALL_THREADS), lds, s, sa);
     }
     return gc::check_launch("gc_conv2d_f32(small planes)");

@@ -162,7 +162,9 @@ def row_pitch(t):
         return 0
     b, c, h, w = t.shape
     sb, sc, sh, sw = t.stride()
-    if sw == 1 and sh > w and sc == h * sh and sb == c * sc:
+    # the kernels read such a tensor in place only when it is what they write themselves: rows a multiple of 32 floats apart, 16-byte
+    # aligned -- an arbitrary column slice x[..., a:b] of a user tensor has the same stride pattern and must be copied instead
+    if sw == 1 and sh > w and sc == h * sh and sb == c * sc and sh % 32 == 0 and t.data_ptr() % 16 == 0:
         return sh
     return 0
 

@@ -583,7 +583,8 @@ class ConvLayer(nn.Sequential):
         out, idx = input, 0
         if self._has_blur:
             blur, idx = self[0], 1
-            out = upfirdn2d(out, blur.kernel, down=2, pad=blur.pad) if self._decimating_fir else blur(out)
+            # the (H + 1)-wide Blur output goes straight into this layer's stride-2 convolution, which reads a row pitch
+            out = upfirdn2d(out, blur.kernel, down=2, pad=blur.pad) if self._decimating_fir else upfirdn2d(out, blur.kernel, pad=blur.pad, _internal=True)
         conv = self[idx]
         stride = 1 if self._decimating_fir else conv.stride
         if fork and not (self._activate and _FUSE_EPILOGUE and not self._has_blur):

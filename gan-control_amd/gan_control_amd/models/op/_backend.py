@@ -60,6 +60,29 @@ def strict_zeros():
     return _STRICT_ZERO[0]
 
 
+# Row-pitched OUTPUTS (the aligned-row layout of the odd-width intermediates) are an internal optimisation: a tensor
+# handed to a caller outside this package must be an ordinary dense tensor (reference-style code calls .view() on it).  The public
+# entry points (upfirdn2d, conv_transpose2d) therefore run with the layout switched off unless the call comes from a module of this
+# package whose consumer reads the pitch (`_internal=True`); backward passes, whose tensors only travel between autograd nodes, keep it.
+_PITCH_ALLOWED = [True]
+
+
+class pitched_outputs:
+    def __init__(self, allowed):
+        self.allowed = bool(allowed)
+
+    def __enter__(self):
+        self.prev = _PITCH_ALLOWED[0]
+        _PITCH_ALLOWED[0] = self.allowed
+
+    def __exit__(self, *exc):
+        _PITCH_ALLOWED[0] = self.prev
+
+
+def pitch_allowed():
+    return _PITCHED_OUTPUT and _PITCH_ALLOWED[0]
+
+
 # Geometry of the generalised convolution (gc_conv_desc minus batch/channels/in-size, which come from tensors)
 ConvGeom = namedtuple('ConvGeom', 'kh kw up down pad_y pad_x out_h out_w')
 
@@ -86,7 +109,7 @@ class HipBackend:
             if self._pitched_fir_ok(x, taps, up, down, out_h, out_w):
                 return self.upfirdn2d_act(x, taps, pad_x0, pad_y0, out_h, out_w, flip, None, None, None, 1.0, 1.0, activate=False)
             x = x.contiguous()
-        elif (_PITCHED_OUTPUT and out_w % 4 != 0 and out_w >= 129 and self.conv_mode != 'f32'
+        elif (pitch_allowed() and out_w % 4 != 0 and out_w >= 129 and self.conv_mode != 'f32'
               and self.upfirdn2d_act_supported(taps, up, down, out_h, out_w, x.shape[0] * x.shape[1])):
             # the (H + 1)-wide output of the Blur in front of a stride-2 convolution (and of the Blur adjoint in G): aligned rows for its
             # 16-byte stores (4.4 -> 5.6 TB/s); the stride-2 kernels read the pitch (gc_conv_desc.in_pitch)
@@ -602,7 +625,7 @@ class HipBackend:
         # (64 -> 32 @512^2: 365 us, 240 us with aligned rows): where the library says so the output is written with a row pitch that is
         # a multiple of 32 floats and handed on as a strided view; its consumers (the Blur that follows, the plane reductions) read the
         # pitch, anything else makes it contiguous.
-        pitch = lib.gc_conv2d_out_pitch(desc, {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(self.conv_mode, 0)) if (geom.up == 2 and x.shape[0] > 0 and _PITCHED_OUTPUT) else 0
+        pitch = lib.gc_conv2d_out_pitch(desc, {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(self.conv_mode, 0)) if (geom.up == 2 and x.shape[0] > 0 and pitch_allowed()) else 0
         if pitch:
             desc.out_pitch = pitch
             y = torch.empty((x.shape[0], n_out, geom.out_h, pitch), dtype=x.dtype, device=dev)[..., :geom.out_w]

@@ -199,5 +199,6 @@ def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_paddi
         raise ValueError('conv_transpose2d: output_padding is not implemented on the HIP path')
     if weight.shape[0] != input.shape[1]:
         raise ValueError(f'conv_transpose2d: weight expects {weight.shape[0]} input channels, got {input.shape[1]}')
-    y = conv_transpose2d_t(input, kernel_layout(weight, weight_scale, flip=True, in_major=True), s, p)
+    with _backend.pitched_outputs(False):         # a public result: dense rows (the row-pitched layout stays inside this package)
+        y = conv_transpose2d_t(input, kernel_layout(weight, weight_scale, flip=True, in_major=True), s, p)
     return y if bias is None else y + bias.reshape(1, -1, 1, 1)

@@ -344,7 +344,8 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
         w_t = kernel_layout(weight.view(oc, ic, k, k), scale, flip=True)                   # correlation form, [k,k,IC,OC]
         oh, ow = (x.shape[2] - 1) * 2 + k, (x.shape[3] - 1) * 2 + k
         y = _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 2, 1, k - 1, k - 1, oh, ow))
-        return upfirdn2d(y, blur_kernel, pad=blur_pad) if apply_blur else y     # apply_blur=False: the caller fuses the Blur with what follows
+        # apply_blur=False (StyledConv): the caller fuses the Blur with what follows and reads the (possibly row-pitched) tensor in place
+        return upfirdn2d(y, blur_kernel, pad=blur_pad) if apply_blur else y
     pad = k // 2 if padding is None else padding
     w_t = kernel_layout(weight.view(oc, ic, k, k), scale)
     oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1

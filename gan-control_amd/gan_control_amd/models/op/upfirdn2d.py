@@ -59,8 +59,13 @@ class _UpFirDn2dAdjoint(Function):
         return ggy, None, None
 
 
-def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0)):
-    return _UpFirDn2d.apply(input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
+def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0), _internal=False):
+    """The reference's socket signature.  ``_internal`` (modules of this package whose consumer reads a row pitch) lets the odd-width
+    output of a Blur come back as a row-pitched view; every other caller gets an ordinary dense tensor."""
+    if _internal:
+        return _UpFirDn2d.apply(input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
+    with _backend.pitched_outputs(False):
+        return _UpFirDn2d.apply(input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
 
 
 class _UpFirDn2dAct(Function):

@@ -707,9 +707,24 @@ def test_row_pitched_fir_and_plane_dot(shape):
         y = torch.randn(shape, generator=gen).to(DEV)
         den = (torch.rand(b, c, generator=gen) + 0.5).to(DEV)
         ref = (x.double() * y.double()).sum((2, 3))
-        for a_, b_ in ((xp, y), (x, _pitched(y, w + 7)), (xp, _pitched(y, w + 40))):
+        p32 = (w + 31) // 32 * 32
+        for a_, b_ in ((xp, y), (x, _pitched(y, p32)), (xp, _pitched(y, p32 + 64))):
             assert rel_err(hip.plane_dot(a_, b_), ref) < 1e-5
             assert rel_err(hip.plane_dot(a_, b_, den), ref / den.double()) < 1e-5
+        # only the layout the kernels write themselves is read in place (rows a multiple of 32 floats apart, 16-byte aligned): a column
+        # slice of a user tensor has the same stride pattern and must be treated as an ordinary non-contiguous tensor
+        assert not _lib.row_pitch(_pitched(y, w + 7)) and not _lib.row_pitch(torch.randn(b, c, h, p32 + 32, device=DEV)[..., 1:w + 1])
+        from gan_control_amd.models.op import upfirdn2d, conv2d_gradfix
+        sliced = torch.randn(b, c, h, p32 + 32, device=DEV)[..., 1:w + 1]
+        assert torch.equal(upfirdn2d(sliced, k4, pad=(1, 1)), upfirdn2d(sliced.contiguous(), k4, pad=(1, 1)))
+        # public results are dense tensors (the reference's callers use .view()): the row-pitched layout stays inside the package
+        if (w + 1) % 4 and w + 1 >= 129:
+            pub = upfirdn2d(x, k4, pad=(2, 2))
+            assert pub.is_contiguous() and pub.view(-1).numel() == pub.numel()
+            assert _lib.row_pitch(upfirdn2d(x, k4, pad=(2, 2), _internal=True))
+            wt = torch.randn(c, 64, 3, 3, generator=gen).to(DEV)
+            if c >= 16:
+                assert conv2d_gradfix.conv_transpose2d(x, wt, stride=2).is_contiguous()
     finally:
         hip.conv_mode = prev
 
