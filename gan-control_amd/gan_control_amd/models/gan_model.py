@@ -65,21 +65,6 @@ class _StylePlan:
             t[torch.arange(len(self.latent_index)), torch.tensor(self.latent_index)] = 1.0
             t = self._idx[(device, n_latent)] = t.to(device)
         return t
-# The style path (26 modulation GEMMs, 18 demodulation GEMMs and the elementwise algebra around them: ~150 launches of a few
-# microseconds on [B, 512] tensors per generator pass, three times that in its backward and second-order passes) on a SIDE STREAM:
-# it depends on the latents and the weights only, so it runs next to the convolutions instead of between them.  Autograd runs
-# every backward node on the stream of its forward, so the backward and double-backward of the path overlap in the same way.
-_STYLE_STREAM = os.environ.get('GANCONTROL_STYLE_STREAM', '0') == '1'     # measured: no gain while the launch path is the bottleneck
-_side_streams = {}
-
-
-def style_stream(device):
-    """The side stream of the style path on ``device`` (one per device, created on first use)."""
-    st = _side_streams.get(device)
-    if st is None:
-        st = _side_streams[device] = torch.cuda.Stream(device=device)
-    return st
-
 CHANNELS = {4: 512, 8: 512, 16: 512, 32: 512}
 
 
@@ -512,35 +497,11 @@ class Generator(nn.Module):
         return mods
 
     def _style_path(self, lat):
-        """(s, d) of every modulated convolution in execution order -- conv1, to_rgb1, then (up-sampling conv, conv, to_rgb) per
-        resolution -- computed ahead of the image path on the side stream.  Returns ``mods(j)``: the pair of layer j, after making the
-        current stream wait for it."""
-        layers = self._style_layers()
-        dev = lat[0].device
-        if not (_STYLE_STREAM and dev.type == 'cuda'):
-            pairs = [m.styles(lat[i]) for m, i in layers]
-            return lambda j: pairs[j]
-        main, side = torch.cuda.current_stream(dev), style_stream(dev)
-        if side == main:
-            pairs = [m.styles(lat[i]) for m, i in layers]
-            return lambda j: pairs[j]
-        side.wait_stream(main)                       # the latents (and the last weight update) are ready
-        pairs, events = [], []
-        with torch.cuda.stream(side):
-            for m, i in layers:
-                s, d = m.styles(lat[i])
-                for t in (s, d):
-                    if t is not None:
-                        t.record_stream(main)        # consumed by convolution launches on the main stream
-                ev = torch.cuda.Event()
-                ev.record(side)
-                pairs.append((s, d))
-                events.append(ev)
-
-        def mods(j):
-            torch.cuda.current_stream(dev).wait_event(events[j])
-            return pairs[j]
-        return mods
+        """(s, d) of every modulated convolution in execution order, one GEMM call per layer (GANCONTROL_FUSED_STYLE=0, and shapes the grouped
+        kernels do not take).  Returns ``mods(j)``: the pair of layer j.  (Round 2 also ran this on a side stream; measured no gain
+        -- DESIGN.md section 6 -- and removed in round 3 together with its stream-safety caveats.)"""
+        pairs = [m.styles(lat[i]) for m, i in self._style_layers()]
+        return lambda j: pairs[j]
 
     @staticmethod
     def g_path_regularize_grad(fake_img, latents, dim_1_shape=1, pl_noise=None):

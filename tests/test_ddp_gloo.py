@@ -145,15 +145,16 @@ def _inputs():
                 n_g=oc.seeded_noise(SIZE, GLOBAL_B, 2), n_pl=oc.seeded_noise(SIZE, GLOBAL_B // 2, 3))
 
 
-def _run_iteration(rank, world):
+def _run_iteration(rank, world, device='cpu'):
     import step_checks
     from gan_control_amd.models.op import _backend
     from gan_control_amd.trainers.utils import requires_grad, accumulate
-    _backend._install_for_tests(EmulatedBackend())
-    tr = step_checks.make_trainer('cpu', size=SIZE, batch=GLOBAL_B)
+    if device == 'cpu':
+        _backend._install_for_tests(EmulatedBackend())
+    tr = step_checks.make_trainer(device, size=SIZE, batch=GLOBAL_B)
     assert tr.local_batch == GLOBAL_B // world
     inp = _inputs()
-    sh = lambda t: t[rank::world].contiguous()            # strided shard keeps the stddev groups of the 1-rank run
+    sh = lambda t: t[rank::world].contiguous().to(device)            # strided shard keeps the stddev groups of the 1-rank run
     shl = lambda maps: [sh(m) for m in maps]
     requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
     tr.discriminator_step([[sh(inp['z_d'])]], [sh(inp['real'])], noise=shl(inp['n_d']))
@@ -168,11 +169,11 @@ def _run_iteration(rank, world):
     return state
 
 
-def _trainer_worker(rank, world, port, out):
+def _trainer_worker(rank, world, port, out, device='cpu'):
     _setup(rank, world, port)
-    state = _run_iteration(rank, world)
+    state = _run_iteration(rank, world, device)
     # every rank draws its own noise from the global generators (NoiseInjection, path-length noise, ADA transforms) ...
-    draw = torch.randn(16)
+    draw = torch.randn(16, device=device).cpu()
     both = [torch.empty(16) for _ in range(world)]
     dist.all_gather(both, draw)
     assert not torch.equal(both[0], both[1]), 'ranks share the global RNG stream: the global batch would see identical injected noise'
@@ -182,7 +183,7 @@ def _trainer_worker(rank, world, port, out):
         dist.broadcast(ref, 0)
         assert torch.equal(ref, v.detach()), k
     if rank == 0:
-        torch.save({'g': {k: v.detach() for k, v in state['g'].items()}, 'd': {k: v.detach() for k, v in state['d'].items()},
+        torch.save({'g': {k: v.detach().cpu() for k, v in state['g'].items()}, 'd': {k: v.detach().cpu() for k, v in state['d'].items()},
                     'mean_path_length': state['mean_path_length'], 'd_loss': state['d_loss']}, out)
     dist.destroy_process_group()
 
@@ -208,3 +209,34 @@ def test_two_ranks_equal_one_rank():
             big += int((diff > 1e-3).sum()); n += diff.numel()
     # Adam's first steps are sign-like: identical up to fp32 summation order except where a gradient is ~0
     assert big <= n * 1e-3, (big, n, worst)
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_the_gpu_equal_one_rank():
+    """The same 2 x 4 == 1 x 8 iteration with BOTH ranks on the HIP kernels of one MI355X (two processes sharing cuda:0; gloo moves the
+    gradients, since RCCL refuses two ranks on one device): the bucketed reducer launching from autograd hooks next to real kernels, the
+    flat-buffer gradient views under a device optimiser, per-rank device RNG, bit-identical replicas.  What is left for the 8-GPU node is
+    RCCL itself."""
+    from gan_control_amd.models.op import _backend
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    port = 33500 + os.getpid() % 2000
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    hip = _backend.get()
+    assert hip.name == 'hip'
+    prev, hip.conv_mode = hip.conv_mode, 'f32'
+    try:
+        with tempfile.TemporaryDirectory() as tmp:
+            out = os.path.join(tmp, 's.pt')
+            mp.spawn(_trainer_worker, args=(2, port, out, 'cuda'), nprocs=2, join=True)
+            two = torch.load(out)
+        one = _run_iteration(0, 1, 'cuda')
+    finally:
+        hip.conv_mode = prev
+    assert abs(two['mean_path_length'] - one['mean_path_length']) < 1e-4 * max(1, abs(one['mean_path_length']))
+    assert abs(two['d_loss'] - one['d_loss']) < 1e-5
+    big, n = 0, 0
+    for tag in ('g', 'd'):
+        for k, v in one[tag].items():
+            diff = (two[tag][k] - v.detach().cpu()).abs()
+            big += int((diff > 1e-3).sum()); n += diff.numel()
+    assert big <= n * 1e-3, (big, n)
