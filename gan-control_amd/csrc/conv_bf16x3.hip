@@ -1350,6 +1350,8 @@ WgPlan plan_wg(const gc_conv_desc* d) {
     pl.small = d->down == 1 && !(d->in_ch >= 64 && d->out_ch >= 64);
     pl.ct = pl.small ? 32 : 64;
     pl.kt = (d->down == 2 && d->in_ch < 64) ? 32 : pl.ct;      // stride 2 with 32..63 input channels: 32k x 64n tiles
+    // (round 3: THREE rows for the 64 x 64 tiles -- 162 MFMAs per wave between barriers, 78 KB of LDS, still two workgroups per CU -- measured
+    // 15-26 % SLOWER: 64 -> 64 @512^2, B = 8: 557 -> 748 us; 512 -> 512 @64^2: 470 -> 543 us: the two extra staging register sets spill 108 bytes per lane)
     pl.tr = pl.small ? 6 : 2;          // 32 x 32 channel tiles: six rows (81 MFMAs per wave between barriers, 65 KB of LDS; four rows: 923 vs 880 us at 32 -> 32 @1024^2)
     if (d->down == 2 && pl.kt == 64) pl.tr = 1;     // stride 2, 64k x 64n: one output row per tile keeps two workgroups per CU (two-row tiles need 110 KB of LDS: 130 vs 171 TFLOP/s)     // stride 2, small planes: one output row per tile, two workgroups per CU
     pl.tiles_x = gc::ceil_div(d->out_w, 32);
