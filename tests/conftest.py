@@ -19,6 +19,10 @@ for p in (REPO, os.path.join(REPO, 'gan-control_amd')):
 
 GOLDEN = os.path.join(REPO, 'tests', 'golden')
 
+# The oracle legs of the tests run on the host.  On a 256-thread GPU box PyTorch's default (one intra-op thread per hardware thread) makes
+# the oracle's many small convolutions up to 60 x slower than 16 - 32 threads do (profiles/cpu_threads_r03.json): cap it.
+torch.set_num_threads(max(1, min(torch.get_num_threads(), 32)))
+
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

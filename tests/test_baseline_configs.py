@@ -99,7 +99,6 @@ def test_augment_1024_against_the_oracle_in_float64():
     x = img.to(DEV).requires_grad_(True)
     out, _ = nl.augment(x, 0.6, (G, C))
     gi, = autograd.grad(out, x, go.to(DEV))
-    torch.set_num_threads(8)
     xr = img.double().requires_grad_(True)
     ref = oaug.augment(xr, G.double(), C.double(), nl.SYM6)
     gr, = autograd.grad(ref, xr, go.double())
