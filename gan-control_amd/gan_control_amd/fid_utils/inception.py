@@ -11,10 +11,19 @@ The pretrained weights are a download the reference makes at construction (FID_W
 touches the network: ``load_fid_weights`` takes the state dict of that checkpoint (key names of the un-wrapped Inception3).
 Inference only: BatchNorm uses its running statistics, and the module refuses training mode.
 """
+import os
+
 import torch
 from torch import nn
 
 from ..models.op import _backend
+from ..models.op._backend import ConvGeom
+
+# Round 3: the 1 x 1 and 3 x 3 layers (64 % of the network's multiply-adds) run on the MFMA convolution kernels of the training path
+# (gc_conv2d_fused_*: split-bf16 products, fp32 accumulate, ~5e-6 per layer) with the folded BatchNorm scale in the weights and
+# shift + ReLU in the fused epilogue (slope 0, gain 1); 5 x 5, 1 x 7 / 7 x 1 and 1 x 3 / 3 x 1 stay on gc_conv2d_bn_relu_f32.
+# GANCONTROL_INCEPTION_MFMA=0: every layer on the direct kernel, as in round 2.
+_MFMA = os.environ.get('GANCONTROL_INCEPTION_MFMA', '1') != '0'
 
 FID_WEIGHTS_URL = 'https://github.com/mseitzer/pytorch-fid/releases/download/fid_weights/pt_inception-2015-12-05-6726825d.pth'
 
@@ -28,6 +37,7 @@ class BasicConv2d(nn.Module):
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding, bias=False)
         self.bn = nn.BatchNorm2d(out_channels, eps=0.001)
         self._folded = None
+        self._mfma = None
 
     def _scale_shift(self):
         bn = self.bn
@@ -37,11 +47,44 @@ class BasicConv2d(nn.Module):
             self._folded = (key, scale.contiguous(), (bn.bias.detach() - bn.running_mean * scale).contiguous())
         return self._folded[1], self._folded[2]
 
+    def _mfma_ok(self, x):
+        conv = self.conv
+        kh, kw = conv.kernel_size
+        be = _backend.get()
+        return (_MFMA and x.is_cuda and getattr(be, 'name', '') == 'hip' and kh == kw and kh in (1, 3) and conv.stride[0] == conv.stride[1]
+                and conv.stride[0] in (1, 2) and conv.padding[0] == conv.padding[1] and conv.in_channels >= 16 and conv.out_channels >= 16)
+
+    def _mfma_weight(self, scale):
+        """[kh, kw, K, N] kernel-layout weights with the BatchNorm scale folded in (a frozen Parameter registered with the cache of derived
+        weight forms, so the hi / lo packs are made once); rebuilt when the convolution weight or the statistics change."""
+        from ..models.op import weight_cache
+        w = self.conv.weight
+        key = (self._folded[0], w._version, w.data_ptr())
+        if self._mfma is None or self._mfma[0] != key:
+            w_t = (w.detach() * scale.reshape(-1, 1, 1, 1)).permute(2, 3, 1, 0).contiguous()
+            w_t = nn.Parameter(w_t, requires_grad=False)
+            weight_cache.register(w_t)
+            self._mfma = (key, w_t)
+        return self._mfma[1]
+
     def forward(self, x, out=None, chan_off=0):
         if self.training:
             raise NotImplementedError('BasicConv2d: inference only (BatchNorm running statistics); call .eval()')
         scale, shift = self._scale_shift()
         conv = self.conv
+        if self._mfma_ok(x):
+            be = _backend.get()
+            k, s, p = conv.kernel_size[0], conv.stride[0], conv.padding[0]
+            oh, ow = (x.shape[2] + 2 * p - k) // s + 1, (x.shape[3] + 2 * p - k) // s + 1
+            prev, be.conv_mode = be.conv_mode, 'bf16x3'
+            try:
+                y = be.conv2d(x.contiguous(), self._mfma_weight(scale), None, None, ConvGeom(k, k, 1, s, p, p, oh, ow), epilogue=(shift, None, None, 0.0, 1.0, True))
+            finally:
+                be.conv_mode = prev
+            if out is None:
+                return y
+            out[:, chan_off:chan_off + y.shape[1]].copy_(y)
+            return out
         return _backend.get().conv2d_bn_relu(x, conv.weight.detach(), scale, shift, conv.stride[0], conv.padding[0], conv.padding[1], True, out, chan_off)
 
 
