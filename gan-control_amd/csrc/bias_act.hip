@@ -285,7 +285,19 @@ __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restric
     const float* xp = x + (size_t)plane * inner;
     const int64_t lo = (int64_t)j * chunk_len, hi = min(inner, lo + chunk_len);
     float acc = 0.f;
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += xp[i];
+    if (((inner | lo | hi) & 3) == 0 && (reinterpret_cast<uintptr_t>(xp) & 15) == 0) {
+        // 16-byte loads, four independent partial sums per lane (a single dependent chain of dword loads reached 3.7 TB/s; fixed order)
+        const float4* x4 = reinterpret_cast<const float4*>(xp);
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll 4
+        for (int64_t i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
+            const float4 v = x4[i];
+            a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+        }
+        acc = (a0 + a1) + (a2 + a3);
+    } else {
+        for (int64_t i = lo + threadIdx.x; i < hi; i += 256) acc += xp[i];
+    }
     const float r = block_sum(acc, lds);
     if (threadIdx.x == 0) partial[((size_t)c * batch + b) * chunks + j] = r;
 }

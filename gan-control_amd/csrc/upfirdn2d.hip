@@ -24,6 +24,9 @@ constexpr int PITCH = 132;                // patch row pitch in floats (multiple
 struct FirEpilogue {
     const float* bias; const float* noise; const float* noise_w;
     float slope, gain; int channels;
+    // EPI = 2 (gc_upfirdn2d_mask_f32): y = FIR(x) * (mask_ref > 0 ? mpos : mneg), mask_ref shaped like the output (dense rows) -- the Blur
+    // adjoint followed by the activation backward of the layer whose output the Blur read (ResBlock conv1, gan_model.py:893-922)
+    const float* mask_ref; float mpos, mneg;
 };
 
 // GC_FIR_NT vertically consecutive tiles per workgroup in one software pipeline (the 16-byte loads of tile t + 1 issued before the
@@ -35,7 +38,7 @@ struct FirEpilogue {
 #define GC_FIR_NT 1
 #endif
 
-template <bool VEC, bool EPI>
+template <bool VEC, int EPI>
 __global__ __launch_bounds__(256) void fir44_tile_kernel(
     const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
     int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip, FirEpilogue ep, int in_pitch, int out_pitch) {
@@ -128,7 +131,28 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
             }
         }
 
-        if (EPI) {
+        if (EPI == 2) {
+            // the activation output the mask comes from: all 16 values of the micro-tile are fetched before the first store
+            const float* ref = ep.mask_ref + plane * (size_t)out_h * out_w;
+            float m[4][4];
+            const bool vec_ref = VEC && (out_w & 3) == 0 && ((reinterpret_cast<uintptr_t>(ref) & 15) == 0);      // dense rows of the activation output: 16-byte loads
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int oy = oy0 + rg * 4 + r;
+                if (vec_ref && oy < out_h && ox + 3 < out_w) {
+                    const float4 t = *reinterpret_cast<const float4*>(ref + (size_t)oy * out_w + ox);
+                    m[r][0] = t.x; m[r][1] = t.y; m[r][2] = t.z; m[r][3] = t.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) m[r][j] = (oy < out_h && ox + j < out_w) ? ref[(size_t)oy * out_w + ox + j] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[r][j] *= m[r][j] > 0.f ? ep.mpos : ep.mneg;
+        }
+        if (EPI == 1) {
             // every noise value of the micro-tile is fetched before the first store (a load between stores costs a full
             // memory round trip: vmcnt counts the stores too)
             const int c = (int)(plane % ep.channels);
@@ -544,10 +568,11 @@ int upfirdn2d_impl(const float* x, const float* taps, float* y,
     if (fast) {
         dim3 grid(gc::ceil_div(out_w, TW), gc::ceil_div(gc::ceil_div(out_h, TH), GC_FIR_NT), planes);
         const bool vec = (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);      // rows start on 16-byte boundaries
-        const FirEpilogue none{nullptr, nullptr, nullptr, 1.f, 1.f, 1};
+        const FirEpilogue none{nullptr, nullptr, nullptr, 1.f, 1.f, 1, nullptr, 1.f, 1.f};
 #define GC_FIR(V, E) hipLaunchKernelGGL((fir44_tile_kernel<V, E>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, ep ? *ep : none, in_pitch, out_pitch)
-        if (ep) { if (vec) GC_FIR(true, true); else GC_FIR(false, true); }
-        else    { if (vec) GC_FIR(true, false); else GC_FIR(false, false); }
+        if (ep && ep->mask_ref) { if (vec) GC_FIR(true, 2); else GC_FIR(false, 2); }
+        else if (ep) { if (vec) GC_FIR(true, 1); else GC_FIR(false, 1); }
+        else    { if (vec) GC_FIR(true, 0); else GC_FIR(false, 0); }
 #undef GC_FIR
         return gc::check_launch("gc_upfirdn2d_f32(fir44_tile)");
     }
@@ -605,8 +630,17 @@ extern "C" int gc_upfirdn2d_pitched_f32(const float* x, const float* taps, float
     if ((noise == nullptr) != (noise_w == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_pitched_f32: noise and noise_w must both be set or both be null");
     if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_pitched_f32: bad batch / channels");
     const bool epi = activate || bias || noise;
-    const FirEpilogue ep{bias, noise, noise_w, activate ? slope : 1.f, activate ? gain : 1.f, channels};
+    const FirEpilogue ep{bias, noise, noise_w, activate ? slope : 1.f, activate ? gain : 1.f, channels, nullptr, 1.f, 1.f};
     return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, epi ? &ep : nullptr, stream, in_pitch, out_pitch);
+}
+
+extern "C" int gc_upfirdn2d_mask_f32(const float* x, const float* taps, float* y, int batch, int channels, int in_h, int in_w, int in_pitch,
+                                     int out_h, int out_w, int kh, int kw, int pad_x0, int pad_y0, int flip_taps,
+                                     const float* mask_ref, float slope, float gain, gc_stream_t stream) {
+    if (!mask_ref) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_mask_f32: null mask reference");
+    if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_mask_f32: bad batch / channels");
+    const FirEpilogue ep{nullptr, nullptr, nullptr, 1.f, 1.f, channels, mask_ref, gain, gain * slope};
+    return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, &ep, stream, in_pitch, 0);
 }
 
 extern "C" int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,
@@ -616,6 +650,6 @@ extern "C" int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,
                                     gc_stream_t stream) {
     if ((noise == nullptr) != (noise_w == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_act_f32: noise and noise_w must both be set or both be null");
     if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_act_f32: bad batch / channels");
-    const FirEpilogue ep{bias, noise, noise_w, slope, gain, channels};
+    const FirEpilogue ep{bias, noise, noise_w, slope, gain, channels, nullptr, 1.f, 1.f};
     return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, &ep, stream);
 }

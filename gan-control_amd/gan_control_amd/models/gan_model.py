@@ -18,10 +18,12 @@ from torch.nn import functional as F
 
 import os
 _FUSE_EPILOGUE = os.environ.get('GANCONTROL_FUSE_EPILOGUE', '1') != '0'   # debugging knob: 0 = convolution and activation as two launches
+_FUSE_BLUR_ADJ = os.environ.get('GANCONTROL_FUSE_BLUR_ADJOINT', '1') != '0'   # ResBlock: Blur adjoint + conv1's activation backward in one pass over the gradient
 _FORK_TORGB = os.environ.get('GANCONTROL_FORK_TORGB', '0') == '1'         # off by default: measured -0.3 % (the in_scale gradient then needs gx - gfork, a pass of its own)
 from .op import _backend
 from .op import (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, upfirdn2d_bias_act, conv2d_gradfix, modulated_conv2d,
                  modulated_conv2d_act)
+from .op.upfirdn2d import blur_of_activation
 from .op.modulated_conv import demod_coefficients, weight_sq_all, _eps_vector
 from .op.linear import scaled_mm, equal_linear
 from .op import style as style_op
@@ -536,8 +538,10 @@ class ConvLayer(nn.Sequential):
         self._decimating_fir = downsample and kernel_size == 1
         self._has_blur, self._activate = downsample, activate
 
-    def forward(self, input, out_gain=1.0, residual=None, fork=False):
-        """out_gain multiplies the layer's output; it is folded into the activation gain / the weight scale (no extra pass).
+    def forward(self, input, out_gain=1.0, residual=None, fork=False, grad_premasked=False, input_act=None):
+        """grad_premasked / input_act: the two ends of ResBlock's conv1 -> Blur pairing (op/upfirdn2d.py::_BlurOfActivation): conv1 is
+        called with grad_premasked=True, conv2 with input_act=(negative_slope, gain) of conv1's activation.
+        out_gain multiplies the layer's output; it is folded into the activation gain / the weight scale (no extra pass).
         residual (activation-free layers) is added in the convolution's epilogue.  fork=True returns (out, input') where
         input' is the input for its second consumer: that consumer's gradient is then added inside this layer's
         input-gradient convolution instead of by a separate elementwise pass."""
@@ -545,7 +549,13 @@ class ConvLayer(nn.Sequential):
         if self._has_blur:
             blur, idx = self[0], 1
             # the (H + 1)-wide Blur output goes straight into this layer's stride-2 convolution, which reads a row pitch
-            out = upfirdn2d(out, blur.kernel, down=2, pad=blur.pad) if self._decimating_fir else upfirdn2d(out, blur.kernel, pad=blur.pad, _internal=True)
+            if self._decimating_fir:
+                out = upfirdn2d(out, blur.kernel, down=2, pad=blur.pad)
+            elif input_act is not None:
+                with _backend.pitched_outputs(True):
+                    out = blur_of_activation(out, blur.kernel, blur.pad, *input_act)
+            else:
+                out = upfirdn2d(out, blur.kernel, pad=blur.pad, _internal=True)
         conv = self[idx]
         stride = 1 if self._decimating_fir else conv.stride
         if fork and not (self._activate and _FUSE_EPILOGUE and not self._has_blur):
@@ -556,7 +566,7 @@ class ConvLayer(nn.Sequential):
             # EqualConv2d -> FusedLeakyReLU in one launch: bias + leaky-ReLU run in the convolution's epilogue
             act = self[idx + 1]
             return conv2d_gradfix.conv2d_bias_act(out, conv.weight, act.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale,
-                                                  negative_slope=act.negative_slope, scale=act.scale * out_gain, fork=fork)
+                                                  negative_slope=act.negative_slope, scale=act.scale * out_gain, fork=fork, grad_premasked=grad_premasked)
         if self._activate:
             out = conv2d_gradfix.conv2d(out, conv.weight, bias=conv.bias, stride=stride, padding=conv.padding, weight_scale=conv.scale)
             act = self[idx + 1]
@@ -588,6 +598,11 @@ class ResBlock(nn.Module):
         # Neither sum of this block is a pass of its own: `out + skip` is the residual epilogue of the skip convolution, and
         # the two gradients of `input` (conv1 path, skip path) meet in the epilogue of conv1's input-gradient convolution
         # (conv1 hands `input` on to the skip branch: fork).
+        if _FUSE_BLUR_ADJ:
+            # conv1's output feeds conv2's Blur and nothing else: the Blur's adjoint applies conv1's activation mask on its way out
+            act1 = self.conv1[1]
+            out, forked = self.conv1(input, fork=True, grad_premasked=True)
+            return self.skip(forked, out_gain=rs, residual=self.conv2(out, out_gain=rs, input_act=(act1.negative_slope, act1.scale)))
         out, forked = self.conv1(input, fork=True)
         return self.skip(forked, out_gain=rs, residual=self.conv2(out, out_gain=rs))
 

@@ -183,6 +183,26 @@ class HipBackend:
             self.timer.stop('fir44_tile_kernel', t0, 4.0 * (x.numel() + y.numel()))
         return y
 
+    def upfirdn2d_mask(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, mask_ref, slope, gain):
+        """FIR(x) * (mask_ref > 0 ? gain : gain * slope) in one pass (gc_upfirdn2d_mask_f32: the Blur adjoint + the activation backward of the
+        layer whose output the Blur read); shapes as upfirdn2d_act_supported, x may be row-pitched, mask_ref is [N, C, out_h, out_w] dense."""
+        pitch = _lib.row_pitch(x)
+        dev = _lib.require_cuda_f32(x, taps, mask_ref, pitched=(x,))
+        n, c, h, w = x.shape
+        if tuple(mask_ref.shape) != (n, c, out_h, out_w):
+            raise RuntimeError('upfirdn2d_mask: mask reference %s, output [%d, %d, %d, %d]' % (tuple(mask_ref.shape), n, c, out_h, out_w))
+        y = torch.empty((n, c, out_h, out_w), dtype=x.dtype, device=dev)
+        if y.numel() == 0:
+            return y
+        t0 = self.timer.start('fir44', 'fir44_tile_kernel') if self.timer else None
+        with (self._guard(dev) or contextlib.nullcontext()):
+            rc = _lib.load().gc_upfirdn2d_mask_f32(_lib.ptr(x), _lib.ptr(taps), _lib.ptr(y), n, c, h, w, pitch or w, out_h, out_w, taps.shape[0], taps.shape[1],
+                                                   pad_x0, pad_y0, int(flip), _lib.ptr(mask_ref), float(slope), float(gain), _lib.stream_of(x))
+        _lib.check(rc, 'gc_upfirdn2d_mask_f32')
+        if t0 is not None:
+            self.timer.stop('fir44_tile_kernel', t0, 4.0 * (x.numel() + 2 * y.numel()))
+        return y
+
     def bias_act(self, x, bias, noise, noise_w, slope, gain):
         """y = gain * lrelu(x + bias[c] + noise_w * noise[b, :]); x is [B, C, *]."""
         dev = _lib.require_cuda_f32(x, bias, noise, noise_w)

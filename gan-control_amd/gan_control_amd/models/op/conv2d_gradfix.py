@@ -102,9 +102,10 @@ class _GConvAct(Function):
     """
 
     @staticmethod
-    def forward(ctx, x, w_t, bias, geom, slope, gain, fork=False):
+    def forward(ctx, x, w_t, bias, geom, slope, gain, fork=False, premasked=False):
         out = _backend.get().conv2d(_dense_or_pitched(x), w_t.contiguous(), None, None, geom, epilogue=(bias, None, None, slope, gain, True))
         ctx.geom, ctx.cfg = geom, (slope, gain)
+        ctx.premasked = bool(premasked)
         ctx.in_hw = (x.shape[2], x.shape[3])
         ctx.save_for_backward(x, w_t, out)
         ctx.set_materialize_grads(False)
@@ -118,11 +119,18 @@ class _GConvAct(Function):
         slope, gain = ctx.cfg
         gx = gw = gb = None
         if not any(ctx.needs_input_grad[:3]):
-            return None, None, None, None, None, None, None
+            return None, None, None, None, None, None, None, None
         if gy is None:                      # only the forked copy was used downstream
-            return (gfork if ctx.needs_input_grad[0] else None), None, None, None, None, None, None
+            return (gfork if ctx.needs_input_grad[0] else None), None, None, None, None, None, None, None
         params = _backend.want_param_grads()
-        if ctx.needs_input_grad[2] and params:
+        if ctx.premasked:
+            # the only consumer of `out` (upfirdn2d.blur_of_activation) has applied this activation's mask already: gy IS the gradient
+            # of the pre-activation
+            from .fused_act import _channel_sum
+            g_pre = gy
+            if ctx.needs_input_grad[2] and params:
+                gb = _channel_sum(gy)
+        elif ctx.needs_input_grad[2] and params:
             g_pre, psum = _BiasActGradReduce.apply(gy, out, None, slope, gain)[:2]
             gb = psum.sum((0, 2))
         else:
@@ -131,7 +139,7 @@ class _GConvAct(Function):
             gx = _GConv.apply(g_pre, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw), gfork)
         if ctx.needs_input_grad[1] and params:
             gw = _weight_grad(x, g_pre, g)
-        return gx, gw, gb, None, None, None, None
+        return gx, gw, gb, None, None, None, None, None
 
 
 def _pair(v):
@@ -177,9 +185,10 @@ def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, 
     return y if bias is None else y + bias.reshape(1, -1, 1, 1)
 
 
-def conv2d_bias_act(input, weight, bias, stride=1, padding=0, weight_scale=1.0, negative_slope=0.2, scale=2 ** 0.5, fork=False):
+def conv2d_bias_act(input, weight, bias, stride=1, padding=0, weight_scale=1.0, negative_slope=0.2, scale=2 ** 0.5, fork=False, grad_premasked=False):
     """scale * leaky_relu(conv2d(input, weight * weight_scale) + bias): EqualConv2d -> FusedLeakyReLU (ConvLayer,
-    gan_model.py:844-890) as ONE kernel launch."""
+    gan_model.py:844-890) as ONE kernel launch.  grad_premasked=True: the result's ONLY consumer is upfirdn2d.blur_of_activation, whose
+    backward returns the gradient of the pre-activation (this layer then skips its own activation-backward pass)."""
     s, p = _check(input, weight, stride, padding, 1, 1)
     if weight.shape[1] != input.shape[1]:
         raise ValueError(f'conv2d: weight expects {weight.shape[1]} input channels, got {input.shape[1]}')
@@ -189,7 +198,7 @@ def conv2d_bias_act(input, weight, bias, stride=1, padding=0, weight_scale=1.0, 
     oh = (input.shape[2] + 2 * p - kh) // s + 1
     ow = (input.shape[3] + 2 * p - kw) // s + 1
     return _GConvAct.apply(input, kernel_layout(weight, weight_scale), bias.reshape(-1).contiguous(),
-                           ConvGeom(kh, kw, 1, s, p, p, oh, ow), float(negative_slope), float(scale), bool(fork))
+                           ConvGeom(kh, kw, 1, s, p, p, oh, ow), float(negative_slope), float(scale), bool(fork), bool(grad_premasked))
 
 
 def conv_transpose2d(input, weight, bias=None, stride=1, padding=0, output_padding=0, groups=1, dilation=1, weight_scale=1.0):

@@ -3,6 +3,7 @@
 Socket: ``upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0))`` -- signature and defaults of the
 reference wrapper gan_model.py:45-50 (which calls upfirdn2d_native, pytorch_upfirdn2d.py:9-51).
 """
+import torch
 from torch.autograd import Function
 
 from . import _backend
@@ -66,6 +67,69 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0), _internal=False):
         return _UpFirDn2d.apply(input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
     with _backend.pitched_outputs(False):
         return _UpFirDn2d.apply(input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
+
+
+class _BlurOfActivation(Function):
+    """y = upfirdn2d(a, kernel, pad=(p0, p1)) where ``a`` is the output of a fused bias + leaky-ReLU layer built with
+    ``grad_premasked=True`` (conv2d_gradfix.conv2d_bias_act): this op's backward hands that layer the gradient w.r.t. its
+    PRE-activation -- Blur adjoint and activation backward in ONE pass over the gradient (gc_upfirdn2d_mask_f32) instead of a FIR
+    launch followed by an elementwise launch (ResBlock: conv1 -> FusedLeakyReLU -> Blur -> conv2, gan_model.py:893-922).
+
+    The two ends belong together: ``a`` must have no other consumer (its producer skips its own mask multiplication)."""
+
+    @staticmethod
+    def forward(ctx, a, kernel, p0, p1, slope, gain):
+        kh, kw = kernel.shape
+        n, c, h, w = a.shape
+        oh, ow = _out_size(h, kh, 1, 1, p0, p1), _out_size(w, kw, 1, 1, p0, p1)
+        ctx.save_for_backward(kernel, a)
+        ctx.cfg, ctx.act = (1, 1, p0, p1, h, w), (slope, gain)
+        ctx.set_materialize_grads(False)
+        return _backend.get().upfirdn2d(_dense_or_pitched(a), kernel, 1, 1, p0, p0, oh, ow, True)
+
+    @staticmethod
+    def backward(ctx, gy):
+        kernel, a = ctx.saved_tensors
+        if gy is None or not ctx.needs_input_grad[0]:
+            return None, None, None, None, None, None
+        return _BlurAdjointMasked.apply(gy, kernel, ctx.cfg, a, *ctx.act), None, None, None, None, None
+
+
+class _BlurAdjointMasked(Function):
+    """g_pre = upfirdn2d_adjoint(gy) * (a > 0 ? gain : gain * slope); linear in gy."""
+
+    @staticmethod
+    def forward(ctx, gy, kernel, cfg, a, slope, gain):
+        up, down, p0, p1, h, w = cfg
+        kh, kw = kernel.shape
+        ctx.save_for_backward(kernel, a)
+        ctx.cfg, ctx.act = cfg, (slope, gain)
+        ctx.set_materialize_grads(False)
+        be = _backend.get()
+        fused = getattr(be, 'upfirdn2d_mask', None)
+        if (fused is not None and not _backend.strict_zeros() and a.is_contiguous()
+                and be.upfirdn2d_act_supported(kernel, 1, 1, h, w, a.shape[0] * a.shape[1])):
+            return fused(_dense_or_pitched(gy), kernel, kw - 1 - p0, kh - 1 - p0, h, w, False, a, slope, gain)
+        g = be.upfirdn2d(_dense_or_pitched(gy), kernel, down, up, kw - 1 - p0, kh - 1 - p0, h, w, False)
+        return be.bias_act_bwd(g.contiguous(), a.contiguous(), slope, gain)
+
+    @staticmethod
+    def backward(ctx, gg):
+        from .fused_act import _BiasActGrad
+        kernel, a = ctx.saved_tensors
+        if gg is None:
+            return None, None, None, None, None, None
+        up, down, p0, p1, h, w = ctx.cfg
+        slope, gain = ctx.act
+        ggy = _UpFirDn2d.apply(_BiasActGrad.apply(gg, a, slope, gain), kernel, up, down, p0, p1) if ctx.needs_input_grad[0] else None
+        # d/da of the mask is zero almost everywhere (zeros only for the trainer's dry run, as in _BiasActGrad)
+        ga = torch.zeros_like(a) if (ctx.needs_input_grad[3] and _backend.strict_zeros()) else None
+        return ggy, None, None, ga, None, None
+
+
+def blur_of_activation(a, kernel, pad, negative_slope, scale):
+    """upfirdn2d(a, kernel, pad=pad) for an ``a`` produced with ``grad_premasked=True`` (see _BlurOfActivation)."""
+    return _BlurOfActivation.apply(a, kernel, int(pad[0]), int(pad[1]), float(negative_slope), float(scale))
 
 
 class _UpFirDn2dAct(Function):

@@ -84,6 +84,15 @@ int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,
                          const float* bias, const float* noise, const float* noise_w, float slope, float gain,
                          gc_stream_t stream);
 
+/* y = FIR(x) * (mask_ref > 0 ? gain : gain * slope): the Blur ADJOINT followed by the backward of the bias + leaky-ReLU whose output the
+ * Blur read (ResBlock: conv1 -> FusedLeakyReLU -> Blur -> stride-2 conv2, gan_model.py:893-922, 844-890) in one pass -- the product is
+ * applied to the fp32 FIR result, so the values equal gc_upfirdn2d_f32 followed by gc_bias_act_bwd_f32 bit for bit, while the
+ * gradient makes one round trip to HBM less.  mask_ref: [batch, channels, out_h, out_w] dense (the activation output); x rows in_pitch
+ * floats apart (0 = dense); 4 x 4 taps, up = down = 1, planes the tile kernel takes (out_w >= 64, out_h >= 16). */
+int gc_upfirdn2d_mask_f32(const float* x, const float* taps, float* y, int batch, int channels, int in_h, int in_w, int in_pitch,
+                          int out_h, int out_w, int kh, int kw, int pad_x0, int pad_y0, int flip_taps,
+                          const float* mask_ref, float slope, float gain, gc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * K2  fused (noise +) bias + leaky-ReLU * gain.
  *

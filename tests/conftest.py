@@ -111,6 +111,9 @@ class EmulatedBackend:
             at += sp.n
         return gws, gbs
 
+    def upfirdn2d_mask(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, mask_ref, slope, gain):
+        return self.bias_act_bwd(self.upfirdn2d(x, taps, 1, 1, pad_x0, pad_y0, out_h, out_w, flip), mask_ref, slope, gain)
+
     def bias_act(self, x, bias, noise, noise_w, slope, gain):
         shape = [1, -1] + [1] * (x.ndim - 2)
         v = x

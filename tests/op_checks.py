@@ -352,3 +352,44 @@ def check_config_ingestion(device, name='ffhq', size=32, batch=8):
     for k in ('d_loss', 'd_r1_loss', 'g_adv_loss', 'g_path_loss'):
         assert stats[k] == stats[k] and abs(stats[k]) < 1e6, (k, stats[k])
     return tr
+
+
+def check_resblock_blur_adjoint_fusion(device, size=128, batch=2, tol=1e-5):
+    """ResBlock with conv1's activation backward folded into the Blur adjoint (gc_upfirdn2d_mask_f32; models/gan_model.py::_FUSE_BLUR_ADJ)
+    against the two-launch form: logits, every parameter gradient of a plain backward, the input gradient, and R1's double backward."""
+    from gan_control_amd.models import gan_model as gm
+    from oracle.networks import procedural_fill_
+    torch.manual_seed(0)
+    d = gm.Discriminator(size, channel_multiplier=2)
+    d.load_state_dict(procedural_fill_(d.state_dict()))
+    d = d.to(device)
+    gen = torch.Generator().manual_seed(12)
+    img = (torch.rand(batch, 3, size, size, generator=gen) * 2 - 1).to(device)
+    res = {}
+    keep = gm._FUSE_BLUR_ADJ
+    try:
+        for fused in (True, False):
+            gm._FUSE_BLUR_ADJ = fused
+            d.zero_grad()
+            x = img.clone().requires_grad_(True)
+            pred, _ = d(x)
+            torch.nn.functional.softplus(pred).mean().backward()
+            plain = ({n: p.grad.clone() for n, p in d.named_parameters()}, x.grad.clone(), pred.detach().clone())
+            d.zero_grad()
+            x = img.clone().requires_grad_(True)
+            pred, _ = d(x)
+            g, = autograd.grad(pred.sum(), x, create_graph=True)
+            g.pow(2).reshape(batch, -1).sum(1).mean().backward()
+            r1 = {n: (None if p.grad is None else p.grad.clone()) for n, p in d.named_parameters()}
+            res[fused] = (plain, r1, g.detach().clone())
+    finally:
+        gm._FUSE_BLUR_ADJ = keep
+    (pa, xa, la), ra, ga = res[True]
+    (pb, xb, lb), rb, gb = res[False]
+    assert torch.equal(la, lb)
+    assert rel_err(xa, xb) <= tol and rel_err(ga, gb) <= tol
+    for n in pb:
+        assert rel_err(pa[n], pb[n]) <= tol, n
+        assert (ra[n] is None) == (rb[n] is None), n
+        if rb[n] is not None and float(rb[n].abs().max()) > 0:
+            assert rel_err(ra[n], rb[n]) <= 10 * tol, n

@@ -201,3 +201,7 @@ def test_weight_cache_reuse_and_invalidation(emu_backend):
     import gc
     gc.collect()
     weight_cache.clear()
+
+
+def test_resblock_blur_adjoint_fusion(emu_backend):
+    oc.check_resblock_blur_adjoint_fusion('cpu', size=64, batch=2)

@@ -1053,3 +1053,27 @@ def test_equal_linear_small_gemm_autograd():
     ref = run(xd, wd, bd, lambda xx, ww, bb: 0.01 * bb + 0.3 * (xx @ ww.t()) + 0.2 * (xx @ ww.t()))
     for g_, r_ in zip(got, ref):
         assert rel_err(g_, r_) < 5e-6
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
+def test_resblock_blur_adjoint_fusion_gpu(mode):
+    hip, _ = _be()
+    prev, hip.conv_mode = hip.conv_mode, mode
+    try:
+        oc.check_resblock_blur_adjoint_fusion(DEV, size=256, batch=2, tol=1e-5 if mode == 'f32' else 2e-4)
+    finally:
+        hip.conv_mode = prev
+
+
+@pytest.mark.parametrize('shape', [(2, 5, 129, 131), (1, 3, 64, 256), (3, 2, 70, 161)])
+def test_upfirdn2d_mask_kernel(shape):
+    """gc_upfirdn2d_mask_f32 == gc_upfirdn2d_f32 followed by gc_bias_act_bwd_f32, bit for bit (dense and row-pitched input)."""
+    hip, _ = _be()
+    gen = torch.Generator().manual_seed(sum(shape))
+    b, c, h, w = shape
+    k4 = torch.rand(4, 4, generator=gen).to(DEV)
+    gy = torch.randn(b, c, h + 1, w + 1, generator=gen).to(DEV)
+    ref_act = torch.randn(b, c, h, w, generator=gen).to(DEV)
+    two = hip.bias_act_bwd(hip.upfirdn2d(gy, k4, 1, 1, 1, 1, h, w, False).contiguous(), ref_act, 0.2, 1.4)
+    assert torch.equal(hip.upfirdn2d_mask(gy, k4, 1, 1, h, w, False, ref_act, 0.2, 1.4), two)
+    assert torch.equal(hip.upfirdn2d_mask(_pitched(gy, (w + 1 + 31) // 32 * 32), k4, 1, 1, h, w, False, ref_act, 0.2, 1.4), two)
