@@ -27,6 +27,11 @@ struct FirEpilogue {
     // EPI = 2 (gc_upfirdn2d_mask_f32): y = FIR(x) * (mask_ref > 0 ? mpos : mneg), mask_ref shaped like the output (dense rows) -- the Blur
     // adjoint followed by the activation backward of the layer whose output the Blur read (ResBlock conv1, gan_model.py:893-922)
     const float* mask_ref; float mpos, mneg;
+    // PRO (gc_upfirdn2d_actbwd_f32): the INPUT is multiplied by the activation mask of pro_ref while it is staged -- x is the gradient that
+    // arrives at a fused Blur + noise + bias + leaky-ReLU (StyledConv's up-sampling branch), the kernel computes the Blur adjoint of the
+    // pre-activation gradient and, per (plane, tile), the sums the bias / noise-strength gradients need (each input element is owned by
+    // exactly one tile: the first TH x TW elements of its patch)
+    const float* pro_ref; const float* pro_noise; float* pro_psum; float* pro_pdot; float ppos, pneg;
 };
 
 // GC_FIR_NT vertically consecutive tiles per workgroup in one software pipeline (the 16-byte loads of tile t + 1 issued before the
@@ -38,7 +43,7 @@ struct FirEpilogue {
 #define GC_FIR_NT 1
 #endif
 
-template <bool VEC, int EPI>
+template <bool VEC, int EPI, bool PRO = false>
 __global__ __launch_bounds__(256) void fir44_tile_kernel(
     const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
     int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip, FirEpilogue ep, int in_pitch, int out_pitch) {
@@ -64,6 +69,25 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
     constexpr int NLD = (PH * GPR + 255) / 256;
     typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
     float4 stage[NLD];
+    // guarded 16-byte load of four consecutive floats of one row (zeros outside the image)
+    auto ld4 = [&](const float* rowp, int ix, int width) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float* src = rowp + ix;
+        if (ix >= 0 && ix + 3 < width) {
+            const f4u t = *reinterpret_cast<const f4u*>(src);
+            v = make_float4(t.x, t.y, t.z, t.w);
+        } else {
+            if (ix >= 0 && ix < width) v.x = src[0];
+            if (ix + 1 >= 0 && ix + 1 < width) v.y = src[1];
+            if (ix + 2 >= 0 && ix + 2 < width) v.z = src[2];
+            if (ix + 3 >= 0 && ix + 3 < width) v.w = src[3];
+        }
+        return v;
+    };
+    static_assert(!PRO || GC_FIR_NT == 1, "the prologue sums are written once per workgroup");
+    float ps = 0.f, pd = 0.f;                                // PRO: this lane's share of the tile's sums
+    const float* refp = PRO ? ep.pro_ref + plane * (size_t)in_h * in_w : nullptr;
+    const float* nzp = (PRO && ep.pro_noise) ? ep.pro_noise + (plane / ep.channels) * (size_t)in_h * in_w : nullptr;
     auto fetch = [&](int oy0) {
         const int iy0 = oy0 - pad_y0;
 #pragma unroll
@@ -73,15 +97,20 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
             const int iy = iy0 + r, ix = ix0 + c;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (idx < PH * GPR && iy >= 0 && iy < in_h) {
-                const float* src = xp + (size_t)iy * in_pitch + ix;
-                if (ix >= 0 && ix + 3 < in_w) {
-                    const f4u t = *reinterpret_cast<const f4u*>(src);
-                    v = make_float4(t.x, t.y, t.z, t.w);
-                } else {
-                    if (ix >= 0 && ix < in_w) v.x = src[0];
-                    if (ix + 1 >= 0 && ix + 1 < in_w) v.y = src[1];
-                    if (ix + 2 >= 0 && ix + 2 < in_w) v.z = src[2];
-                    if (ix + 3 >= 0 && ix + 3 < in_w) v.w = src[3];
+                v = ld4(xp + (size_t)iy * in_pitch, ix, in_w);
+                if (PRO) {
+                    const float4 m = ld4(refp + (size_t)iy * in_w, ix, in_w);
+                    v.x *= m.x > 0.f ? ep.ppos : ep.pneg; v.y *= m.y > 0.f ? ep.ppos : ep.pneg;
+                    v.z *= m.z > 0.f ? ep.ppos : ep.pneg; v.w *= m.w > 0.f ? ep.ppos : ep.pneg;
+                    // owned by this tile: the first TH x TW elements of the patch, plus what lies beyond them in the last tile row / column
+                    // (there is no next tile to own it); elements outside the image are zero
+                    if ((r < TH || blockIdx.y == gridDim.y - 1) && (c < TW || blockIdx.x == gridDim.x - 1)) {
+                        ps += (v.x + v.y) + (v.z + v.w);
+                        if (nzp) {
+                            const float4 z = ld4(nzp + (size_t)iy * in_w, ix, in_w);
+                            pd += (v.x * z.x + v.y * z.y) + (v.z * z.z + v.w * z.w);
+                        }
+                    }
                 }
             }
             stage[j] = v;
@@ -101,8 +130,19 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
     const int tiles_y = (out_h + TH - 1) / TH;
     const int nt = min(GC_FIR_NT, tiles_y - ty0);
     fetch(ty0 * TH);
+    __shared__ float red[8];
+    if (PRO) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { ps += __shfl_xor(ps, off, 64); pd += __shfl_xor(pd, off, 64); }
+        if ((tid & 63) == 0) { red[(tid >> 6) * 2] = ps; red[(tid >> 6) * 2 + 1] = pd; }
+    }
     commit();
     __syncthreads();
+    if (PRO && tid == 0) {
+        const size_t slot = plane * ((size_t)gridDim.x * gridDim.y) + (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+        ep.pro_psum[slot] = (red[0] + red[2]) + (red[4] + red[6]);
+        if (ep.pro_pdot) ep.pro_pdot[slot] = (red[1] + red[3]) + (red[5] + red[7]);
+    }
     for (int t = 0; t < nt; ++t) {
         const int oy0 = (ty0 + t) * TH;
         const bool more = t + 1 < nt;
@@ -568,7 +608,13 @@ int upfirdn2d_impl(const float* x, const float* taps, float* y,
     if (fast) {
         dim3 grid(gc::ceil_div(out_w, TW), gc::ceil_div(gc::ceil_div(out_h, TH), GC_FIR_NT), planes);
         const bool vec = (out_pitch % 4 == 0) && ((reinterpret_cast<uintptr_t>(y) & 15) == 0);      // rows start on 16-byte boundaries
-        const FirEpilogue none{nullptr, nullptr, nullptr, 1.f, 1.f, 1, nullptr, 1.f, 1.f};
+        const FirEpilogue none{nullptr, nullptr, nullptr, 1.f, 1.f, 1, nullptr, 1.f, 1.f, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
+        if (ep && ep->pro_ref) {
+            if (in_pitch != in_w) return gc::fail(GC_ERR_UNSUPPORTED, "gc_upfirdn2d_actbwd_f32: the gradient must have dense rows");
+            if (vec) hipLaunchKernelGGL((fir44_tile_kernel<true, 0, true>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, *ep, in_pitch, out_pitch);
+            else     hipLaunchKernelGGL((fir44_tile_kernel<false, 0, true>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, *ep, in_pitch, out_pitch);
+            return gc::check_launch("gc_upfirdn2d_actbwd_f32");
+        }
 #define GC_FIR(V, E) hipLaunchKernelGGL((fir44_tile_kernel<V, E>), grid, dim3(256), 0, s, x, taps, y, in_h, in_w, out_h, out_w, pad_x0, pad_y0, flip_taps, ep ? *ep : none, in_pitch, out_pitch)
         if (ep && ep->mask_ref) { if (vec) GC_FIR(true, 2); else GC_FIR(false, 2); }
         else if (ep) { if (vec) GC_FIR(true, 1); else GC_FIR(false, 1); }
@@ -630,8 +676,23 @@ extern "C" int gc_upfirdn2d_pitched_f32(const float* x, const float* taps, float
     if ((noise == nullptr) != (noise_w == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_pitched_f32: noise and noise_w must both be set or both be null");
     if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_pitched_f32: bad batch / channels");
     const bool epi = activate || bias || noise;
-    const FirEpilogue ep{bias, noise, noise_w, activate ? slope : 1.f, activate ? gain : 1.f, channels, nullptr, 1.f, 1.f};
+    const FirEpilogue ep{bias, noise, noise_w, activate ? slope : 1.f, activate ? gain : 1.f, channels, nullptr, 1.f, 1.f, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
     return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, epi ? &ep : nullptr, stream, in_pitch, out_pitch);
+}
+
+extern "C" int gc_upfirdn2d_actbwd_tiles(int out_h, int out_w) {
+    if (out_h <= 0 || out_w <= 0) return 0;
+    return gc::ceil_div(out_w, TW) * gc::ceil_div(gc::ceil_div(out_h, TH), GC_FIR_NT);
+}
+
+extern "C" int gc_upfirdn2d_actbwd_f32(const float* gy, const float* y_ref, const float* noise, const float* taps, float* gx, float* psum, float* pdot,
+                                       int batch, int channels, int in_h, int in_w, int out_h, int out_w, int out_pitch, int kh, int kw,
+                                       int pad_x0, int pad_y0, int flip_taps, float slope, float gain, gc_stream_t stream) {
+    if (!y_ref || !psum) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_actbwd_f32: null pointer");
+    if ((noise == nullptr) != (pdot == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_actbwd_f32: noise and pdot go together");
+    if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_actbwd_f32: bad batch / channels");
+    const FirEpilogue ep{nullptr, nullptr, nullptr, 1.f, 1.f, channels, nullptr, 1.f, 1.f, y_ref, noise, psum, pdot, gain, gain * slope};
+    return upfirdn2d_impl(gy, taps, gx, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, &ep, stream, 0, out_pitch);
 }
 
 extern "C" int gc_upfirdn2d_mask_f32(const float* x, const float* taps, float* y, int batch, int channels, int in_h, int in_w, int in_pitch,
@@ -639,7 +700,7 @@ extern "C" int gc_upfirdn2d_mask_f32(const float* x, const float* taps, float* y
                                      const float* mask_ref, float slope, float gain, gc_stream_t stream) {
     if (!mask_ref) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_mask_f32: null mask reference");
     if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_mask_f32: bad batch / channels");
-    const FirEpilogue ep{nullptr, nullptr, nullptr, 1.f, 1.f, channels, mask_ref, gain, gain * slope};
+    const FirEpilogue ep{nullptr, nullptr, nullptr, 1.f, 1.f, channels, mask_ref, gain, gain * slope, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
     return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, &ep, stream, in_pitch, 0);
 }
 
@@ -650,6 +711,6 @@ extern "C" int gc_upfirdn2d_act_f32(const float* x, const float* taps, float* y,
                                     gc_stream_t stream) {
     if ((noise == nullptr) != (noise_w == nullptr)) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_act_f32: noise and noise_w must both be set or both be null");
     if (batch < 0 || channels <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_upfirdn2d_act_f32: bad batch / channels");
-    const FirEpilogue ep{bias, noise, noise_w, slope, gain, channels, nullptr, 1.f, 1.f};
+    const FirEpilogue ep{bias, noise, noise_w, slope, gain, channels, nullptr, 1.f, 1.f, nullptr, nullptr, nullptr, nullptr, 1.f, 1.f};
     return upfirdn2d_impl(x, taps, y, batch * channels, in_h, in_w, out_h, out_w, kh, kw, 1, 1, 1, 1, pad_x0, pad_y0, flip_taps, &ep, stream);
 }

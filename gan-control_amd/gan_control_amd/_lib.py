@@ -86,6 +86,8 @@ SIGNATURES = {
     'gc_conv2d_variant_name': (_i32, [ctypes.POINTER(ConvDesc), _i32, ctypes.c_char_p, _i32]),
     'gc_conv2d_out_pitch': (_i32, [ctypes.POINTER(ConvDesc), _i32]),
     'gc_conv2d_in_pitch_ok': (_i32, [ctypes.POINTER(ConvDesc), _i32, _i32]),
+    'gc_upfirdn2d_actbwd_tiles': (_i32, [_i32, _i32]),
+    'gc_upfirdn2d_actbwd_f32': (_i32, [_vp] * 7 + [_i32] * 12 + [_f32, _f32, _vp]),
     'gc_upfirdn2d_mask_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 12 + [_vp, _f32, _f32, _vp]),
     'gc_upfirdn2d_pitched_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 14 + [_vp, _vp, _vp, _f32, _f32, _vp]),
     'gc_plane_dot_pitched_chunks': (_i32, [_i32]),

@@ -203,6 +203,30 @@ class HipBackend:
             self.timer.stop('fir44_tile_kernel', t0, 4.0 * (x.numel() + 2 * y.numel()))
         return y
 
+    def upfirdn2d_actbwd(self, gy, y_ref, noise, taps, pad_x0, pad_y0, out_h, out_w, flip, slope, gain):
+        """(gx, psum [B, C, tiles], pdot [B, C, tiles] | None): the Blur adjoint of gy * mask(y_ref) and the per-tile sums for the bias /
+        noise-strength gradients in one pass over gy (gc_upfirdn2d_actbwd_f32).  gx comes back row-pitched when its width is odd."""
+        dev = _lib.require_cuda_f32(gy, y_ref, noise, taps)
+        n, c, h, w = gy.shape
+        lib = _lib.load()
+        tiles = lib.gc_upfirdn2d_actbwd_tiles(out_h, out_w)
+        out_pitch = (out_w + 31) // 32 * 32 if (pitch_allowed() and out_w % 4 != 0 and out_w >= 129 and self.conv_mode != 'f32') else 0
+        if out_pitch:
+            gx = torch.empty((n, c, out_h, out_pitch), dtype=gy.dtype, device=dev)[..., :out_w]
+        else:
+            gx = torch.empty((n, c, out_h, out_w), dtype=gy.dtype, device=dev)
+        psum = torch.empty((n, c, tiles), dtype=gy.dtype, device=dev)
+        pdot = torch.empty((n, c, tiles), dtype=gy.dtype, device=dev) if noise is not None else None
+        t0 = self.timer.start('fir44', 'fir44_tile_kernel') if self.timer else None
+        with (self._guard(dev) or contextlib.nullcontext()):
+            rc = lib.gc_upfirdn2d_actbwd_f32(_lib.ptr(gy), _lib.ptr(y_ref), _lib.ptr(noise), _lib.ptr(taps), _lib.ptr(gx), _lib.ptr(psum), _lib.ptr(pdot),
+                                             n, c, h, w, out_h, out_w, out_pitch, taps.shape[0], taps.shape[1], pad_x0, pad_y0, int(flip),
+                                             float(slope), float(gain), _lib.stream_of(gy))
+        _lib.check(rc, 'gc_upfirdn2d_actbwd_f32')
+        if t0 is not None:
+            self.timer.stop('fir44_tile_kernel', t0, 4.0 * (2 * gy.numel() + gx.numel()))
+        return gx, psum, pdot
+
     def bias_act(self, x, bias, noise, noise_w, slope, gain):
         """y = gain * lrelu(x + bias[c] + noise_w * noise[b, :]); x is [B, C, *]."""
         dev = _lib.require_cuda_f32(x, bias, noise, noise_w)

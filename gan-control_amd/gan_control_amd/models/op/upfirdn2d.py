@@ -6,7 +6,11 @@ reference wrapper gan_model.py:45-50 (which calls upfirdn2d_native, pytorch_upfi
 import torch
 from torch.autograd import Function
 
+import os
+
 from . import _backend
+
+_FUSE_ACT_BWD = os.environ.get('GANCONTROL_FUSE_ACT_BWD_BLUR', '1') != '0'     # dev knob: 0 = activation backward and Blur adjoint as two launches
 
 
 def _out_size(n, k, up, down, p0, p1):
@@ -161,6 +165,21 @@ class _UpFirDn2dAct(Function):
         want_b, want_nw = ctx.has_bias and need[4] and params, ctx.has_noise and need[6] and params
         if gy is None or not (need[0] or want_b or want_nw):
             return (None,) * 9
+        be = _backend.get()
+        up, down, p0, p1, h, w = ctx.cfg
+        kh, kw = kernel.shape
+        fused = getattr(be, 'upfirdn2d_actbwd', None)
+        if (fused is not None and _FUSE_ACT_BWD and need[0] and not torch.is_grad_enabled() and not _backend.strict_zeros()
+                and gy.is_contiguous() and out.is_contiguous() and 0 <= p0 <= min(kh, kw) - 1
+                and be.upfirdn2d_act_supported(kernel, 1, 1, h, w, gy.shape[0] * gy.shape[1])):
+            # plain (not differentiated further) backward: activation backward, both reductions and the Blur adjoint in ONE pass over gy --
+            # the pre-activation gradient never travels to HBM (gc_upfirdn2d_actbwd_f32).  Orders above one take the Functions below.
+            gx, psum, pdot = fused(gy, out, noise.contiguous() if want_nw else None, kernel, kw - 1 - p0, kh - 1 - p0, h, w, False, slope, gain)
+            if want_b:
+                gb = psum.sum((0, 2))
+            if want_nw:
+                gnw = pdot.sum().reshape(noise_w.shape)
+            return gx, None, None, None, gb, None, gnw, None, None
         if want_b or want_nw:
             g_pre, psum, pdot = _BiasActGradReduce.apply(gy, out, noise if want_nw else None, slope, gain)[:3]
             if want_b:

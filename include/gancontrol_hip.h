@@ -93,6 +93,18 @@ int gc_upfirdn2d_mask_f32(const float* x, const float* taps, float* y, int batch
                           int out_h, int out_w, int kh, int kw, int pad_x0, int pad_y0, int flip_taps,
                           const float* mask_ref, float slope, float gain, gc_stream_t stream);
 
+/* The backward of StyledConv's up-sampling tail (Blur -> NoiseInjection -> FusedLeakyReLU, gan_model.py:402-408 after :304-307) in one pass
+ * over the gradient:  g_pre = gy * (y_ref > 0 ? gain : gain * slope) is formed while gy is staged, gx = FIR(g_pre) (the Blur adjoint) is
+ * stored, and per (plane, tile)  psum = sum g_pre,  pdot = sum g_pre * noise[b]  over the input elements the tile owns (every element once):
+ * the bias gradient is the sum of psum over batch and tiles, the noise-strength gradient the sum of all pdot.  g_pre never travels to HBM
+ * (gc_bias_act_bwd_reduce_f32 + gc_upfirdn2d_f32 write and re-read it).  gy, y_ref: [batch, channels, in_h, in_w] dense; noise
+ * [batch, in_h * in_w] with pdot, or both NULL; gx rows out_pitch floats apart (0 = dense); psum / pdot: [batch * channels,
+ * gc_upfirdn2d_actbwd_tiles(out_h, out_w)].  4 x 4 taps on planes the tile kernel takes. */
+int gc_upfirdn2d_actbwd_tiles(int out_h, int out_w);
+int gc_upfirdn2d_actbwd_f32(const float* gy, const float* y_ref, const float* noise, const float* taps, float* gx, float* psum, float* pdot,
+                            int batch, int channels, int in_h, int in_w, int out_h, int out_w, int out_pitch, int kh, int kw,
+                            int pad_x0, int pad_y0, int flip_taps, float slope, float gain, gc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * K2  fused (noise +) bias + leaky-ReLU * gain.
  *

@@ -111,6 +111,13 @@ class EmulatedBackend:
             at += sp.n
         return gws, gbs
 
+    def upfirdn2d_actbwd(self, gy, y_ref, noise, taps, pad_x0, pad_y0, out_h, out_w, flip, slope, gain):
+        g_pre = self.bias_act_bwd(gy, y_ref, slope, gain)
+        b, c = gy.shape[:2]
+        psum = g_pre.reshape(b, c, -1).sum(2, keepdim=True)
+        pdot = (g_pre * noise.reshape(b, 1, *gy.shape[2:])).reshape(b, c, -1).sum(2, keepdim=True) if noise is not None else None
+        return self.upfirdn2d(g_pre, taps, 1, 1, pad_x0, pad_y0, out_h, out_w, flip), psum, pdot
+
     def upfirdn2d_mask(self, x, taps, pad_x0, pad_y0, out_h, out_w, flip, mask_ref, slope, gain):
         return self.bias_act_bwd(self.upfirdn2d(x, taps, 1, 1, pad_x0, pad_y0, out_h, out_w, flip), mask_ref, slope, gain)
 

@@ -1077,3 +1077,53 @@ def test_upfirdn2d_mask_kernel(shape):
     two = hip.bias_act_bwd(hip.upfirdn2d(gy, k4, 1, 1, 1, 1, h, w, False).contiguous(), ref_act, 0.2, 1.4)
     assert torch.equal(hip.upfirdn2d_mask(gy, k4, 1, 1, h, w, False, ref_act, 0.2, 1.4), two)
     assert torch.equal(hip.upfirdn2d_mask(_pitched(gy, (w + 1 + 31) // 32 * 32), k4, 1, 1, h, w, False, ref_act, 0.2, 1.4), two)
+
+
+@pytest.mark.parametrize('shape,noise', [((2, 5, 128, 130), True), ((1, 3, 64, 256), False), ((3, 2, 70, 160), True), ((2, 4, 256, 256), True)])
+def test_upfirdn2d_actbwd_kernel(shape, noise):
+    """gc_upfirdn2d_actbwd_f32 (activation backward + bias / noise sums + Blur adjoint in one pass over the gradient) against
+    gc_bias_act_bwd_reduce_f32 followed by gc_upfirdn2d_f32: the Blur adjoint bit for bit, the sums to fp32 summation order."""
+    hip, _ = _be()
+    gen = torch.Generator().manual_seed(sum(shape) + noise)
+    b, c, h, w = shape
+    k4 = torch.rand(4, 4, generator=gen).to(DEV)
+    gy = torch.randn(b, c, h, w, generator=gen).to(DEV)
+    y = torch.randn(b, c, h, w, generator=gen).to(DEV)
+    nz = torch.randn(b, 1, h, w, generator=gen).to(DEV) if noise else None
+    g_pre, psum, pdot, _ = hip.bias_act_bwd_reduce(gy, y, nz, 0.2, 1.4)
+    ref = hip.upfirdn2d(g_pre, k4, 1, 1, 2, 2, h + 1, w + 1, False).contiguous()
+    gx, ps, pd = hip.upfirdn2d_actbwd(gy, y, nz, k4, 2, 2, h + 1, w + 1, False, 0.2, 1.4)
+    assert torch.equal(gx.contiguous(), ref)
+    assert rel_err(ps.sum(2), psum.sum(2)) < 1e-5 and rel_err(ps.sum((0, 2)), g_pre.double().sum((0, 2, 3))) < 1e-5
+    if noise:
+        assert rel_err(pd.sum(), (g_pre.double() * nz.double()).sum()) < 1e-5
+    else:
+        assert pd is None
+
+
+def test_upsampling_tail_backward_fused_vs_two_launches(bf16x3_mode):
+    """upfirdn2d_bias_act's plain backward through the fused kernel and through the two-launch Functions: same input gradient (bit for bit),
+    same bias / noise-strength gradients (summation order)."""
+    import importlib
+    upmod = importlib.import_module('gan_control_amd.models.op.upfirdn2d')
+    from gan_control_amd.models.op import upfirdn2d_bias_act
+    gen = torch.Generator().manual_seed(5)
+    b, c, h = 2, 6, 129          # a (2H + 1)-wide transposed-convolution output
+    k4 = (torch.rand(4, 4, generator=gen) + 0.1).to(DEV)
+    res = []
+    keep = upmod._FUSE_ACT_BWD
+    try:
+        for fused in (True, False):
+            upmod._FUSE_ACT_BWD = fused
+            gen2 = torch.Generator().manual_seed(6)
+            x = torch.randn(b, c, h, h, generator=gen2).to(DEV).requires_grad_(True)
+            bias = torch.randn(c, generator=gen2).to(DEV).requires_grad_(True)
+            nw = torch.randn(1, generator=gen2).to(DEV).requires_grad_(True)
+            nz = torch.randn(b, 1, h - 1, h - 1, generator=gen2).to(DEV)
+            out = upfirdn2d_bias_act(x, k4, (1, 1), bias, nz, nw)
+            go = torch.randn(out.shape, generator=gen2).to(DEV)
+            res.append(torch.autograd.grad(out, [x, bias, nw], go))
+    finally:
+        upmod._FUSE_ACT_BWD = keep
+    assert torch.equal(res[0][0], res[1][0])
+    assert rel_err(res[0][1], res[1][1]) < 1e-5 and rel_err(res[0][2], res[1][2]) < 1e-5
