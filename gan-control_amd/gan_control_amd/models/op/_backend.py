@@ -93,6 +93,14 @@ class HipBackend:
     # 'f32': exact fp32 MFMA (the parity mode); 'bf16x3': split-bf16 MFMA, ~5e-6 relative error per layer;
     # 'bf16': one bf16 MFMA per product, fp32 accumulate and storage, ~3e-3 per layer (BASELINE config[1]; never the default)
     conv_mode = os.environ.get('GANCONTROL_CONV_PRECISION', 'f32')
+    _conv_plans = {}      # (shape, geometry, mode) -> the library's per-shape answers (see conv2d)
+    _chunks = {}          # plane size -> gc_bias_act_bwd_chunks
+
+    def _bwd_chunks(self, inner):
+        v = self._chunks.get(inner)
+        if v is None:
+            v = self._chunks[inner] = _lib.load().gc_bias_act_bwd_chunks(inner)
+        return v
 
     @staticmethod
     def _guard(dev):
@@ -274,7 +282,7 @@ class HipBackend:
         batch, ch = dy.shape[0], dy.shape[1]
         inner = dy.numel() // (batch * ch)
         lib = _lib.load()
-        chunks = lib.gc_bias_act_bwd_chunks(inner)
+        chunks = self._bwd_chunks(inner)
         dx = torch.empty_like(dy)
         psum = torch.empty((batch, ch, chunks), dtype=dy.dtype, device=dev)
         pdot = torch.empty((batch, ch, chunks), dtype=dy.dtype, device=dev) if noise is not None else None
@@ -300,7 +308,7 @@ class HipBackend:
         batch, ch = y_ref.shape[0], y_ref.shape[1]
         inner = y_ref.numel() // (batch * ch)
         lib = _lib.load()
-        chunks = lib.gc_bias_act_bwd_chunks(inner)
+        chunks = self._bwd_chunks(inner)
         for t in (cs, cd, cw):
             if t is not None and tuple(t.shape) != (batch, ch, chunks):
                 raise RuntimeError('bias_act_bwd_reduce_adjoint: cotangent shape %s, expected %s' % (tuple(t.shape), (batch, ch, chunks)))
@@ -485,7 +493,7 @@ class HipBackend:
         batch, ch = a.shape[0], a.shape[1]
         inner = a.numel() // (batch * ch)
         lib = _lib.load()
-        chunks = lib.gc_bias_act_bwd_chunks(inner)
+        chunks = self._bwd_chunks(inner)
         partial = torch.empty((batch, ch, chunks), dtype=a.dtype, device=dev)
         g = self._guard(dev)
         if g: g.__enter__()
@@ -658,6 +666,17 @@ class HipBackend:
         lib = _lib.load()
         n_out = w_t.shape[3]
         desc = self._desc(x, n_out, geom)
+        mode_id = {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(self.conv_mode, 0)
+        # the library's per-shape answers (packed-weight bytes, split-K bytes, whether / how the output is row-pitched) do not change
+        # between calls: each is asked once per (shape, mode, pitches) -- up to four ctypes round trips less per convolution on the host
+        pkey = (x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom, mode_id)
+
+        def ask(what, fn, *extra):
+            k = (what, pkey, desc.in_pitch, desc.out_pitch)
+            v = self._conv_plans.get(k)
+            if v is None:
+                v = self._conv_plans[k] = fn(desc, *extra)
+            return v
         in_pitch = _lib.row_pitch(x)
         if in_pitch:          # the pitched output of a Blur: the split-bf16 stride-2 kernel reads it in place
             if geom.down == 2 and lib.gc_conv2d_in_pitch_ok(desc, {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(self.conv_mode, 0), 0):
@@ -669,7 +688,7 @@ class HipBackend:
         # (64 -> 32 @512^2: 365 us, 240 us with aligned rows): where the library says so the output is written with a row pitch that is
         # a multiple of 32 floats and handed on as a strided view; its consumers (the Blur that follows, the plane reductions) read the
         # pitch, anything else makes it contiguous.
-        pitch = lib.gc_conv2d_out_pitch(desc, {'f32': 0, 'bf16x3': 1, 'bf16': 2}.get(self.conv_mode, 0)) if (geom.up == 2 and x.shape[0] > 0 and pitch_allowed()) else 0
+        pitch = ask('out_pitch', lib.gc_conv2d_out_pitch, mode_id) if (geom.up == 2 and x.shape[0] > 0 and pitch_allowed()) else 0
         if pitch:
             desc.out_pitch = pitch
             y = torch.empty((x.shape[0], n_out, geom.out_h, pitch), dtype=x.dtype, device=dev)[..., :geom.out_w]
@@ -691,7 +710,7 @@ class HipBackend:
             ep = ctypes.byref(_lib.ConvEpilogue(_lib.ptr(bias), _lib.ptr(noise), _lib.ptr(noise_w), float(slope), float(gain), int(bool(activate)), _lib.ptr(residual)))
         ws = packed = None
         if self.conv_mode in ('bf16x3', 'bf16'):
-            pbytes = lib.gc_conv2d_bf16x3_packed_bytes(desc)
+            pbytes = ask('packed', lib.gc_conv2d_bf16x3_packed_bytes)
             if pbytes:
                 # hi / lo split of the weights: once per (weight, optimiser step) when w_t derives from a parameter (weight_cache.py)
                 def pack():
@@ -699,14 +718,14 @@ class HipBackend:
                     with (self._guard(dev) or contextlib.nullcontext()):
                         _lib.check(lib.gc_conv2d_pack_weights_bf16x3(desc, _lib.ptr(w_t), _lib.ptr(buf), pbytes, _lib.stream_of(w_t)), 'gc_conv2d_pack_weights_bf16x3')
                     return buf
-                packed = weight_cache.derive(w_t, ('pack_bf16x3',), pack, recipe=('pack', tuple(getattr(desc, f) for f, _ in _lib.ConvDesc._fields_)))
-                sbytes = lib.gc_conv2d_bf16x3_splitk_bytes(desc)          # K slices of a small-plane launch
+                packed = weight_cache.derive(w_t, ('pack_bf16x3',), pack, recipe=lambda: ('pack', tuple(getattr(desc, f) for f, _ in _lib.ConvDesc._fields_)))
+                sbytes = ask('splitk', lib.gc_conv2d_bf16x3_splitk_bytes)          # K slices of a small-plane launch
                 ws = torch.empty(sbytes // 4, dtype=torch.float32, device=dev) if sbytes else None
             else:
                 nbytes = lib.gc_conv2d_bf16x3_workspace(desc)
                 ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
         elif self.conv_mode == 'f32':
-            nbytes = lib.gc_conv2d_f32_workspace(desc)          # K slices of a small-plane launch (planes <= 16 px wide), else 0
+            nbytes = ask('f32ws', lib.gc_conv2d_f32_workspace)          # K slices of a small-plane launch (planes <= 16 px wide), else 0
             ws = torch.empty(nbytes // 4, dtype=torch.float32, device=dev) if nbytes else None
         else:
             raise RuntimeError('GANCONTROL_CONV_PRECISION must be f32, bf16x3 or bf16, got %r' % self.conv_mode)
@@ -754,7 +773,10 @@ class HipBackend:
         desc.in_pitch = in_pitch
         lib = _lib.load()
         fast = self.conv_mode in ('bf16x3', 'bf16')
-        nbytes = (lib.gc_conv2d_wgrad_bf16x3_workspace if fast else lib.gc_conv2d_wgrad_workspace)(desc)
+        wkey = ('wgrad_ws', x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom, fast, in_pitch)
+        nbytes = self._conv_plans.get(wkey)
+        if nbytes is None:
+            nbytes = self._conv_plans[wkey] = (lib.gc_conv2d_wgrad_bf16x3_workspace if fast else lib.gc_conv2d_wgrad_workspace)(desc)
         ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
         g = self._guard(dev)
         t0 = self.timer.start('wgrad') if self.timer else None

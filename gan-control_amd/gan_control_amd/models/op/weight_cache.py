@@ -168,6 +168,8 @@ def derive(src, op, make, recipe=None):
     bucket = _roots[rid][2]
     out = bucket.get(key)
     if out is None and recipe is not None:
+        if callable(recipe):             # built on a miss only: the hot path (a hit) pays nothing for it
+            recipe = recipe()
         _recipes.setdefault(rid, {})[key] = recipe
         gid = _group_of.get(rid)
         if BATCHED and gid is not None:
