@@ -53,7 +53,11 @@ stats = {'hit': 0, 'miss': 0, 'bypass': 0, 'batched': 0}
 batch_runner = None   # set by op/_backend.py: () -> callable(kind, items) -> [tensor] of the active backend, or None
 
 
+generation = [0]      # bumped whenever anything is dropped: lets callers keep their own short-cuts over several cached tensors honest
+
+
 def _drop(rid):
+    generation[0] += 1
     entry = _roots.pop(rid, None)
     if entry is not None:
         for t in entry[2].values():

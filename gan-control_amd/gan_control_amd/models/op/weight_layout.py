@@ -14,16 +14,29 @@ from . import weight_cache
 class _Relayout(Function):
     """spec = (taps, k, n, src_stride, dst_shape, dst_stride, flip); strides are for the logical axes (tap, k, n)."""
 
+    _memo = {}      # (storage address, version, cache generation, spec, scale) -> the cached re-layout: the ~100 hits per pass skip the cache's own look-up
+
     @staticmethod
     def forward(ctx, src, spec, scale):
         taps, k, n, src_stride, dst_shape, dst_stride, flip = spec
         ctx.inverse = (taps, k, n, dst_stride, tuple(src.shape), src_stride, flip)
         ctx.scale = scale
+        fast = (src.data_ptr(), src._version, weight_cache.generation[0], spec, scale) if weight_cache.ENABLED else None
+        hit = _Relayout._memo.get(fast) if fast is not None else None
+        if hit is not None:
+            weight_cache.stats['hit'] += 1
+            return hit.detach()
         # once per (weight, optimiser step): the result is cached on the weight's version counter (weight_cache.py); .detach() = a
         # fresh alias for autograd to attach this node to
         key = ('layout', taps, k, n, tuple(src_stride), tuple(dst_shape), tuple(dst_stride), bool(flip), float(scale))
         out = weight_cache.derive(src, key, lambda: _backend.get().weight_layout(src.contiguous(), taps, k, n, src_stride, dst_shape, dst_stride, flip, scale),
                                   recipe=key)
+        if fast is not None and weight_cache._derived.get(out.data_ptr()) is not None:
+            # only what the cache itself holds (a parameter's or a cached tensor's form: both outlive the entry); the generation in the key
+            # retires the entry with the next invalidation
+            if len(_Relayout._memo) > 4096:
+                _Relayout._memo.clear()
+            _Relayout._memo[(fast[0], fast[1], weight_cache.generation[0], spec, scale)] = out
         return out.detach()
 
     @staticmethod
