@@ -261,10 +261,16 @@ int launch(const gc_glin_group* groups, int n_groups, int batch, gc_stream_t str
         if (blocks == 0) continue;
         hipStream_t s = (hipStream_t)stream;
         if (kind == K_FWD) {
-            if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(style_glin_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (lds > 64 * 1024) {
+                static bool done[16] = {false};
+                if (int rc = gc::allow_dynamic_lds(reinterpret_cast<const void*>(style_glin_fwd_kernel), 160 * 1024, done, what)) return rc;
+            }
             hipLaunchKernelGGL(style_glin_fwd_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
         } else if (kind == K_BWD_X) {
-            if (lds > 64 * 1024) hipFuncSetAttribute(reinterpret_cast<const void*>(style_glin_bwd_x_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (lds > 64 * 1024) {
+                static bool done[16] = {false};
+                if (int rc = gc::allow_dynamic_lds(reinterpret_cast<const void*>(style_glin_bwd_x_kernel), 160 * 1024, done, what)) return rc;
+            }
             hipLaunchKernelGGL(style_glin_bwd_x_kernel, dim3((unsigned)blocks), dim3(256), lds, s, a);
         } else {
             hipLaunchKernelGGL(style_glin_bwd_w_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
