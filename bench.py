@@ -146,16 +146,26 @@ def family_table(trainer, it, real, backend, precision, steps, KernelTimer, worl
     from torch.profiler import profile, ProfilerActivity
     tally = KernelTimer(only=None)
     backend.timer = tally
-    with profile(activities=[ProfilerActivity.CUDA]) as prof:
-        for _ in range(steps):
+    done = 0
+    try:
+        with profile(activities=[ProfilerActivity.CUDA]) as prof:
+            for _ in range(steps):
+                trainer.train_iteration(it, real)
+                it += 1
+                done += 1
+            torch.cuda.synchronize()
+        backend.timer = None
+        path = os.path.join(tempfile.mkdtemp(prefix='gc_bench_'), 'trace.json')
+        prof.export_chrome_trace(path)
+        events = json.load(open(path))['traceEvents']
+        os.remove(path)
+    except Exception as e:       # noqa: BLE001 -- a profiler that cannot start (another tracer attached, ...) must not cost the bench line
+        backend.timer = None
+        for _ in range(steps - done):          # the other ranks run the same number of iterations: keep the collectives paired
             trainer.train_iteration(it, real)
             it += 1
-        torch.cuda.synchronize()
-    backend.timer = None
-    path = os.path.join(tempfile.mkdtemp(prefix='gc_bench_'), 'trace.json')
-    prof.export_chrome_trace(path)
-    events = json.load(open(path))['traceEvents']
-    os.remove(path)
+        print('bench.py: family pass skipped (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
+        return None, None, it
     fam = {}
     for e in events:
         if e.get('cat') == 'kernel' and 'dur' in e:
@@ -427,6 +437,8 @@ def main(argv=None, entry=None):
                 it += 1
         barrier()
 
+    if families is None:
+        step_flops = None
     if rank == 0:
         images = args.steps * args.batch_per_gpu * world
         out = {
