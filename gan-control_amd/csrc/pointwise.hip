@@ -21,7 +21,14 @@ struct PwArgs {
     ConvArgs c;
     long long plane;             // pixels per channel plane
     int vec;                     // planes are multiples of 4 pixels and 16-byte aligned
+    // gc_pw_act_dgrad_f32: x is the gradient arriving at a fused bias + leaky-ReLU; it is multiplied by that activation's mask
+    // (in_mask > 0 ? mpos : mneg, in_mask shaped like x) while it is loaded -- no separate activation-backward pass
+    const float* in_mask; float mpos, mneg;
 };
+
+__device__ __forceinline__ float4 mask4(float4 v, float4 m, float pos, float neg) {
+    return make_float4(v.x * (m.x > 0.f ? pos : neg), v.y * (m.y > 0.f ? pos : neg), v.z * (m.z > 0.f ? pos : neg), v.w * (m.w > 0.f ? pos : neg));
+}
 
 template <bool VEC>
 __device__ __forceinline__ float4 ld4(const float* p, long long i, long long n) {
@@ -55,6 +62,11 @@ __global__ __launch_bounds__(256) void pw_narrow_kernel(PwArgs a) {
         float4 v[CHUNK];
 #pragma unroll
         for (int q = 0; q < CHUNK; ++q) v[q] = ld4<VEC>(xb + (size_t)min(k0 + q, p.K - 1) * a.plane, i, a.plane);     // clamped: the scale below is 0 past K
+        if (a.in_mask) {
+            const float* mb = a.in_mask + (size_t)b * p.K * a.plane;
+#pragma unroll
+            for (int q = 0; q < CHUNK; ++q) v[q] = mask4(v[q], ld4<VEC>(mb + (size_t)min(k0 + q, p.K - 1) * a.plane, i, a.plane), a.mpos, a.mneg);
+        }
 #pragma unroll
         for (int q = 0; q < CHUNK; ++q) {
             const int k = min(k0 + q, p.K - 1);
@@ -134,6 +146,9 @@ struct PwWgArgs {
     float* part;
     int B, S, L;
     long long plane; int vec; int groups_per_block; int thin_is_x;
+    // gc_pw_act_wgrad_f32: the wide operand (dy) is multiplied by the activation mask of wide_mask while it is loaded, and thin channel
+    // `ones` (= S - 1 when >= 0) is a plane of ones: its row of the result is the bias gradient sum_p dy_masked
+    const float* wide_mask; float mpos, mneg; int ones;
 };
 
 template <bool VEC>
@@ -158,10 +173,21 @@ __global__ __launch_bounds__(256) void pw_wgrad_kernel(PwWgArgs a) {
             const long long i = g * 4;
             float4 t[MAXS];
 #pragma unroll
-            for (int s = 0; s < MAXS; ++s) t[s] = ld4<VEC>(a.thin + ((size_t)b * a.S + min(s, a.S - 1)) * a.plane, i, a.plane);   // clamped duplicates are never written
+            for (int s = 0; s < MAXS; ++s) {
+                const int real = a.ones >= 0 ? a.S - 1 : a.S;          // thin planes that exist in memory
+                if (a.ones >= 0 && s == a.ones)
+                    t[s] = make_float4(i < a.plane ? 1.f : 0.f, i + 1 < a.plane ? 1.f : 0.f, i + 2 < a.plane ? 1.f : 0.f, i + 3 < a.plane ? 1.f : 0.f);
+                else
+                    t[s] = ld4<VEC>(a.thin + ((size_t)b * real + min(s, real - 1)) * a.plane, i, a.plane);   // clamped duplicates are never written
+            }
             float4 v[CHUNK];
 #pragma unroll
             for (int q = 0; q < CHUNK; ++q) v[q] = ld4<VEC>(a.wide + ((size_t)b * a.L + min(l0 + q, a.L - 1)) * a.plane, i, a.plane);
+            if (a.wide_mask) {
+#pragma unroll
+                for (int q = 0; q < CHUNK; ++q)
+                    v[q] = mask4(v[q], ld4<VEC>(a.wide_mask + ((size_t)b * a.L + min(l0 + q, a.L - 1)) * a.plane, i, a.plane), a.mpos, a.mneg);
+            }
 #pragma unroll
             for (int q = 0; q < CHUNK; ++q)
 #pragma unroll
@@ -236,6 +262,7 @@ int gcconv::pointwise_conv(const gc_conv_desc* d, const float* x, const float* w
     a.c.k_per_split = 0; a.c.part = nullptr;
     a.plane = (long long)d->out_h * d->out_w;
     a.vec = a.plane % 4 == 0 && aligned16(x) && aligned16(y) && (!a.c.noise || aligned16(a.c.noise)) && (!a.c.residual || aligned16(a.c.residual));
+    a.in_mask = nullptr; a.mpos = a.mneg = 1.f;
     const long long groups = (a.plane + 3) / 4;
     dim3 grid((unsigned)((groups + 255) / 256), d->batch);
     hipStream_t s = (hipStream_t)stream;
@@ -264,6 +291,7 @@ int gcconv::pointwise_wgrad(const gc_conv_desc* d, const float* x, const float* 
     a.B = d->batch; a.thin_is_x = thin_is_x ? 1 : 0;
     a.plane = (long long)d->out_h * d->out_w;
     a.vec = a.plane % 4 == 0 && aligned16(x) && aligned16(dy);
+    a.wide_mask = nullptr; a.mpos = a.mneg = 1.f; a.ones = -1;
     a.part = static_cast<float*>(workspace);
     const int blocks = wgrad_blocks(a.plane);
     a.groups_per_block = (int)(((a.plane + 3) / 4 + blocks - 1) / blocks);
@@ -276,4 +304,57 @@ int gcconv::pointwise_wgrad(const gc_conv_desc* d, const float* x, const float* 
     const int kn = d->in_ch * d->out_ch;
     hipLaunchKernelGGL(pw_wgrad_finish_kernel, dim3(kn), dim3(64), 0, s, a.part, dw, blocks * d->batch, kn);
     return gc::check_launch("gc_conv2d_wgrad_f32(pointwise finish)");
+}
+
+// ---- the backward of a fused (3 -> C) 1x1 convolution + bias + leaky-ReLU without a separate activation-backward pass ----------------
+// (the discriminator's FromRGB ConvLayer, gan_model.py:955, 844-890: its output is the largest activation of D, [B, 32, 1024, 1024])
+extern "C" size_t gc_pw_act_wgrad_workspace(int batch, int k, int n, int64_t plane) {
+    if (batch <= 0 || k <= 0 || k >= MAXS || n <= 0 || plane <= 0) return 0;
+    return (size_t)wgrad_blocks(plane) * batch * (k + 1) * n * sizeof(float);
+}
+
+extern "C" int gc_pw_act_wgrad_f32(const float* x, const float* dy, const float* y_ref, float* dw_db, int batch, int k, int n, int64_t plane,
+                                   float slope, float gain, void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    if (!x || !dy || !y_ref || !dw_db) return gc::fail(GC_ERR_BAD_ARG, "gc_pw_act_wgrad_f32: null pointer");
+    if (batch <= 0 || batch > 65535 || k <= 0 || k >= MAXS || n <= 0 || plane <= 0)
+        return gc::fail(GC_ERR_UNSUPPORTED, "gc_pw_act_wgrad_f32: batch %d, %d -> %d channels (at most %d input channels)", batch, k, n, MAXS - 1);
+    const size_t need = gc_pw_act_wgrad_workspace(batch, k, n, plane);
+    if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_pw_act_wgrad_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+    PwWgArgs a;
+    a.thin = x; a.wide = dy; a.st = nullptr; a.sw = nullptr;
+    a.S = k + 1; a.L = n; a.B = batch; a.thin_is_x = 1;
+    a.plane = plane;
+    a.vec = plane % 4 == 0 && aligned16(x) && aligned16(dy) && aligned16(y_ref);
+    a.wide_mask = y_ref; a.mpos = gain; a.mneg = gain * slope; a.ones = k;
+    a.part = static_cast<float*>(workspace);
+    const int blocks = wgrad_blocks(plane);
+    a.groups_per_block = (int)(((plane + 3) / 4 + blocks - 1) / blocks);
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid(blocks, batch, (a.L + CHUNK - 1) / CHUNK);
+    if (a.vec) hipLaunchKernelGGL(pw_wgrad_kernel<true>, grid, dim3(256), 0, s, a);
+    else       hipLaunchKernelGGL(pw_wgrad_kernel<false>, grid, dim3(256), 0, s, a);
+    int rc = gc::check_launch("gc_pw_act_wgrad_f32");
+    if (rc) return rc;
+    const int count = (k + 1) * n;
+    hipLaunchKernelGGL(pw_wgrad_finish_kernel, dim3(count), dim3(64), 0, s, a.part, dw_db, blocks * batch, count);
+    return gc::check_launch("gc_pw_act_wgrad_f32(finish)");
+}
+
+extern "C" int gc_pw_act_dgrad_f32(const float* dy, const float* y_ref, const float* w, float* gx, int batch, int n, int k, int64_t plane,
+                                   float slope, float gain, gc_stream_t stream) {
+    if (!dy || !y_ref || !w || !gx) return gc::fail(GC_ERR_BAD_ARG, "gc_pw_act_dgrad_f32: null pointer");
+    if (batch <= 0 || batch > 65535 || n <= 0 || k <= 0 || k > MAXS || plane <= 0)
+        return gc::fail(GC_ERR_UNSUPPORTED, "gc_pw_act_dgrad_f32: batch %d, %d -> %d channels (at most %d output channels)", batch, n, k, MAXS);
+    PwArgs a;
+    a.c = ConvArgs{dy, w, nullptr, nullptr, gx, batch, n, k, 1, 1, 1, 1, 0, 0, 0, 0};
+    set_epilogue(a.c, nullptr);
+    a.c.k_per_split = 0; a.c.part = nullptr;
+    a.plane = plane;
+    a.vec = plane % 4 == 0 && aligned16(dy) && aligned16(gx) && aligned16(y_ref);
+    a.in_mask = y_ref; a.mpos = gain; a.mneg = gain * slope;
+    const long long groups = (plane + 3) / 4;
+    dim3 grid((unsigned)((groups + 255) / 256), batch);
+    if (a.vec) hipLaunchKernelGGL(pw_narrow_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else       hipLaunchKernelGGL(pw_narrow_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return gc::check_launch("gc_pw_act_dgrad_f32");
 }

@@ -99,6 +99,9 @@ SIGNATURES = {
     'gc_conv2d_wgrad_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_affine_warp_bilinear_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 7 + [_vp]),
     'gc_reflect_pad_f32': (_i32, [_vp, _vp] + [_i32] * 8 + [_vp]),
+    'gc_pw_act_wgrad_workspace': (_sz, [_i32, _i32, _i32, _i64]),
+    'gc_pw_act_wgrad_f32': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _f32, _f32, _vp, _sz, _vp]),
+    'gc_pw_act_dgrad_f32': (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i64, _f32, _f32, _vp]),
     'gc_grouped_linear_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
     'gc_grouped_linear_bwd_x_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),
     'gc_grouped_linear_bwd_w_f32': (_i32, [ctypes.POINTER(GlinGroup), _i32, _i32, _vp]),

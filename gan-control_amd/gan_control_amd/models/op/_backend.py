@@ -235,6 +235,42 @@ class HipBackend:
             self.timer.stop('fir44_tile_kernel', t0, 4.0 * (2 * gy.numel() + gx.numel()))
         return gx, psum, pdot
 
+    # -- backward of a fused (<= 3 -> n) 1x1 convolution + bias + leaky-ReLU (D's FromRGB layer) without an activation-backward pass -------
+    @staticmethod
+    def pw_act_supported(x, dy):
+        """Shapes gc_pw_act_wgrad_f32 / gc_pw_act_dgrad_f32 take, where they pay: a bandwidth-sized plane and at most 3 input channels."""
+        return x.dim() == 4 and x.shape[1] <= 3 and x.shape[0] <= 65535 and dy.shape[2] * dy.shape[3] * dy.shape[0] >= (1 << 18)
+
+    def pw_act_wgrad(self, x, dy, y_ref, slope, gain):
+        """(dw [1, 1, k, n], dbias [n]) of y = lrelu(conv1x1(x, w) + bias) * gain for the gradient dy at y (mask applied while dy is read)."""
+        dev = _lib.require_cuda_f32(x, dy, y_ref)
+        b, k, h, w = x.shape
+        n = dy.shape[1]
+        lib = _lib.load()
+        nbytes = lib.gc_pw_act_wgrad_workspace(b, k, n, h * w)
+        ws = torch.empty(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+        out = torch.empty((k + 1, n), dtype=x.dtype, device=dev)
+        t0 = self.timer.start('wgrad') if self.timer else None
+        with (self._guard(dev) or contextlib.nullcontext()):
+            rc = lib.gc_pw_act_wgrad_f32(_lib.ptr(x), _lib.ptr(dy), _lib.ptr(y_ref), _lib.ptr(out), b, k, n, h * w, float(slope), float(gain),
+                                         _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
+        _lib.check(rc, 'gc_pw_act_wgrad_f32')
+        if t0 is not None:
+            self.timer.stop('wgrad_mfma_kernel(+reduce)', t0, 2.0 * b * k * n * h * w)
+        return out[:k].view(1, 1, k, n), out[k]
+
+    def pw_act_dgrad(self, dy, y_ref, w_adj, slope, gain):
+        """gx [B, k, H, W] = conv1x1(dy * mask(y_ref), w_adj) with w_adj [1, 1, n, k] (the input-gradient weights)."""
+        dev = _lib.require_cuda_f32(dy, y_ref, w_adj)
+        b, n, h, w = dy.shape
+        k = w_adj.shape[3]
+        gx = torch.empty((b, k, h, w), dtype=dy.dtype, device=dev)
+        with (self._guard(dev) or contextlib.nullcontext()):
+            rc = _lib.load().gc_pw_act_dgrad_f32(_lib.ptr(dy), _lib.ptr(y_ref), _lib.ptr(w_adj), _lib.ptr(gx), b, n, k, h * w, float(slope), float(gain),
+                                                 _lib.stream_of(dy))
+        _lib.check(rc, 'gc_pw_act_dgrad_f32')
+        return gx
+
     def bias_act(self, x, bias, noise, noise_w, slope, gain):
         """y = gain * lrelu(x + bias[c] + noise_w * noise[b, :]); x is [B, C, *]."""
         dev = _lib.require_cuda_f32(x, bias, noise, noise_w)

@@ -13,6 +13,8 @@ d_GConv/dx is a _GConv with (up <-> down, flipped taps, swapped channel axes); d
 _WGrad; both derivatives of _WGrad are _GConv's.  Weights travel as w_t = [kh, kw, K, N]
 (correlation order, N contiguous); the layout changes are single fused passes (weight_layout.py).
 """
+import os
+
 import torch
 from torch.autograd import Function
 
@@ -20,6 +22,9 @@ from . import _backend
 from .upfirdn2d import _dense_or_pitched
 from ._backend import ConvGeom
 from .weight_layout import adjoint_layout, kernel_layout
+
+
+_FUSE_PW_ACT = os.environ.get('GANCONTROL_FUSE_PW_ACT', '1') != '0'      # dev knob: 0 = FromRGB's activation backward as a launch of its own
 
 
 def _adjoint_geom(g, in_h, in_w):
@@ -123,6 +128,19 @@ class _GConvAct(Function):
         if gy is None:                      # only the forked copy was used downstream
             return (gfork if ctx.needs_input_grad[0] else None), None, None, None, None, None, None, None
         params = _backend.want_param_grads()
+        be = _backend.get()
+        if (_FUSE_PW_ACT and not ctx.premasked and gfork is None and g.kh == 1 and g.kw == 1 and g.up == 1 and g.down == 1 and g.pad_y == 0
+                and not torch.is_grad_enabled() and not _backend.strict_zeros() and getattr(be, 'pw_act_wgrad', None) is not None
+                and gy.is_contiguous() and out.is_contiguous() and x.is_contiguous() and be.pw_act_supported(x, gy)):
+            # D's FromRGB layer (3 -> C, 1x1, on the largest planes of the network): its activation backward rides in the loads of the
+            # weight-gradient / input-gradient kernels (gc_pw_act_wgrad_f32 / gc_pw_act_dgrad_f32) instead of being a pass of its own
+            if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) and params:
+                gw_, gb_ = be.pw_act_wgrad(x, gy, out, slope, gain)
+                gw = gw_ if ctx.needs_input_grad[1] else None
+                gb = gb_ if ctx.needs_input_grad[2] else None
+            if ctx.needs_input_grad[0]:
+                gx = be.pw_act_dgrad(gy, out, _adjoint_weight(w_t).contiguous(), slope, gain)
+            return gx, gw, gb, None, None, None, None, None
         if ctx.premasked:
             # the only consumer of `out` (upfirdn2d.blur_of_activation) has applied this activation's mask already: gy IS the gradient
             # of the pre-activation

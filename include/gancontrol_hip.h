@@ -405,6 +405,19 @@ typedef struct gc_wpack_group {
 } gc_wpack_group;
 int gc_conv2d_pack_weights_bf16x3_grouped(const gc_wpack_group* groups, int n_groups, gc_stream_t stream);
 
+/* The backward of a fused (k <= 3 -> n) 1x1 convolution + bias + leaky-ReLU -- the discriminator's FromRGB ConvLayer (gan_model.py:955,
+ * 844-890), whose output [B, 32, 1024, 1024] is the largest activation of D -- without a separate activation-backward pass: the gradient dy
+ * that arrives at the activation output is multiplied by the mask (y_ref > 0 ? gain : gain * slope) while it is loaded.
+ *   gc_pw_act_wgrad_f32  dw_db[j, :] = sum_{b,p} x[b, j, p] * dy_masked[b, :, p]  for j < k, and dw_db[k, :] = sum_{b,p} dy_masked[b, :, p]
+ *                        (the weight gradient in [k, n] order followed by the bias gradient; fixed summation order)
+ *   gc_pw_act_dgrad_f32  gx[b, j, p] = sum_i w[i, j] * dy_masked[b, i, p]          w: [n, k] (the input-gradient weights), k <= 4
+ * x: [batch, k, plane], dy / y_ref: [batch, n, plane], gx: [batch, k, plane]; planes dense. */
+size_t gc_pw_act_wgrad_workspace(int batch, int k, int n, int64_t plane);
+int gc_pw_act_wgrad_f32(const float* x, const float* dy, const float* y_ref, float* dw_db, int batch, int k, int n, int64_t plane,
+                        float slope, float gain, void* workspace, size_t workspace_bytes, gc_stream_t stream);
+int gc_pw_act_dgrad_f32(const float* dy, const float* y_ref, const float* w, float* gx, int batch, int n, int k, int64_t plane,
+                        float slope, float gain, gc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Grouped dense layers of the style path: every EqualLinear of one kind in ONE launch.
  *

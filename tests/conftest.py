@@ -111,6 +111,19 @@ class EmulatedBackend:
             at += sp.n
         return gws, gbs
 
+    @staticmethod
+    def pw_act_supported(x, dy):
+        return x.dim() == 4 and x.shape[1] <= 3
+
+    def pw_act_wgrad(self, x, dy, y_ref, slope, gain):
+        g = self.bias_act_bwd(dy, y_ref, slope, gain)
+        dw = torch.einsum('bkp,bnp->kn', x.flatten(2), g.flatten(2))
+        return dw.reshape(1, 1, *dw.shape), g.sum((0, 2, 3))
+
+    def pw_act_dgrad(self, dy, y_ref, w_adj, slope, gain):
+        g = self.bias_act_bwd(dy, y_ref, slope, gain)
+        return torch.einsum('bnp,nk->bkp', g.flatten(2), w_adj[0, 0]).reshape(dy.shape[0], w_adj.shape[3], *dy.shape[2:])
+
     def upfirdn2d_actbwd(self, gy, y_ref, noise, taps, pad_x0, pad_y0, out_h, out_w, flip, slope, gain):
         g_pre = self.bias_act_bwd(gy, y_ref, slope, gain)
         b, c = gy.shape[:2]

@@ -1127,3 +1127,51 @@ def test_upsampling_tail_backward_fused_vs_two_launches(bf16x3_mode):
         upmod._FUSE_ACT_BWD = keep
     assert torch.equal(res[0][0], res[1][0])
     assert rel_err(res[0][1], res[1][1]) < 1e-5 and rel_err(res[0][2], res[1][2]) < 1e-5
+
+
+@pytest.mark.parametrize('shape', [(2, 3, 32, 256, 260), (1, 3, 40, 512, 512), (3, 1, 16, 300, 301), (2, 2, 64, 256, 256)])
+def test_pointwise_activation_backward_kernels(shape):
+    """gc_pw_act_wgrad_f32 / gc_pw_act_dgrad_f32 (FromRGB's backward with the activation mask applied in the loads) against the three
+    launches they replace: activation backward, pointwise weight gradient / input gradient, bias sum."""
+    from gan_control_amd.models.op._backend import ConvGeom
+    hip, emu = _be()
+    b, k, n, h, w = shape
+    gen = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(b, k, h, w, generator=gen).to(DEV)
+    dy = torch.randn(b, n, h, w, generator=gen).to(DEV)
+    y = torch.randn(b, n, h, w, generator=gen).to(DEV)
+    w_adj = torch.randn(1, 1, n, k, generator=gen).to(DEV)
+    assert hip.pw_act_supported(x, dy) == (b * h * w >= (1 << 18))          # the autograd layer only takes this path on bandwidth-sized planes
+    g_pre = hip.bias_act_bwd(dy, y, 0.2, 1.4)
+    dw, db = hip.pw_act_wgrad(x, dy, y, 0.2, 1.4)
+    ref_dw = torch.einsum('bkp,bnp->kn', x.double().flatten(2), g_pre.double().flatten(2))
+    assert dw.shape == (1, 1, k, n) and rel_err(dw[0, 0], ref_dw) < 1e-5
+    assert rel_err(db, g_pre.double().sum((0, 2, 3))) < 1e-5
+    gx = hip.pw_act_dgrad(dy, y, w_adj, 0.2, 1.4)
+    geom = ConvGeom(1, 1, 1, 1, 0, 0, h, w)
+    assert rel_err(gx, hip.conv2d(g_pre, w_adj, None, None, geom)) < 1e-6
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
+def test_from_rgb_backward_fused_vs_three_launches(mode):
+    """D's first layer through _GConvAct.backward with and without the fused pointwise path: same gradients."""
+    from gan_control_amd.models.op import conv2d_gradfix
+    hip, _ = _be()
+    prev, hip.conv_mode = hip.conv_mode, mode
+    keep = conv2d_gradfix._FUSE_PW_ACT
+    try:
+        res = []
+        for fused in (True, False):
+            conv2d_gradfix._FUSE_PW_ACT = fused
+            gen = torch.Generator().manual_seed(2)
+            x = torch.randn(2, 3, 512, 512, generator=gen).to(DEV).requires_grad_(True)
+            wt = (torch.randn(32, 3, 1, 1, generator=gen) * 0.5).to(DEV).requires_grad_(True)
+            bias = torch.randn(32, generator=gen).to(DEV).requires_grad_(True)
+            out = conv2d_gradfix.conv2d_bias_act(x, wt, bias, weight_scale=0.57)
+            go = torch.randn(out.shape, generator=gen).to(DEV)
+            res.append(torch.autograd.grad(out, [x, wt, bias], go))
+        for a, c in zip(*res):
+            assert rel_err(a, c) < 1e-5
+    finally:
+        conv2d_gradfix._FUSE_PW_ACT = keep
+        hip.conv_mode = prev
