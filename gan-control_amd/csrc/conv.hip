@@ -471,26 +471,51 @@ __global__ __launch_bounds__(256, 2) void wgrad_mfma_kernel(WgradArgs p) {
     }
 }
 
-// dw[i] = sum_s ws[s][i] in fixed order; count is a multiple of 4 when VEC (16-byte loads, 8 in flight per lane)
-template <bool VEC>
+// dw[i] = sum_s ws[s][i] in a fixed order; count is a multiple of 4 when VEC (16-byte loads, 8 in flight per lane).
+// JG > 1: a small weight tensor split over many pixel splits (32 x 32 x 9 floats x 512 splits at 1024^2) would be a handful of workgroups
+// each walking hundreds of dependent-latency loads; there 256 / JG lanes own an element group and JG lane groups each sum every JG-th
+// split, added through LDS in group order.
+__device__ __forceinline__ float4 add4(float4 a, float4 b) { return make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w); }
+
+template <int JG>
+__device__ __forceinline__ float4 sum_parts4(const float* __restrict__ base, size_t count, size_t i, int parts, int jg) {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = jg;
+    for (; s + 7 * JG < parts; s += 8 * JG) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(base + (size_t)(s + u * JG) * count)[i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc = add4(acc, v[u]);
+    }
+    for (; s < parts; s += JG) acc = add4(acc, reinterpret_cast<const float4*>(base + (size_t)s * count)[i]);
+    return acc;
+}
+
+// the JG partial sums of one element group, added in group order by the lanes of group 0 (all 256 lanes call this)
+template <int JG>
+__device__ __forceinline__ float4 join_groups(float4 acc, float4* red, int il, int jg) {
+    if (JG == 1) return acc;
+    __syncthreads();
+    red[jg * (256 / JG) + il] = acc;
+    __syncthreads();
+    float4 tot = red[il];
+#pragma unroll
+    for (int g = 1; g < JG; ++g) tot = add4(tot, red[g * (256 / JG) + il]);
+    return tot;
+}
+
+template <bool VEC, int JG>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, size_t count, int parts) {
     if (VEC) {
+        __shared__ float4 red[JG == 1 ? 1 : 256];
+        constexpr int IL = 256 / JG;
+        const int il = threadIdx.x % IL, jg = threadIdx.x / IL;
         const size_t n4 = count / 4;
-        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            int s = 0;
-            for (; s + 8 <= parts; s += 8) {
-                float4 v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = reinterpret_cast<const float4*>(ws + (size_t)(s + u) * count)[i];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
-            }
-            for (; s < parts; ++s) {
-                const float4 v = reinterpret_cast<const float4*>(ws + (size_t)s * count)[i];
-                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
-            }
-            reinterpret_cast<float4*>(dw)[i] = acc;
+        for (size_t i0 = (size_t)blockIdx.x * IL; i0 < n4; i0 += (size_t)gridDim.x * IL) {       // uniform trip count: the barriers inside are safe
+            const size_t i = i0 + il;
+            const float4 acc = join_groups<JG>(i < n4 ? sum_parts4<JG>(ws, count, i, parts, jg) : make_float4(0.f, 0.f, 0.f, 0.f), red, il, jg);
+            if (jg == 0 && i < n4) reinterpret_cast<float4*>(dw)[i] = acc;
         }
     } else {
         for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
@@ -498,6 +523,86 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             for (int s = 0; s < parts; ++s) acc += ws[(size_t)s * count + i];
             dw[i] = acc;
         }
+    }
+}
+
+// Partial sums grouped by sample, ws[b][j][i]: samples[b][i] = sum_j ws[b][j][i] and dw[i] = sum_b samples[b][i], both in fixed order.
+template <bool VEC, int JG>
+__global__ __launch_bounds__(256) void wgrad_reduce_samples_kernel(const float* __restrict__ ws, float* __restrict__ dw, float* __restrict__ samples,
+                                                                   size_t count, int batch, int per_sample) {
+    if (VEC) {
+        __shared__ float4 red[JG == 1 ? 1 : 256];
+        constexpr int IL = 256 / JG;
+        const int il = threadIdx.x % IL, jg = threadIdx.x / IL;
+        const size_t n4 = count / 4;
+        for (size_t i0 = (size_t)blockIdx.x * IL; i0 < n4; i0 += (size_t)gridDim.x * IL) {
+            const size_t i = i0 + il;
+            float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int b = 0; b < batch; ++b) {
+                const float* base = ws + (size_t)b * per_sample * count;
+                const float4 acc = join_groups<JG>(i < n4 ? sum_parts4<JG>(base, count, i, per_sample, jg) : make_float4(0.f, 0.f, 0.f, 0.f), red, il, jg);
+                if (jg == 0 && i < n4) reinterpret_cast<float4*>(samples + (size_t)b * count)[i] = acc;
+                tot = add4(tot, acc);
+            }
+            if (jg == 0 && i < n4) reinterpret_cast<float4*>(dw)[i] = tot;
+        }
+    } else {
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) {
+            float tot = 0.f;
+            for (int b = 0; b < batch; ++b) {
+                float acc = 0.f;
+                for (int j = 0; j < per_sample; ++j) acc += ws[((size_t)b * per_sample + j) * count + i];
+                samples[(size_t)b * count + i] = acc;
+                tot += acc;
+            }
+            dw[i] = tot;
+        }
+    }
+}
+
+// gc_wgrad_samples_contract_f32, first pass: one workgroup per (a, b); lane c sums w * s over the taps, writes colpart[b][a][c] when the
+// C-side result is wanted, and the workgroup adds its lanes in a fixed tree: g_a[b][a] = sum_{t,c} w[t][a][c] s[b][t][a][c] / sa[b][a].
+__global__ __launch_bounds__(256) void wgrad_contract_rows_kernel(const float* __restrict__ s, const float* __restrict__ w, const float* __restrict__ sa,
+                                                                   float* __restrict__ g_a, float* __restrict__ colpart, int taps, int A, int C) {
+    __shared__ float red[4];
+    const int a = blockIdx.x, b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t count = (size_t)taps * A * C;
+    const float* sb = s + (size_t)b * count;
+    float row = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float p = 0.f;
+        for (int t = 0; t < taps; ++t) {
+            const size_t e = ((size_t)t * A + a) * C + c;
+            p = fmaf(w[e], sb[e], p);
+        }
+        if (colpart) colpart[((size_t)b * A + a) * C + c] = p;
+        row += p;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) row += __shfl_down(row, o, 64);
+    if (lane == 0) red[wave] = row;
+    __syncthreads();
+    if (threadIdx.x == 0 && g_a) {
+        const float sum = (red[0] + red[1]) + (red[2] + red[3]);
+        const float den = sa ? sa[(size_t)b * A + a] : 1.f;
+        g_a[(size_t)b * A + a] = sum / (den == 0.f ? 1.f : den);        // zero-safe like rows_sum_div_kernel
+    }
+}
+
+// second pass: g_c[b][c] = sum_a colpart[b][a][c] / sc[b][c]; 64 columns x 4 interleaved row groups per workgroup, groups added in fixed order
+__global__ __launch_bounds__(256) void wgrad_contract_cols_kernel(const float* __restrict__ colpart, const float* __restrict__ sc, float* __restrict__ g_c, int A, int C) {
+    __shared__ float red[4][64];
+    const int lane = threadIdx.x & 63, part = threadIdx.x >> 6, b = blockIdx.y;
+    const int c = blockIdx.x * 64 + lane;
+    float acc = 0.f;
+    if (c < C)
+        for (int a = part; a < A; a += 4) acc += colpart[((size_t)b * A + a) * C + c];
+    red[part][lane] = acc;
+    __syncthreads();
+    if (part == 0 && c < C) {
+        const float sum = (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+        const float den = sc ? sc[(size_t)b * C + c] : 1.f;
+        g_c[(size_t)b * C + c] = sum / (den == 0.f ? 1.f : den);
     }
 }
 
@@ -874,7 +979,7 @@ extern "C" int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const 
     const WgradPlan pl = plan_wgrad(d);
     const size_t need = gc_conv2d_wgrad_workspace(d);
     if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_f32: workspace %zu < %zu bytes", workspace_bytes, need);
-    if (pointwise_thin_wgrad(d)) return pointwise_wgrad(d, x, dy, in_scale, out_scale, dw, workspace, stream);
+    if (pointwise_thin_wgrad(d)) return pointwise_wgrad(d, x, dy, in_scale, out_scale, dw, nullptr, workspace, stream);
     WgradArgs a{x, dy, in_scale, out_scale, pl.parts == 1 ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w,
                 d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split};
     if (d->kh == 3) rc = d->down == 2 ? dispatch_wgrad<2, 3>(a, pl, s) : dispatch_wgrad<1, 3>(a, pl, s);
@@ -884,10 +989,69 @@ extern "C" int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const 
     return launch_wgrad_reduce(static_cast<const float*>(workspace), dw, count, pl.parts, s);
 }
 
+// lane groups per element group (see wgrad_reduce_kernel): only where the tensor alone cannot fill the chip and there are splits to share out
+static int reduce_groups(size_t n4, int parts) {
+#ifdef GC_REDUCE_FLAT       // A/B build: one lane per element group everywhere (the round-2 reduce)
+    return 1;
+#endif
+    if (n4 >= 256 * 256 || parts < 16) return 1;
+    return parts >= 64 ? 16 : 4;
+}
+
 int gcconv::launch_wgrad_reduce(const float* ws, float* dw, size_t count, int parts, hipStream_t s) {
     const bool vec = count % 4 == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
-    const int blocks = (int)std::min<size_t>(((vec ? count / 4 : count) + 255) / 256, 2048);
-    if (vec) hipLaunchKernelGGL(wgrad_reduce_kernel<true>, dim3(blocks), dim3(256), 0, s, ws, dw, count, parts);
-    else     hipLaunchKernelGGL(wgrad_reduce_kernel<false>, dim3(blocks), dim3(256), 0, s, ws, dw, count, parts);
+    const int jg = vec ? reduce_groups(count / 4, parts) : 1;
+    const size_t per_block = vec ? 256 / jg : 256;
+    const int blocks = (int)std::min<size_t>(((vec ? count / 4 : count) + per_block - 1) / per_block, 2048);
+    if (!vec)         hipLaunchKernelGGL((wgrad_reduce_kernel<false, 1>), dim3(blocks), dim3(256), 0, s, ws, dw, count, parts);
+    else if (jg == 1) hipLaunchKernelGGL((wgrad_reduce_kernel<true, 1>), dim3(blocks), dim3(256), 0, s, ws, dw, count, parts);
+    else if (jg == 4) hipLaunchKernelGGL((wgrad_reduce_kernel<true, 4>), dim3(blocks), dim3(256), 0, s, ws, dw, count, parts);
+    else              hipLaunchKernelGGL((wgrad_reduce_kernel<true, 16>), dim3(blocks), dim3(256), 0, s, ws, dw, count, parts);
     return gc::check_launch("gc_conv2d_wgrad(reduce)");
+}
+
+int gcconv::launch_wgrad_reduce_samples(const float* ws, float* dw, float* samples, size_t count, int batch, int per_sample, hipStream_t s) {
+    const bool vec = count % 4 == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 &&
+                     (reinterpret_cast<uintptr_t>(samples) & 15) == 0;
+    const int jg = vec ? reduce_groups(count / 4, per_sample) : 1;
+    const size_t per_block = vec ? 256 / jg : 256;
+    const int blocks = (int)std::min<size_t>(((vec ? count / 4 : count) + per_block - 1) / per_block, 2048);
+    if (!vec)         hipLaunchKernelGGL((wgrad_reduce_samples_kernel<false, 1>), dim3(blocks), dim3(256), 0, s, ws, dw, samples, count, batch, per_sample);
+    else if (jg == 1) hipLaunchKernelGGL((wgrad_reduce_samples_kernel<true, 1>), dim3(blocks), dim3(256), 0, s, ws, dw, samples, count, batch, per_sample);
+    else if (jg == 4) hipLaunchKernelGGL((wgrad_reduce_samples_kernel<true, 4>), dim3(blocks), dim3(256), 0, s, ws, dw, samples, count, batch, per_sample);
+    else              hipLaunchKernelGGL((wgrad_reduce_samples_kernel<true, 16>), dim3(blocks), dim3(256), 0, s, ws, dw, samples, count, batch, per_sample);
+    return gc::check_launch("gc_conv2d_wgrad_samples(reduce)");
+}
+
+// fp32 arithmetic: only the thin 1x1 shapes (ToRGB / FromRGB class) have a per-sample form; gc_conv2d_wgrad_samples_workspace(d, 0) says which
+extern "C" int gc_conv2d_wgrad_samples_f32(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale,
+                                           float* dw, float* dw_samples, void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    int rc = validate(d, "gc_conv2d_wgrad_samples_f32", true);
+    if (rc) return rc;
+    if (!x || !dy || !dw || !dw_samples) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_wgrad_samples_f32: null pointer");
+    if (d->batch <= 0 || !pointwise_thin_wgrad(d) || (d->in_pitch != 0 && d->in_pitch != d->in_w))
+        return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_samples_f32: only dense 1x1 shapes with <= 4 channels on one side (gc_conv2d_wgrad_samples_workspace() == 0 otherwise)");
+    const size_t need = pointwise_wgrad_workspace(d);
+    if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_samples_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+    return pointwise_wgrad(d, x, dy, in_scale, out_scale, dw, dw_samples, workspace, stream);
+}
+
+extern "C" size_t gc_wgrad_samples_contract_workspace(int batch, int a, int c) {
+    return batch > 0 && a > 0 && c > 0 ? (size_t)batch * a * c * sizeof(float) : 0;
+}
+
+extern "C" int gc_wgrad_samples_contract_f32(const float* dw_samples, const float* w, const float* scale_a, const float* scale_c, float* g_a, float* g_c,
+                                             int batch, int taps, int a, int c, void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    if (!dw_samples || !w || (!g_a && !g_c)) return gc::fail(GC_ERR_BAD_ARG, "gc_wgrad_samples_contract_f32: null pointer");
+    if (batch < 0 || batch > 65535 || taps <= 0 || a <= 0 || c <= 0) return gc::fail(GC_ERR_BAD_ARG, "gc_wgrad_samples_contract_f32: batch %d, taps %d, %d x %d", batch, taps, a, c);
+    if (batch == 0) return GC_OK;
+    const size_t need = g_c ? gc_wgrad_samples_contract_workspace(batch, a, c) : 0;
+    if (g_c && (!workspace || workspace_bytes < need)) return gc::fail(GC_ERR_WORKSPACE, "gc_wgrad_samples_contract_f32: workspace %zu < %zu bytes", workspace_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    float* colpart = g_c ? static_cast<float*>(workspace) : nullptr;
+    hipLaunchKernelGGL(wgrad_contract_rows_kernel, dim3(a, batch), dim3(256), 0, s, dw_samples, w, scale_a, g_a, colpart, taps, a, c);
+    int rc = gc::check_launch("gc_wgrad_samples_contract_f32(rows)");
+    if (rc || !g_c) return rc;
+    hipLaunchKernelGGL(wgrad_contract_cols_kernel, dim3(gc::ceil_div(c, 64), batch), dim3(256), 0, s, colpart, scale_c, g_c, a, c);
+    return gc::check_launch("gc_wgrad_samples_contract_f32(columns)");
 }

@@ -813,6 +813,7 @@ struct WgArgs {
     int B, K, N, in_h, in_w, out_h, out_w, pad_y, pad_x;
     int tiles_x, tiles_y, tiles_per_split;
     int x_pitch;          // floats between the rows of x (wgrad_bf16x3_s2_kernel; in_w when dense)
+    int spb;              // > 0: per-sample mode -- split z works on sample z / spb only (its tiles spb apart), so ws[z] is a partial sum of ONE sample
 };
 
 __device__ __forceinline__ uint4 shift_px(const uint4 a, const uint4 b, int tx) {
@@ -885,9 +886,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
     const int total_tiles = tiles_per_sample * p.B;
     // GC_WG_STRIDED: tiles run ACROSS the rows and the tiles of one split are gridDim.z apart, so the resident workgroups read a band
     // of neighbouring rows (contiguous in DRAM, halo rows shared through L2) instead of one 32-column strip each, all over the batch.
-    const int tstep = GC_WG_STRIDED ? (int)gridDim.z : 1;
-    const int t_begin = GC_WG_STRIDED ? split : split * p.tiles_per_split;
-    const int t_end = GC_WG_STRIDED ? total_tiles : min(total_tiles, t_begin + p.tiles_per_split);
+    const int sb = p.spb ? split / p.spb : 0;        // per-sample mode (gc_conv2d_wgrad_samples_*): the splits of one sample walk that sample's tiles only
+    const int tstep = p.spb ? p.spb : (GC_WG_STRIDED ? (int)gridDim.z : 1);
+    const int t_begin = p.spb ? sb * tiles_per_sample + (split - sb * p.spb) : (GC_WG_STRIDED ? split : split * p.tiles_per_split);
+    const int t_end = p.spb ? (sb + 1) * tiles_per_sample : (GC_WG_STRIDED ? total_tiles : min(total_tiles, t_begin + p.tiles_per_split));
     const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
 
     // Staging is kept LEAN: with two workgroups per CU the vector ALUs (index arithmetic, masks, conversions), not the
@@ -1134,9 +1136,10 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
 
     const int tiles_per_sample = p.tiles_x * p.tiles_y;
     const int total_tiles = tiles_per_sample * p.B;
-    const int tstep = GC_WG2_STRIDED ? (int)gridDim.z : 1;
-    const int t_begin = GC_WG2_STRIDED ? split : split * p.tiles_per_split;
-    const int t_end = GC_WG2_STRIDED ? total_tiles : min(total_tiles, t_begin + p.tiles_per_split);
+    const int sb = p.spb ? split / p.spb : 0;
+    const int tstep = p.spb ? p.spb : (GC_WG2_STRIDED ? (int)gridDim.z : 1);
+    const int t_begin = p.spb ? sb * tiles_per_sample + (split - sb * p.spb) : (GC_WG2_STRIDED ? split : split * p.tiles_per_split);
+    const int t_end = p.spb ? (sb + 1) * tiles_per_sample : (GC_WG2_STRIDED ? total_tiles : min(total_tiles, t_begin + p.tiles_per_split));
     const int xchan = p.in_h * p.x_pitch, ychan = p.out_h * p.out_w;
     const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
 
@@ -1803,6 +1806,7 @@ size_t splitk_bytes(const gc_conv_desc* d) {
 // the plain-bf16 build shares the queries, the weight pack (its lo half is simply not read) and the workspace layout of the split build
 #define gc_conv2d_fused_bf16x3_packed_f32 gc_conv2d_fused_bf16_packed_f32
 #define gc_conv2d_wgrad_bf16x3_f32 gc_conv2d_wgrad_bf16_f32
+#define gc_conv2d_wgrad_samples_bf16x3_f32 gc_conv2d_wgrad_samples_bf16_f32
 #else
 extern "C" size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d) {
     if (!d || d->in_ch <= 0 || d->out_ch <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
@@ -1962,22 +1966,31 @@ extern "C" size_t gc_conv2d_wgrad_bf16x3_workspace(const gc_conv_desc* d) {
 }
 #endif
 
-extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* dy,
-                                          const float* in_scale, const float* out_scale, float* dw,
-                                          void* workspace, size_t workspace_bytes, gc_stream_t stream) {
-    int rc = validate(d, "gc_conv2d_wgrad_bf16x3_f32", true);
-    if (rc) return rc;
-    if (!x || !dy || !dw) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_wgrad_bf16x3_f32: null pointer");
-    if (d->in_pitch != 0 && d->in_pitch != d->in_w && !(wg_eligible(d) && d->down == 2))
-        return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_bf16x3_f32: in_pitch %d: only the split-bf16 stride-2 kernel reads pitched rows (gc_conv2d_in_pitch_ok)", d->in_pitch);
-    if (d->batch == 0 || !wg_eligible(d)) return gc_conv2d_wgrad_f32(d, x, dy, in_scale, out_scale, dw, workspace, workspace_bytes, stream);
-    const WgPlan pl = plan_wg(d);
+namespace {
+
+// per-sample mode: the pixel splits of plan_wg regrouped as B x spb, every split inside one sample
+WgPlan plan_wg_samples(const gc_conv_desc* d) {
+    WgPlan pl = plan_wg(d);
+    const int per_sample = pl.tiles_x * pl.tiles_y;
+    const int ctiles = gc::ceil_div(d->in_ch, pl.kt) * gc::ceil_div(d->out_ch, pl.ct);
+    int spb = gc::ceil_div(gc::ceil_div(512, ctiles), d->batch);
+    spb = std::max(1, std::min(spb, per_sample));
+    pl.tiles_per_split = gc::ceil_div(per_sample, spb);
+    pl.splits = spb * d->batch;
+    return pl;
+}
+
+// dw_samples == nullptr: dw = the sum over the batch (gc_conv2d_wgrad_bf16x3_f32); else also dw_samples[b] = sample b's share of it
+int wgrad_launch(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale, float* dw,
+                 float* dw_samples, void* workspace, size_t workspace_bytes, hipStream_t s, const char* who) {
+    const WgPlan pl = dw_samples ? plan_wg_samples(d) : plan_wg(d);
     const size_t count = (size_t)d->kh * d->kw * d->in_ch * d->out_ch;
     const size_t need = (size_t)pl.splits * count * sizeof(float);
-    if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_bf16x3_f32: workspace %zu < %zu bytes", workspace_bytes, need);
-    hipStream_t s = (hipStream_t)stream;
-    WgArgs a{x, dy, in_scale, out_scale, pl.splits == 1 ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch,
-             d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split, d->in_pitch ? d->in_pitch : d->in_w};
+    const bool direct = pl.splits == 1 && !dw_samples;
+    if (!direct && (!workspace || workspace_bytes < need)) return gc::fail(GC_ERR_WORKSPACE, "%s: workspace %zu < %zu bytes", who, workspace_bytes, need);
+    WgArgs a{x, dy, in_scale, out_scale, direct ? dw : static_cast<float*>(workspace), d->batch, d->in_ch, d->out_ch,
+             d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split, d->in_pitch ? d->in_pitch : d->in_w,
+             dw_samples ? pl.splits / d->batch : 0};
     dim3 grid(gc::ceil_div(d->in_ch, pl.kt), gc::ceil_div(d->out_ch, pl.ct), pl.splits);
     if (d->down == 2) {
         if (pl.kt == 32) {
@@ -1987,7 +2000,7 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
             if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 3, 2>), grid, dim3(256), 0, s, a);
             else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 1, 2>), grid, dim3(256), 0, s, a);
         } else {
-            return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_bf16x3_f32: no stride-2 kernel for this tile plan");
+            return gc::fail(GC_ERR_UNSUPPORTED, "%s: no stride-2 kernel for this tile plan", who);
         }
     } else if (pl.small) {
         if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<1, 1, 4, 6, 3>), grid, dim3(256), 0, s, a);
@@ -2003,7 +2016,46 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
         if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 3>), grid, dim3(256), 0, s, a);
         else            hipLaunchKernelGGL((wgrad_bf16x3_kernel<2, 2, 1, 2, 1>), grid, dim3(256), 0, s, a);
     }
-    rc = gc::check_launch("gc_conv2d_wgrad_bf16x3_f32");
-    if (rc || pl.splits == 1) return rc;
+    int rc = gc::check_launch(who);
+    if (rc || direct) return rc;
+    if (dw_samples) return launch_wgrad_reduce_samples(static_cast<const float*>(workspace), dw, dw_samples, count, d->batch, pl.splits / d->batch, s);
     return launch_wgrad_reduce(static_cast<const float*>(workspace), dw, count, pl.splits, s);
+}
+
+}  // namespace
+
+extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* dy,
+                                          const float* in_scale, const float* out_scale, float* dw,
+                                          void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    int rc = validate(d, "gc_conv2d_wgrad_bf16x3_f32", true);
+    if (rc) return rc;
+    if (!x || !dy || !dw) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_wgrad_bf16x3_f32: null pointer");
+    if (d->in_pitch != 0 && d->in_pitch != d->in_w && !(wg_eligible(d) && d->down == 2))
+        return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_bf16x3_f32: in_pitch %d: only the split-bf16 stride-2 kernel reads pitched rows (gc_conv2d_in_pitch_ok)", d->in_pitch);
+    if (d->batch == 0 || !wg_eligible(d)) return gc_conv2d_wgrad_f32(d, x, dy, in_scale, out_scale, dw, workspace, workspace_bytes, stream);
+    return wgrad_launch(d, x, dy, in_scale, out_scale, dw, nullptr, workspace, workspace_bytes, (hipStream_t)stream, "gc_conv2d_wgrad_bf16x3_f32");
+}
+
+#ifndef GC_SINGLE
+extern "C" size_t gc_conv2d_wgrad_samples_workspace(const gc_conv_desc* d, int mode) {
+    if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
+    if (pointwise_thin_wgrad(d)) return pointwise_wgrad_workspace(d);
+    if (mode == 0 || !wg_eligible(d)) return 0;
+    return (size_t)plan_wg_samples(d).splits * d->kh * d->kw * d->in_ch * d->out_ch * sizeof(float);
+}
+#endif
+
+// gc_conv2d_wgrad_samples_bf16x3_f32 / _bf16_f32: the weight gradient AND each sample's share of it (header: what the shares are for)
+extern "C" int gc_conv2d_wgrad_samples_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale,
+                                                  float* dw, float* dw_samples, void* workspace, size_t workspace_bytes, gc_stream_t stream) {
+    int rc = validate(d, "gc_conv2d_wgrad_samples_bf16x3_f32", true);
+    if (rc) return rc;
+    if (!x || !dy || !dw || !dw_samples) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_wgrad_samples_bf16x3_f32: null pointer");
+    if (d->batch == 0) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_samples_bf16x3_f32: empty batch");
+    if (pointwise_thin_wgrad(d)) return gc_conv2d_wgrad_samples_f32(d, x, dy, in_scale, out_scale, dw, dw_samples, workspace, workspace_bytes, stream);
+    if (!wg_eligible(d))
+        return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_samples_bf16x3_f32: shape not taken by the split-bf16 weight-gradient kernels (gc_conv2d_wgrad_samples_workspace() == 0)");
+    if (d->in_pitch != 0 && d->in_pitch != d->in_w && d->down != 2)
+        return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_samples_bf16x3_f32: in_pitch %d: only the stride-2 kernel reads pitched rows", d->in_pitch);
+    return wgrad_launch(d, x, dy, in_scale, out_scale, dw, dw_samples, workspace, workspace_bytes, (hipStream_t)stream, "gc_conv2d_wgrad_samples_bf16x3_f32");
 }

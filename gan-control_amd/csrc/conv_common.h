@@ -151,7 +151,7 @@ int pointwise_conv(const gc_conv_desc* d, const float* x, const float* w, const 
                    const gc_conv_epilogue* ep, float* y, gc_stream_t stream);
 size_t pointwise_wgrad_workspace(const gc_conv_desc* d);
 int pointwise_wgrad(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale,
-                    float* dw, void* workspace, gc_stream_t stream);
+                    float* dw, float* dw_samples, void* workspace, gc_stream_t stream);      // dw_samples: optional [B][K * N] per-sample shares
 
 // defined in conv.hip: the fp32 convolution with an optional workspace (split-K over the input channels on small planes)
 size_t conv2d_f32_workspace(const gc_conv_desc* d);
@@ -163,5 +163,7 @@ int launch_splitk_finish(const ConvArgs& fin, int slices, long long per_slice, h
 
 // defined in conv.hip: dw[i] = sum_s ws[s][i] in fixed order (deterministic split reduction)
 int launch_wgrad_reduce(const float* ws, float* dw, size_t count, int parts, hipStream_t s);
+// the same for partial sums grouped by sample, ws[b][j][i] (j < per_sample): samples[b][i] = sum_j, dw[i] = sum_b samples[b][i]
+int launch_wgrad_reduce_samples(const float* ws, float* dw, float* samples, size_t count, int batch, int per_sample, hipStream_t s);
 
 }  // namespace gcconv

@@ -229,6 +229,22 @@ __global__ __launch_bounds__(64) void pw_wgrad_finish_kernel(const float* __rest
     if (threadIdx.x == 0) dw[e] = s;
 }
 
+// per-sample form: part is ordered [b][block]; samples[b][e] = sum over that sample's blocks, dw[e] = sum_b samples[b][e]
+__global__ __launch_bounds__(64) void pw_wgrad_finish_samples_kernel(const float* __restrict__ part, float* __restrict__ dw, float* __restrict__ samples,
+                                                                     int blocks, int batch, int count) {
+    const int e = blockIdx.x;
+    float tot = 0.f;
+    for (int b = 0; b < batch; ++b) {
+        float s = 0.f;
+        for (int pt = threadIdx.x; pt < blocks; pt += 64) s += part[((size_t)b * blocks + pt) * count + e];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+        if (threadIdx.x == 0) samples[(size_t)b * count + e] = s;
+        tot += s;
+    }
+    if (threadIdx.x == 0) dw[e] = tot;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int wgrad_blocks(long long plane) {
@@ -282,7 +298,7 @@ size_t gcconv::pointwise_wgrad_workspace(const gc_conv_desc* d) {
 }
 
 int gcconv::pointwise_wgrad(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale,
-                            float* dw, void* workspace, gc_stream_t stream) {
+                            float* dw, float* dw_samples, void* workspace, gc_stream_t stream) {
     PwWgArgs a;
     const bool thin_is_x = d->in_ch <= MAXS;
     a.thin = thin_is_x ? x : dy; a.wide = thin_is_x ? dy : x;
@@ -302,7 +318,8 @@ int gcconv::pointwise_wgrad(const gc_conv_desc* d, const float* x, const float* 
     int rc = gc::check_launch("gc_conv2d_wgrad_f32(pointwise)");
     if (rc) return rc;
     const int kn = d->in_ch * d->out_ch;
-    hipLaunchKernelGGL(pw_wgrad_finish_kernel, dim3(kn), dim3(64), 0, s, a.part, dw, blocks * d->batch, kn);
+    if (dw_samples) hipLaunchKernelGGL(pw_wgrad_finish_samples_kernel, dim3(kn), dim3(64), 0, s, a.part, dw, dw_samples, blocks, d->batch, kn);
+    else            hipLaunchKernelGGL(pw_wgrad_finish_kernel, dim3(kn), dim3(64), 0, s, a.part, dw, blocks * d->batch, kn);
     return gc::check_launch("gc_conv2d_wgrad_f32(pointwise finish)");
 }
 

@@ -97,6 +97,12 @@ SIGNATURES = {
     'gc_conv2d_wgrad_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'gc_conv2d_wgrad_bf16x3_workspace': (_sz, [ctypes.POINTER(ConvDesc)]),
     'gc_conv2d_wgrad_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'gc_conv2d_wgrad_samples_workspace': (_sz, [ctypes.POINTER(ConvDesc), _i32]),
+    'gc_conv2d_wgrad_samples_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'gc_conv2d_wgrad_samples_bf16x3_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'gc_conv2d_wgrad_samples_bf16_f32': (_i32, [ctypes.POINTER(ConvDesc), _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'gc_wgrad_samples_contract_workspace': (_sz, [_i32, _i32, _i32]),
+    'gc_wgrad_samples_contract_f32': (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     'gc_affine_warp_bilinear_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 7 + [_vp]),
     'gc_reflect_pad_f32': (_i32, [_vp, _vp] + [_i32] * 8 + [_vp]),
     'gc_pw_act_wgrad_workspace': (_sz, [_i32, _i32, _i32, _i64]),

@@ -829,6 +829,71 @@ class HipBackend:
             self.timer.stop('wgrad_mfma_kernel(+reduce)', t0, conv_flops(x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom))
         return dw
 
+    _MODES = {'f32': 0, 'bf16x3': 1, 'bf16': 2}
+
+    def conv2d_wgrad_samples_bytes(self, x, dy, geom):
+        """Scratch bytes of conv2d_wgrad_samples for these operands in the current arithmetic, 0 = this shape has no per-sample form."""
+        n_out = dy.shape[1]
+        key = ('wgrad_samples_ws', x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom, self.conv_mode)
+        nbytes = self._conv_plans.get(key)
+        if nbytes is None:
+            nbytes = self._conv_plans[key] = _lib.load().gc_conv2d_wgrad_samples_workspace(self._desc(x, n_out, geom), self._MODES.get(self.conv_mode, 0))
+        return nbytes
+
+    def conv2d_wgrad_samples(self, x, dy, in_scale, out_scale, geom):
+        """-> (dw [kh,kw,K,N], dw_samples [B,kh,kw,K,N]): gc_conv2d_wgrad_samples_*; the caller has checked conv2d_wgrad_samples_bytes() > 0."""
+        in_pitch = _lib.row_pitch(x)
+        if in_pitch and geom.down != 2:
+            x, in_pitch = x.contiguous(), 0
+        if _lib.row_pitch(dy):
+            dy = dy.contiguous()
+        dev = _lib.require_cuda_f32(x, dy, in_scale, out_scale, pitched=(x,))
+        n_out = dy.shape[1]
+        nbytes = self.conv2d_wgrad_samples_bytes(x, dy, geom)
+        if nbytes <= 0:
+            raise ValueError('conv2d_wgrad_samples: no per-sample form for this shape (conv2d_wgrad_samples_bytes() == 0)')
+        dw = torch.empty((geom.kh, geom.kw, x.shape[1], n_out), dtype=x.dtype, device=dev)
+        dws = torch.empty((x.shape[0], geom.kh, geom.kw, x.shape[1], n_out), dtype=x.dtype, device=dev)
+        desc = self._desc(x, n_out, geom)
+        desc.in_pitch = in_pitch
+        lib = _lib.load()
+        ws = torch.empty(max(nbytes // 4, 4), dtype=torch.float32, device=dev)
+        fn = {'bf16x3': lib.gc_conv2d_wgrad_samples_bf16x3_f32, 'bf16': lib.gc_conv2d_wgrad_samples_bf16_f32}.get(self.conv_mode, lib.gc_conv2d_wgrad_samples_f32)
+        g = self._guard(dev)
+        t0 = self.timer.start('wgrad') if self.timer else None
+        if g: g.__enter__()
+        try:
+            rc = fn(desc, _lib.ptr(x), _lib.ptr(dy), _lib.ptr(in_scale), _lib.ptr(out_scale), _lib.ptr(dw), _lib.ptr(dws),
+                    _lib.ptr(ws), ws.numel() * 4, _lib.stream_of(x))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_conv2d_wgrad_samples_f32')
+        if t0 is not None:
+            from ...utils.profiling import conv_flops
+            self.timer.stop('wgrad_mfma_kernel(+reduce)', t0, conv_flops(x.shape[0], x.shape[1], n_out, x.shape[2], x.shape[3], geom))
+        return dw, dws
+
+    def wgrad_samples_contract(self, dws, w, scale_a, scale_c, want_a=True, want_c=True):
+        """dws [B,T..,A,C], w [T..,A,C] -> (g_a [B,A] or None, g_c [B,C] or None): gc_wgrad_samples_contract_f32."""
+        dev = _lib.require_cuda_f32(dws, w, scale_a, scale_c)
+        b, a, c = dws.shape[0], dws.shape[-2], dws.shape[-1]
+        taps = w.numel() // (a * c)
+        if dws.numel() != b * w.numel() or not dws.is_contiguous() or not w.is_contiguous():
+            raise ValueError(f'wgrad_samples_contract: shapes {tuple(dws.shape)} / {tuple(w.shape)}')
+        g_a = torch.empty((b, a), dtype=dws.dtype, device=dev) if want_a else None
+        g_c = torch.empty((b, c), dtype=dws.dtype, device=dev) if want_c else None
+        lib = _lib.load()
+        ws = torch.empty(max(b * a * c, 4), dtype=torch.float32, device=dev) if want_c else None
+        g = self._guard(dev)
+        if g: g.__enter__()
+        try:
+            rc = lib.gc_wgrad_samples_contract_f32(_lib.ptr(dws), _lib.ptr(w), _lib.ptr(scale_a), _lib.ptr(scale_c), _lib.ptr(g_a), _lib.ptr(g_c),
+                                                   b, taps, a, c, _lib.ptr(ws), ws.numel() * 4 if ws is not None else 0, _lib.stream_of(dws))
+        finally:
+            if g: g.__exit__(None, None, None)
+        _lib.check(rc, 'gc_wgrad_samples_contract_f32')
+        return g_a, g_c
+
 
 _active = HipBackend()
 weight_cache.batch_runner = lambda: getattr(_active, 'weight_prep_batch', None)

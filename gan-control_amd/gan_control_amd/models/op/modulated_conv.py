@@ -17,8 +17,14 @@ Autograd closure (all orders): with  F(x, w, si, so) = so * gconv(si * x, w)
     dF/dsi  = sum_hw x * (dF/dx) / si ;  dF/dso = sum_hw gy * y / so -> _PlaneDot (+ a [B,C] division)
 
 and both derivatives of _ModWGrad are _ModConv's, so R1 / path-length double-backward close.
+
+First-order shortcut (grad mode off, i.e. nothing will differentiate this backward pass again): dF/dsi and dF/dso are contractions of the
+PER-SAMPLE weight gradient with the weight,  dF/dsi[b,k] = sum_{t,n} w[t,k,n] WG_b[t,k,n] / si[b,k]  (dF/dso alike over k), and the
+weight-gradient kernel can hand out WG_b at no cost (its pixel splits regrouped by sample: gc_conv2d_wgrad_samples_*), so the two
+full-plane products of _PlaneDot are not needed where the planes are large next to the weights (_samples_route).
 """
 import math
+import os
 
 import torch
 from torch.autograd import Function
@@ -28,6 +34,43 @@ from ._backend import ConvGeom
 from .conv2d_gradfix import _adjoint_geom, _adjoint_weight
 from .weight_layout import kernel_layout
 from .upfirdn2d import upfirdn2d, _dense_or_pitched
+
+
+_WGRAD_SAMPLES = int(os.environ.get('GANCONTROL_WGRAD_SAMPLES', '1'))      # 0: off; 1: nodes of the forward pass; 2: also the input-gradient nodes met in a second backward
+_SAMPLES_MIN_RATIO = float(os.environ.get('GANCONTROL_WGRAD_SAMPLES_RATIO', '2'))        # plane bytes the _PlaneDot's would read / bytes the per-sample route writes and re-reads
+
+
+def _samples_route(x, gy, g, want_si, want_so, derived=False):
+    """True where the scale gradients come from the per-sample weight gradient: first-order only (the route is not differentiable),
+    a shape the backend has the per-sample form for, and planes large enough that skipping the plane products pays for writing and
+    reading [B, taps, K, N] (at 512 channels and 64 x 64 pixels it does not)."""
+    if not _WGRAD_SAMPLES or torch.is_grad_enabled() or not (want_si or want_so) or (derived and _WGRAD_SAMPLES < 2):
+        return False
+    be = _backend.get()
+    if not hasattr(be, 'conv2d_wgrad_samples_bytes'):
+        return False
+    saved = 2.0 * ((x.numel() if want_si else 0) + (gy.numel() if want_so else 0))
+    extra = 3.0 * x.shape[0] * g.kh * g.kw * x.shape[1] * gy.shape[1]
+    if saved < _SAMPLES_MIN_RATIO * extra:
+        return False
+    if g.up == 1:
+        return be.conv2d_wgrad_samples_bytes(_dense_or_pitched(x), gy, g) > 0
+    return be.conv2d_wgrad_samples_bytes(_dense_or_pitched(gy), x, _swapped_geom(g, x)) > 0
+
+
+def _weight_and_scale_grads(x, gy, w_t, si, so, g, want_si, want_so):
+    """(gw, gsi, gso) of F = so * gconv(si * x, w_t) from ONE weight-gradient launch (see the module docstring); gsi / gso None if not wanted."""
+    be = _backend.get()
+    cs = lambda t: None if t is None else t.contiguous()
+    if g.up == 1:
+        gw, dws = be.conv2d_wgrad_samples(_dense_or_pitched(x), _dense_or_pitched(gy), cs(si), cs(so), g)
+        gsi, gso = be.wgrad_samples_contract(dws, w_t.contiguous(), cs(si), cs(so), want_si, want_so)
+        return gw, gsi, gso
+    # transposed convolution: the weight gradient is computed with the operands swapped, in the layout of the input-gradient weights
+    # (_mod_weight_grad); the contraction runs in that layout too -- adj(w_t) is what the input-gradient convolution used a moment ago
+    dw_adj, dws = be.conv2d_wgrad_samples(_dense_or_pitched(gy), _dense_or_pitched(x), cs(so), cs(si), _swapped_geom(g, x))
+    gso, gsi = be.wgrad_samples_contract(dws, _adjoint_weight(w_t).contiguous(), cs(so), cs(si), want_so, want_si)
+    return _adjoint_weight(dw_adj), gsi, gso
 
 
 def _wsq_value(w):
@@ -190,7 +233,8 @@ class _ModConv(Function):
     epilogue) instead of by autograd's separate elementwise add over the largest tensors of G."""
 
     @staticmethod
-    def forward(ctx, x, w_t, si, so, geom, bias=None, residual=None, fork=False):
+    def forward(ctx, x, w_t, si, so, geom, bias=None, residual=None, fork=False, derived=False):
+        ctx.derived = derived        # a node of a backward pass (an input-gradient convolution of some other node), not of the network's forward pass
         ep = None
         if bias is not None or residual is not None:
             ep = (bias, None, None, 1.0, 1.0, False, None if residual is None else residual.contiguous())
@@ -215,17 +259,22 @@ class _ModConv(Function):
         need = ctx.needs_input_grad
         gx = gw = gsi = gso = gb = gres = None
         if gy is None:                      # only the forked copy was used downstream (or nothing at all)
-            return (gfork if need[0] else None), None, None, None, None, None, None, None
+            return (gfork if need[0] else None), None, None, None, None, None, None, None, None
         need_si = ctx.has_si and need[2]
-        if need[0] or need_si:
-            gx = _ModConv.apply(gy, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw), None, gfork if need[0] else None)
-        if need[1] and _backend.want_param_grads():
+        need_so = ctx.has_so and need[3]
+        fused = need[1] and _backend.want_param_grads() and _samples_route(x, gy, g, need_si, need_so, ctx.derived)
+        if need[0] or (need_si and not fused):
+            gx = _ModConv.apply(gy, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw), None, gfork if need[0] else None, False, True)
+        if fused:
+            gw, gsi, gso = _weight_and_scale_grads(x, gy, w_t, si, so, g, need_si, need_so)
+            need_si = need_so = False
+        elif need[1] and _backend.want_param_grads():
             gw = _mod_weight_grad(x, gy, si, so, g)
         if need_si:
             # d/dsi sees the convolution only, not the forked gradient that was added in the epilogue
             conv_part = gx if (gfork is None or not need[0]) else gx - gfork
             gsi = _PlaneDot.apply(x, conv_part, si)
-        if ctx.has_so and need[3]:
+        if need_so:
             conv_part = y
             if ctx.has_res:
                 conv_part = conv_part - res
@@ -237,7 +286,7 @@ class _ModConv(Function):
             gb = _channel_sum(gy)
         if ctx.has_res and need[6]:
             gres = gy
-        return (gx if need[0] else None), gw, gsi, gso, None, gb, gres, None
+        return (gx if need[0] else None), gw, gsi, gso, None, gb, gres, None, None
 
 
 class _ModConvAct(Function):
@@ -288,21 +337,27 @@ class _ModConvAct(Function):
         else:
             g_pre = _BiasActGrad.apply(gy, out, slope, gain)
         need_si = has_si and need[2]
-        if need[0] or need_si:
-            gx = _ModConv.apply(g_pre, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw))
-        if need[1]:
+        fused = need[1] and _samples_route(x, g_pre, g, need_si, False)
+        if need[0] or (need_si and not fused):
+            gx = _ModConv.apply(g_pre, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw), None, None, False, True)
+        if fused:
+            gw, gsi, _ = _weight_and_scale_grads(x, g_pre, w_t, si, so, g, True, False)
+        elif need[1]:
             gw = _mod_weight_grad(x, g_pre, si, so, g)
-        if need_si:
+        if need_si and not fused:
             gsi = _PlaneDot.apply(x, gx, si)
         return (gx if need[0] else None), gw, gsi, gso, gb, None, gnw, None, None, None
+
+
+def _swapped_geom(g, x):
+    """The weight gradient of a transposed convolution: correlate gy (as the "input", decimated by `up`) with x (as the "output gradient")."""
+    return ConvGeom(g.kh, g.kw, 1, g.up, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x, x.shape[2], x.shape[3])
 
 
 def _mod_weight_grad(x, gy, si, so, g):
     if g.up == 1:
         return _ModWGrad.apply(x, gy, si, so, g)
-    # transposed conv: correlate gy (as the "input", decimated by `up`) with x (as the "output gradient")
-    swapped = ConvGeom(g.kh, g.kw, 1, g.up, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x, x.shape[2], x.shape[3])
-    return _adjoint_weight(_ModWGrad.apply(gy, x, so, si, swapped))
+    return _adjoint_weight(_ModWGrad.apply(gy, x, so, si, _swapped_geom(g, x)))
 
 
 class _ModWGrad(Function):
@@ -330,9 +385,9 @@ class _ModWGrad(Function):
         need_si = ctx.has_si and ctx.needs_input_grad[2]
         need_so = ctx.has_so and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[0] or need_si:
-            gx = _ModConv.apply(gy, _adjoint_weight(ggw), so, si, _adjoint_geom(g, *ctx.in_hw))
+            gx = _ModConv.apply(gy, _adjoint_weight(ggw), so, si, _adjoint_geom(g, *ctx.in_hw), None, None, False, True)
         if ctx.needs_input_grad[1] or need_so:
-            ggy = _ModConv.apply(x, ggw.contiguous(), si, so, g)
+            ggy = _ModConv.apply(x, ggw.contiguous(), si, so, g, None, None, False, True)
         if need_si:
             gsi = _PlaneDot.apply(x, gx, si)
         if need_so:

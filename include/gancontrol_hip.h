@@ -347,6 +347,40 @@ int gc_conv2d_wgrad_bf16_f32(const gc_conv_desc* d, const float* x, const float*
                              const float* in_scale, const float* out_scale, float* dw,
                              void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
+/* Weight gradient together with each sample's share of it:
+ *
+ *   dw_samples[b,ty,tx,k,n] = in_scale[b,k] * out_scale[b,n] * sum_{oy,ox} x[b,k, oy*down + ty - pad_y, ...] * dy[b,n,oy,ox]
+ *   dw = sum_b dw_samples[b]                                       (both reduced in a fixed order)
+ *
+ * What the shares are for: ModulatedConv2d (gan_model.py:281-331) multiplies its weight by the per-sample style,
+ * `weight = self.scale * self.weight * style` (and by the demodulation factor), so the gradients of those factors are contractions of
+ * the SAME per-sample products with the weight (gc_wgrad_samples_contract_f32 below) -- autograd's route through
+ * aten::convolution_backward of the grouped convolution materialises them per sample as well.  Taking them from here replaces two
+ * full-plane products per layer, sum_p x * dx and sum_p dy * y (gc_plane_dot_f32), by reads of [B, taps, K, N].
+ * The pixel splits of the plain weight gradient are regrouped so that every split stays inside one sample; same kernels, same
+ * arithmetic.  gc_conv2d_wgrad_samples_workspace(): bytes of scratch for `mode` (0 = fp32, 1 = split-bf16, 2 = plain bf16), 0 when
+ * the shape has no per-sample form: fp32 has one for the thin 1x1 shapes only (<= 4 channels on one side: ToRGB), the bf16 modes
+ * additionally for everything their own weight-gradient kernels take (>= 32 channels on both sides, planes >= 4 px wide). */
+size_t gc_conv2d_wgrad_samples_workspace(const gc_conv_desc* d, int mode);
+int gc_conv2d_wgrad_samples_f32(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale,
+                                float* dw, float* dw_samples, void* workspace, size_t workspace_bytes, gc_stream_t stream);
+int gc_conv2d_wgrad_samples_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale,
+                                       float* dw, float* dw_samples, void* workspace, size_t workspace_bytes, gc_stream_t stream);
+int gc_conv2d_wgrad_samples_bf16_f32(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale,
+                                     float* dw, float* dw_samples, void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
+/* The scale gradients from the per-sample shares (w and dw_samples[b] are [taps, a, c], the kernel layout [kh*kw, K, N]):
+ *
+ *   g_a[b,a] = sum_{t,c} w[t,a,c] * dw_samples[b,t,a,c] / scale_a[b,a]          (d loss / d in_scale:  the modulation, gan_model.py:283-284)
+ *   g_c[b,c] = sum_{t,a} w[t,a,c] * dw_samples[b,t,a,c] / scale_c[b,c]          (d loss / d out_scale: the demodulation, gan_model.py:286-288)
+ *
+ * (dw_samples carries both scales as factors; dividing one out leaves the derivative with respect to it.  A scale of exactly 0 divides
+ * by 1, as gc_rows_sum_div_f32 does.)  g_a or g_c may be null, a null scale divides by 1.  Fixed summation order.
+ * workspace: gc_wgrad_samples_contract_workspace(batch, a, c) bytes, needed for g_c only. */
+size_t gc_wgrad_samples_contract_workspace(int batch, int a, int c);
+int gc_wgrad_samples_contract_f32(const float* dw_samples, const float* w, const float* scale_a, const float* scale_c, float* g_a, float* g_c,
+                                  int batch, int taps, int a, int c, void* workspace, size_t workspace_bytes, gc_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Weight re-layout: scale + permute + optional tap mirror in one pass.
  *

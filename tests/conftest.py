@@ -315,6 +315,24 @@ class EmulatedBackend:
             g, = torch.autograd.grad(y, w, dy.detach())
         return g
 
+    # per-sample weight gradients (gc_conv2d_wgrad_samples_* / gc_wgrad_samples_contract_f32): every shape has the form here
+    def conv2d_wgrad_samples_bytes(self, x, dy, geom):
+        return 4
+
+    def conv2d_wgrad_samples(self, x, dy, in_scale, out_scale, geom):
+        per = [self.conv2d_wgrad(x[b:b + 1], dy[b:b + 1], None if in_scale is None else in_scale[b:b + 1],
+                                 None if out_scale is None else out_scale[b:b + 1], geom) for b in range(x.shape[0])]
+        dws = torch.stack(per)
+        return dws.sum(0), dws
+
+    def wgrad_samples_contract(self, dws, w, scale_a, scale_c, want_a=True, want_c=True):
+        b, a, c = dws.shape[0], dws.shape[-2], dws.shape[-1]
+        prod = (dws * w.unsqueeze(0)).reshape(b, -1, a, c)
+        safe = lambda den: torch.where(den == 0, torch.ones_like(den), den)
+        g_a = prod.sum((1, 3)) / (safe(scale_a) if scale_a is not None else 1.0) if want_a else None
+        g_c = prod.sum((1, 2)) / (safe(scale_c) if scale_c is not None else 1.0) if want_c else None
+        return g_a, g_c
+
 
 @pytest.fixture
 def emu_backend():

@@ -393,3 +393,60 @@ def check_resblock_blur_adjoint_fusion(device, size=128, batch=2, tol=1e-5):
         assert (ra[n] is None) == (rb[n] is None), n
         if rb[n] is not None and float(rb[n].abs().max()) > 0:
             assert rel_err(ra[n], rb[n]) <= 10 * tol, n
+
+
+def check_scale_grads_from_sample_wgrad(device, size=64, batch=3, tol=1e-5, pl_tol=None, dtype=torch.float32, thin_only=False, level=1):
+    """The modulation / demodulation gradients taken from the per-sample weight gradient (models/op/modulated_conv.py::_samples_route,
+    gc_conv2d_wgrad_samples_* + gc_wgrad_samples_contract_f32) against the plane-product route: every parameter gradient of a generator
+    backward pass (plain, up-sampling and ToRGB layers all take the route when forced) and of the path-length step's second backward.
+    level 1 (the default of the package): nodes of the forward pass only; level 2: also the input-gradient nodes a second backward meets.
+    In fp64 (CPU emulation) the routes agree to rounding at both levels.  In split-bf16 arithmetic level 2 does NOT hold up in the
+    path-length step: the scale gradient of an input-gradient node cancels exactly against its _PlaneDot partner's (d/dsi of
+    sum_p x * (si * g) / si is zero), which the plane route preserves by reading the same tensor twice and a different arithmetic for one
+    of the two terms does not (tools/samples_route_probe.py: 5.7e-2 against 2.8e-3 on one layer) -- hence level 1."""
+    from gan_control_amd.models import gan_model as gm
+    from gan_control_amd.models.op import modulated_conv as mc
+    from oracle.networks import procedural_fill_
+    torch.manual_seed(0)
+    g = gm.Generator(size, 64, 2, channel_multiplier=2, conv_transpose=True)
+    g.load_state_dict(procedural_fill_(g.state_dict()))
+    g = g.to(device=device, dtype=dtype)
+    gen = torch.Generator().manual_seed(3)
+    z = torch.randn(batch, 64, generator=gen).to(device=device, dtype=dtype)
+    probe = torch.randn(batch, 3, size, size, generator=gen).to(device=device, dtype=dtype)
+    keep = (mc._WGRAD_SAMPLES, mc._SAMPLES_MIN_RATIO)
+    res, taken = {}, {}
+    be = mc._backend.get()
+    orig = be.conv2d_wgrad_samples
+    try:
+        for fused in (True, False):
+            mc._WGRAD_SAMPLES, mc._SAMPLES_MIN_RATIO = (level if fused else 0), 0.0
+            calls = []
+            be.conv2d_wgrad_samples = lambda *a, _c=calls, **k: (_c.append(a[4]), orig(*a, **k))[1]
+            g.zero_grad()
+            img, _ = g([z], randomize_noise=False)
+            (img * probe).sum().backward()
+            plain = {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+            g.zero_grad()
+            img, latents = g([z], return_latents=True, randomize_noise=False)
+            grad, = autograd.grad((img * probe).sum() / size, latents, create_graph=True)
+            grad.pow(2).sum(2).mean(1).sqrt().mean().backward()
+            pl = {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+            res[fused], taken[fused] = (plain, pl), calls
+    finally:
+        mc._WGRAD_SAMPLES, mc._SAMPLES_MIN_RATIO = keep
+        del be.conv2d_wgrad_samples
+    assert not taken[False]
+    kinds = {(geom.kh, geom.up, geom.down) for geom in taken[True]}
+    if thin_only:
+        assert kinds == {(1, 1, 1)}, kinds             # fp32 arithmetic on the GPU: only the ToRGB class has the per-sample form
+    else:
+        assert {(3, 1, 1), (3, 1, 2)} <= kinds, kinds       # plain 3x3 and the swapped form of the up-sampling layers; 1x1 where the backend has the thin form
+    (pa, la), (pb, lb) = res[True], res[False]
+    assert pa.keys() == pb.keys() and la.keys() == lb.keys()
+    for n in pb:
+        assert rel_err(pa[n], pb[n]) <= tol, ('backward', n, rel_err(pa[n], pb[n]))
+    for n in lb:
+        if float(lb[n].abs().max()) > 0:
+            assert rel_err(la[n], lb[n]) <= (pl_tol or 10 * tol), ('path length', n, rel_err(la[n], lb[n]))
+    return kinds

@@ -205,3 +205,8 @@ def test_weight_cache_reuse_and_invalidation(emu_backend):
 
 def test_resblock_blur_adjoint_fusion(emu_backend):
     oc.check_resblock_blur_adjoint_fusion('cpu', size=64, batch=2)
+
+
+@pytest.mark.parametrize('level', [1, 2])
+def test_scale_grads_from_sample_wgrad(level, emu_backend):
+    oc.check_scale_grads_from_sample_wgrad('cpu', size=32, batch=2, tol=1e-10, dtype=torch.float64, level=level)

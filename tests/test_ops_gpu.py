@@ -1175,3 +1175,92 @@ def test_from_rgb_backward_fused_vs_three_launches(mode):
     finally:
         conv2d_gradfix._FUSE_PW_ACT = keep
         hip.conv_mode = prev
+
+
+SAMPLE_WGRAD_CASES = [
+    # b, K, N, h, w, k, down, pad, pitched x
+    (3, 64, 64, 48, 80, 3, 1, 1, False),       # 64k x 64n tiles, stride 1
+    (2, 32, 48, 70, 66, 3, 1, 1, False),       # 32 x 32 tiles of six rows, ragged channel tile
+    (4, 64, 96, 40, 40, 1, 1, 0, False),       # 1 x 1 on the matrix kernels
+    (2, 64, 128, 65, 65, 3, 2, 0, False),      # stride 2, 64k x 64n, one output row per tile
+    (3, 32, 64, 129, 129, 3, 2, 0, True),      # stride 2, 32k x 64n; x row-pitched as the transposed convolution leaves it
+    (5, 64, 64, 6, 6, 3, 1, 1, False),         # fewer tiles per sample than the splits wanted
+    (2, 128, 3, 128, 128, 1, 1, 0, False),     # ToRGB class: thin 1 x 1 on the vector ALUs
+    (2, 3, 64, 128, 128, 1, 1, 0, False),      # FromRGB class
+]
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'bf16', 'f32'])
+@pytest.mark.parametrize('case', SAMPLE_WGRAD_CASES)
+def test_wgrad_samples_kernels(case, mode):
+    """gc_conv2d_wgrad_samples_*: dw is the plain weight gradient, dw_samples[b] the weight gradient of sample b alone, and
+    gc_wgrad_samples_contract_f32 turns the shares into the gradients of the two scales (checked against fp64 and against the
+    plane products the route replaces)."""
+    from gan_control_amd.models.op._backend import ConvGeom
+    hip, emu = _be()
+    b, K, N, h, w, k, down, pad, pitched = case
+    gen = torch.Generator().manual_seed(hash(case) & 0xFFFF)
+    oh, ow = (h + 2 * pad - k) // down + 1, (w + 2 * pad - k) // down + 1
+    geom = ConvGeom(k, k, 1, down, pad, pad, oh, ow)
+    x = torch.randn(b, K, h, w, generator=gen).to(DEV)
+    dy = torch.randn(b, N, oh, ow, generator=gen).to(DEV)
+    si = (torch.randn(b, K, generator=gen) + 1.5).to(DEV)
+    so = (torch.rand(b, N, generator=gen) + 0.5).to(DEV)
+    wt = torch.randn(k, k, K, N, generator=gen).to(DEV)
+    if pitched:
+        pitch = (w + 31) // 32 * 32
+        buf = torch.zeros(b, K, h, pitch, device=DEV)
+        buf[..., :w] = x
+        x = buf[..., :w]
+    prev, hip.conv_mode = hip.conv_mode, mode
+    try:
+        thin = k == 1 and min(K, N) <= 4
+        if mode == 'f32' and not thin:
+            assert hip.conv2d_wgrad_samples_bytes(x, dy, geom) == 0          # fp32 arithmetic: the thin 1 x 1 shapes only
+            with pytest.raises(ValueError):
+                hip.conv2d_wgrad_samples(x, dy, si, so, geom)
+            return
+        assert hip.conv2d_wgrad_samples_bytes(x, dy, geom) > 0
+        tol = 2e-2 if (mode == 'bf16' and not thin) else 5e-5
+        for scales in ((si, so), (None, None), (si, None)):
+            dw, dws = hip.conv2d_wgrad_samples(x, dy, scales[0], scales[1], geom)
+            plain = hip.conv2d_wgrad(x, dy, scales[0], scales[1], geom)
+            assert rel_err(dw, plain) < 1e-5            # same products, the splits grouped differently
+            one = torch.stack([hip.conv2d_wgrad(x[i:i + 1].contiguous(), dy[i:i + 1], None if scales[0] is None else scales[0][i:i + 1],
+                                                None if scales[1] is None else scales[1][i:i + 1], geom) for i in range(b)])
+            assert rel_err(dws, one) < 1e-5
+            assert rel_err(dws.sum(0), dw) < 1e-6
+            ref = emu.conv2d_wgrad(x.double().cpu(), dy.double().cpu(), *[None if t is None else t.double().cpu() for t in scales], geom)
+            assert rel_err(dw, ref) < tol
+            d2, s2 = hip.conv2d_wgrad_samples(x, dy, scales[0], scales[1], geom)
+            assert torch.equal(d2, dw) and torch.equal(s2, dws), 'run-to-run deterministic'
+        dw, dws = hip.conv2d_wgrad_samples(x, dy, si, so, geom)
+        g_a, g_c = hip.wgrad_samples_contract(dws, wt, si, so)
+        prod = dws.double() * wt.double()
+        assert rel_err(g_a, prod.sum((1, 2, 4)) / si.double()) < 1e-5
+        assert rel_err(g_c, prod.sum((1, 2, 3)) / so.double()) < 1e-5
+        only_a, none = hip.wgrad_samples_contract(dws, wt, si, None, True, False)
+        assert none is None and torch.equal(only_a, g_a)
+        zero = si.clone()
+        zero[0, 1] = 0.0                                   # a scale of exactly zero divides by one (gc_rows_sum_div_f32's rule)
+        g0, _ = hip.wgrad_samples_contract(dws, wt, zero, so, True, False)
+        assert torch.equal(g0[0, 1], (g_a * si)[0, 1]) or rel_err(g0[0, 1], (g_a * si)[0, 1]) < 1e-6
+        # ... and they are what the plane products give: d/dsi = sum_p x * (input gradient before its si factor), d/dso = sum_p dy * (y / so)
+        if down == 1:
+            y = hip.conv2d(x.contiguous(), wt, si, None, geom)
+            assert rel_err(g_c, (dy.double() * y.double()).sum((2, 3))) < (5e-2 if mode == 'bf16' else 2e-4)
+    finally:
+        hip.conv_mode = prev
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'f32'])
+def test_scale_grads_from_sample_wgrad(mode):
+    """Generator backward and the path-length step with the modulation / demodulation gradients taken from the per-sample weight
+    gradients against the plane-product route (f32 arithmetic: the ToRGB layers only have the form)."""
+    hip, _ = _be()
+    prev, hip.conv_mode = hip.conv_mode, mode
+    try:
+        kinds = oc.check_scale_grads_from_sample_wgrad(DEV, size=128, batch=3, tol=2e-4, pl_tol=2e-4, thin_only=mode == 'f32')
+        assert (1, 1, 1) in kinds
+    finally:
+        hip.conv_mode = prev
