@@ -19,7 +19,7 @@ from torch.nn import functional as F
 import os
 _FUSE_EPILOGUE = os.environ.get('GANCONTROL_FUSE_EPILOGUE', '1') != '0'   # debugging knob: 0 = convolution and activation as two launches
 _FUSE_BLUR_ADJ = os.environ.get('GANCONTROL_FUSE_BLUR_ADJOINT', '1') != '0'   # ResBlock: Blur adjoint + conv1's activation backward in one pass over the gradient
-_FORK_TORGB = os.environ.get('GANCONTROL_FORK_TORGB', '0') == '1'         # off by default: measured -0.3 % (the in_scale gradient then needs gx - gfork, a pass of its own)
+_FORK_TORGB = os.environ.get('GANCONTROL_FORK_TORGB', '1') == '1'         # round 2: -0.3 % (the in_scale gradient needed gx - gfork, a pass of its own); on since that gradient comes from the per-sample weight gradient (modulated_conv._samples_route): four image-sized adds less per generator backward
 from .op import _backend
 from .op import (FusedLeakyReLU, fused_leaky_relu, upfirdn2d, upfirdn2d_bias_act, conv2d_gradfix, modulated_conv2d,
                  modulated_conv2d_act)

@@ -450,3 +450,40 @@ def check_scale_grads_from_sample_wgrad(device, size=64, batch=3, tol=1e-5, pl_t
         if float(lb[n].abs().max()) > 0:
             assert rel_err(la[n], lb[n]) <= (pl_tol or 10 * tol), ('path length', n, rel_err(la[n], lb[n]))
     return kinds
+
+
+def check_torgb_fork(device, size=64, batch=2, tol=1e-5, pl_tol=None, dtype=torch.float32):
+    """ToRGB handing its input on to the next up-sampling layer (gan_model._FORK_TORGB: the two gradients of a StyledConv output meet in the
+    epilogue of ToRGB's input-gradient kernel) against autograd's own sum: image, every parameter gradient, path-length step."""
+    from gan_control_amd.models import gan_model as gm
+    from oracle.networks import procedural_fill_
+    torch.manual_seed(0)
+    g = gm.Generator(size, 64, 2, channel_multiplier=2, conv_transpose=True)
+    g.load_state_dict(procedural_fill_(g.state_dict()))
+    g = g.to(device=device, dtype=dtype)
+    gen = torch.Generator().manual_seed(4)
+    z = torch.randn(batch, 64, generator=gen).to(device=device, dtype=dtype)
+    probe = torch.randn(batch, 3, size, size, generator=gen).to(device=device, dtype=dtype)
+    keep, res = gm._FORK_TORGB, {}
+    try:
+        for fork in (True, False):
+            gm._FORK_TORGB = fork
+            g.zero_grad()
+            img, _ = g([z], randomize_noise=False)
+            (img * probe).sum().backward()
+            plain = {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+            g.zero_grad()
+            img2, latents = g([z], return_latents=True, randomize_noise=False)
+            grad, = autograd.grad((img2 * probe).sum() / size, latents, create_graph=True)
+            grad.pow(2).sum(2).mean(1).sqrt().mean().backward()
+            res[fork] = (img.detach().clone(), plain, {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None})
+    finally:
+        gm._FORK_TORGB = keep
+    (ia, pa, la), (ib, pb, lb) = res[True], res[False]
+    assert torch.equal(ia, ib)
+    assert pa.keys() == pb.keys() and la.keys() == lb.keys()
+    for n in pb:
+        assert rel_err(pa[n], pb[n]) <= tol, ('backward', n, rel_err(pa[n], pb[n]))
+    for n in lb:
+        if float(lb[n].abs().max()) > 0:
+            assert rel_err(la[n], lb[n]) <= (pl_tol or 10 * tol), ('path length', n, rel_err(la[n], lb[n]))

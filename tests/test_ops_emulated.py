@@ -210,3 +210,7 @@ def test_resblock_blur_adjoint_fusion(emu_backend):
 @pytest.mark.parametrize('level', [1, 2])
 def test_scale_grads_from_sample_wgrad(level, emu_backend):
     oc.check_scale_grads_from_sample_wgrad('cpu', size=32, batch=2, tol=1e-10, dtype=torch.float64, level=level)
+
+
+def test_torgb_fork(emu_backend):
+    oc.check_torgb_fork('cpu', size=32, batch=2, tol=1e-10, dtype=torch.float64)

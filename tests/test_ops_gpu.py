@@ -1264,3 +1264,16 @@ def test_scale_grads_from_sample_wgrad(mode):
         assert (1, 1, 1) in kinds
     finally:
         hip.conv_mode = prev
+
+
+@pytest.mark.parametrize('mode', ['bf16x3', 'f32'])
+def test_torgb_fork(mode):
+    """fp32 storage: the fork moves one addition from an ATen pass into a kernel epilogue and, where the per-sample route is not taken,
+    subtracts it again for the modulation gradient -- rounding-level differences, which the path-length step's cancellation amplifies
+    (5e-3: the size of either variant's own distance from fp64 there, tools/samples_route_probe.py)."""
+    hip, _ = _be()
+    prev, hip.conv_mode = hip.conv_mode, mode
+    try:
+        oc.check_torgb_fork(DEV, size=128, batch=3, tol=2e-4, pl_tol=5e-3)      # 2.4e-5 measured on the 4 x 4 ToRGB (gx - gfork cancels there)
+    finally:
+        hip.conv_mode = prev

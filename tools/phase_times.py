@@ -39,3 +39,12 @@ def issue(fn, n=5):
     torch.cuda.synchronize()
     return min(out)
 print('CPU issue time (ms):', {k: round(issue(f), 2) for k, f in (('d_step', dstep), ('r1', r1), ('g_step', gstep), ('pl', pl))})
+# device-busy time: the sum of the kernel durations of one repetition (torch.profiler); wall - busy = what the host leaves idle
+def busy(fn):
+    from torch.profiler import profile, ProfilerActivity
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        fn(); torch.cuda.synchronize()
+    ev = [e for e in prof.events() if e.device_type == torch.autograd.DeviceType.CUDA]
+    return sum(e.device_time for e in ev) / 1e3, len(ev)
+print('device busy (ms, launches):', {k: tuple(round(v, 2) for v in busy(f)) for k, f in (('d_step', dstep), ('r1', r1), ('g_step', gstep), ('pl', pl))})
