@@ -923,7 +923,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
         const int b = tile / tiles_per_sample;
         const int rem = tile - b * tiles_per_sample;
         const int oy0 = GC_WG_STRIDED ? (rem / p.tiles_x) * TR : (rem % p.tiles_y) * TR, ox0 = GC_WG_STRIDED ? (rem % p.tiles_x) * 32 : (rem / p.tiles_y) * 32;      // see the tile loop
+#if defined(GC_ABL) && (GC_ABL == 4 || GC_ABL == 5)      // dev ablation (wrong results): the patch rows start on the tile's own 128-byte line instead of one pixel left of it
+        const int iy0 = oy0 - p.pad_y, ix0 = ox0;
+#else
         const int iy0 = oy0 - p.pad_y, ix0 = ox0 - p.pad_x;
+#endif
         const int xoff = (k0 * xchan + iy0 * p.in_w + ix0) * 4, yoff = (n0 * ychan + oy0 * p.out_w + ox0) * 4;
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
         const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
@@ -936,7 +940,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             const unsigned d = (unsigned)opaque((int)xdesc[j]);       // opaque: nothing derived from the descriptor may be hoisted out of the tile loop (registers)
             const int r = (int)((d >> 20) & 15u);
             const int lin = (int)((d >> 24) & 63u) * (xchan * 4) + r * (p.in_w * 4) + (int)((d >> 16) & 15u) * 32 + xoff;
+#if defined(GC_ABL) && GC_ABL == 5      // ... and the fifth (halo) unit of every row is not fetched: exactly one 128-byte line per row
+            const unsigned off = ((int)d >= 0 && (unsigned)(iy0 + r) < (unsigned)p.in_h && ((d >> 16) & 15u) < 4u) ? (unsigned)max(lin, 0) : OUTSIDE;
+#else
             const unsigned off = ((int)d >= 0 && (unsigned)(iy0 + r) < (unsigned)p.in_h) ? (unsigned)max(lin, 0) : OUTSIDE;
+#endif
             xreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 0));
             xreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 16));
         }
