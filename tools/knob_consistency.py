@@ -16,7 +16,8 @@ sd = {k: v.detach().double().cpu() for k, v in list(tr.generator.state_dict().it
 torch.save({'sd': sd, 'stats': {k: float(v) for k, v in tr.stats.items() if torch.is_tensor(v) and v.numel() == 1}}, sys.argv[1])
 ''' % REPO
 outs = {}
-OFF = {'GANCONTROL_FUSE_BLUR_ADJOINT': '0', 'GANCONTROL_FUSE_ACT_BWD_BLUR': '0', 'GANCONTROL_FUSED_STYLE': '0', 'GANCONTROL_WEIGHT_BATCH': '0'}
+OFF = {'GANCONTROL_FUSE_BLUR_ADJOINT': '0', 'GANCONTROL_FUSE_ACT_BWD_BLUR': '0', 'GANCONTROL_FUSED_STYLE': '0', 'GANCONTROL_WEIGHT_BATCH': '0',
+       'GANCONTROL_FUSE_PW_ACT': '0', 'GANCONTROL_WGRAD_SAMPLES': '0', 'GANCONTROL_FORK_TORGB': '0'}
 for tag, env in (('on', {}), ('off', OFF), ('on_bf16x3', {'KNOB_MODE': 'bf16x3'}), ('off_bf16x3', dict(OFF, KNOB_MODE='bf16x3'))):
     path = '/tmp/knob_%s.pt' % tag
     subprocess.run([sys.executable, '-c', code, path], check=True, env=dict(os.environ, **env))
