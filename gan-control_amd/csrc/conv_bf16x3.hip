@@ -2048,7 +2048,7 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
 extern "C" size_t gc_conv2d_wgrad_samples_workspace(const gc_conv_desc* d, int mode) {
     if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->kh <= 0 || d->kw <= 0) return 0;
     if (pointwise_thin_wgrad(d)) return pointwise_wgrad_workspace(d);
-    if (mode == 0 || !wg_eligible(d)) return 0;
+    if (mode == 0 || !wg_eligible(d) || d->batch > 16384) return 0;      // the splits are a grid dimension: B x spb <= 65535 with room to spare
     return (size_t)plan_wg_samples(d).splits * d->kh * d->kw * d->in_ch * d->out_ch * sizeof(float);
 }
 #endif
@@ -2061,7 +2061,7 @@ extern "C" int gc_conv2d_wgrad_samples_bf16x3_f32(const gc_conv_desc* d, const f
     if (!x || !dy || !dw || !dw_samples) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_wgrad_samples_bf16x3_f32: null pointer");
     if (d->batch == 0) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_samples_bf16x3_f32: empty batch");
     if (pointwise_thin_wgrad(d)) return gc_conv2d_wgrad_samples_f32(d, x, dy, in_scale, out_scale, dw, dw_samples, workspace, workspace_bytes, stream);
-    if (!wg_eligible(d))
+    if (!wg_eligible(d) || d->batch > 16384)
         return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_samples_bf16x3_f32: shape not taken by the split-bf16 weight-gradient kernels (gc_conv2d_wgrad_samples_workspace() == 0)");
     if (d->in_pitch != 0 && d->in_pitch != d->in_w && d->down != 2)
         return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_samples_bf16x3_f32: in_pitch %d: only the stride-2 kernel reads pitched rows", d->in_pitch);
