@@ -58,9 +58,13 @@ __global__ __launch_bounds__(256) void bias_act_flat_kernel(
     }
 }
 
-// Every block owns ONE contiguous run of BWD_RUN float4 (64 KB per operand): the blocks resident together then stream neighbouring
-// memory (a grid-stride loop has each of them hop through the tensor in 32 MB steps: 4.7 vs 5.5 TB/s on [4, 32, 1024, 1024]).
-constexpr int BWD_RUN = 4096;
+// Every block owns ONE contiguous run of BWD_RUN float4 (16 KB per operand): the blocks resident together then stream neighbouring
+// memory (a grid-stride loop has each of them hop through the tensor in 32 MB steps: 4.7 vs 5.5 TB/s on [4, 32, 1024, 1024]; runs of
+// 64 KB 5.4-5.6 TB/s, of 16 KB 5.75-5.85, of 8 KB 5.7-5.85: same-box A/B at the end of round 3).
+#ifndef GC_BWD_RUN
+#define GC_BWD_RUN 1024
+#endif
+constexpr int BWD_RUN = GC_BWD_RUN;
 template <bool VEC>
 __global__ __launch_bounds__(256) void bias_act_bwd_kernel(
     const float* __restrict__ dy, const float* __restrict__ yref, float* __restrict__ dx, int64_t count, float pos, float neg) {
@@ -313,8 +317,12 @@ __global__ __launch_bounds__(256) void channel_sum_stage2(const float* __restric
 }
 
 inline void channel_sum_plan(int64_t inner, int* chunks, int64_t* chunk_len) {
-    // 16K elements per block keeps the grid >> 256 CUs on the large layers
-    int64_t len = 16384;
+    // 16K elements per block keeps the grid >> 256 CUs on the large layers (end of round 3: 4K-element chunks run the activation-backward
+    // reductions 6-8 % faster in isolation, 5.27 -> 5.63 TB/s on [4, 32, 1024, 1024], and change nothing in the training step: kept at 16K)
+#ifndef GC_SUM_LEN
+#define GC_SUM_LEN 16384
+#endif
+    int64_t len = GC_SUM_LEN;
     int n = (int)gc::ceil_div64(inner, len);
     if (n < 1) n = 1;
     *chunks = n;
