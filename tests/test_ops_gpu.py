@@ -1187,6 +1187,7 @@ SAMPLE_WGRAD_CASES = [
     (5, 64, 64, 6, 6, 3, 1, 1, False),         # fewer tiles per sample than the splits wanted
     (2, 128, 3, 128, 128, 1, 1, 0, False),     # ToRGB class: thin 1 x 1 on the vector ALUs
     (2, 3, 64, 128, 128, 1, 1, 0, False),      # FromRGB class
+    (2, 160, 160, 64, 64, 3, 1, 1, False),     # 57 / 29 splits of a < 256 K-element tensor: the reduce passes with four lane groups per element group
 ]
 
 
