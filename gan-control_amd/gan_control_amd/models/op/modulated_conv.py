@@ -43,7 +43,10 @@ _SAMPLES_MIN_RATIO = float(os.environ.get('GANCONTROL_WGRAD_SAMPLES_RATIO', '2')
 def _samples_route(x, gy, g, want_si, want_so, derived=False):
     """True where the scale gradients come from the per-sample weight gradient: first-order only (the route is not differentiable),
     a shape the backend has the per-sample form for, and planes large enough that skipping the plane products pays for writing and
-    reading [B, taps, K, N] (at 512 channels and 64 x 64 pixels it does not)."""
+    reading [B, taps, K, N] (at 512 channels and 64 x 64 pixels it does not).  At the default level 1 only nodes of the network's FORWARD
+    pass take it: the scale gradient of an input-gradient node (`derived`, met in the path-length step's second backward) cancels exactly
+    against its _PlaneDot partner's, which only the plane route -- the same tensor read on both sides -- preserves in split-bf16
+    arithmetic (tools/samples_route_probe.py)."""
     if not _WGRAD_SAMPLES or torch.is_grad_enabled() or not (want_si or want_so) or (derived and _WGRAD_SAMPLES < 2):
         return False
     be = _backend.get()
