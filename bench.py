@@ -145,25 +145,33 @@ def family_table(trainer, it, real, backend, precision, steps, KernelTimer, worl
     import torch
     from torch.profiler import profile, ProfilerActivity
     tally = KernelTimer(only=None)
-    backend.timer = tally
-    done = 0
+    # Only the profiler's own start / stop / export may fail softly (another tracer attached, ...): an exception out of train_iteration -- a
+    # kernel error, a collective timeout -- is a failed bench and propagates.  Rank 0 alone carries the profiler's overhead in this pass; the
+    # other ranks wait for it in their collectives, which is why the pass is untimed and `comm` is tallied over the timed region only.
+    prof = None
     try:
-        with profile(activities=[ProfilerActivity.CUDA]) as prof:
-            for _ in range(steps):
-                trainer.train_iteration(it, real)
-                it += 1
-                done += 1
-            torch.cuda.synchronize()
+        prof = profile(activities=[ProfilerActivity.CUDA])
+        prof.__enter__()
+    except Exception as e:       # noqa: BLE001
+        print('bench.py: profiler did not start (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
+        prof = None
+    backend.timer = tally
+    try:
+        for _ in range(steps):
+            trainer.train_iteration(it, real)
+            it += 1
+        torch.cuda.synchronize()
+    finally:
         backend.timer = None
+    if prof is None:
+        return None, None, it
+    try:
+        prof.__exit__(None, None, None)
         path = os.path.join(tempfile.mkdtemp(prefix='gc_bench_'), 'trace.json')
         prof.export_chrome_trace(path)
         events = json.load(open(path))['traceEvents']
         os.remove(path)
-    except Exception as e:       # noqa: BLE001 -- a profiler that cannot start (another tracer attached, ...) must not cost the bench line
-        backend.timer = None
-        for _ in range(steps - done):          # the other ranks run the same number of iterations: keep the collectives paired
-            trainer.train_iteration(it, real)
-            it += 1
+    except Exception as e:       # noqa: BLE001
         print('bench.py: family pass skipped (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
         return None, None, it
     fam = {}
@@ -286,7 +294,8 @@ def main(argv=None, entry=None):
             raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
         torch.cuda.set_device(local_rank)
     if world > 1:
-        torch.set_num_threads(4)          # N ranks share the host: do not let each spawn one intra-op thread per core
+        # N ranks share the host: do not let each spawn one intra-op thread per core (an explicit OMP_NUM_THREADS below 4 is respected)
+        torch.set_num_threads(max(1, min(4, int(os.environ.get('OMP_NUM_THREADS', '4') or 4))))
     use_dist = world > 1 or ('RANK' in os.environ and os.environ.get('GANCONTROL_FORCE_DDP') == '1')
     rccl = None
     if use_dist:
@@ -319,7 +328,7 @@ def main(argv=None, entry=None):
     trainer = GeneratorTrainer(cfg, device=dev, seed=0)
     real = trainer.synthetic_batch()              # resident in HBM before the timed region
     for red in (trainer.g_reducer, trainer.d_reducer):
-        red.measure = use_dist and not cpu_test
+        red.measure = use_dist
 
     def barrier():
         _sync()
@@ -378,7 +387,7 @@ def main(argv=None, entry=None):
                     'r1': sum(1 for i in timed if i % tc['d_reg_every'] == 0), 'pl': sum(1 for i in timed if i % tc['g_reg_every'] == 0),
                     'cadence': {'r1_every': tc['d_reg_every'], 'pl_every': tc['g_reg_every']}}
     comm = None
-    if use_dist and not cpu_test:
+    if use_dist:
         parts = [red.comm_summary() for red in (trainer.g_reducer, trainer.d_reducer)]
         comm = {'bytes_per_step': sum(c['bytes'] for c in parts) / args.steps, 'exposed_ms_per_step': sum(c['exposed_ms'] for c in parts) / args.steps,
                 'note': 'gradient payload handed to the all-reduce per rank and step; exposed = compute-stream stall at GradientReducer.finish() '

@@ -44,6 +44,10 @@ def _expected_bin(logits):
 
 # predict(features) and controller_criterion(pred, target) of the reference's criteria, used by the phase-2 controller's
 # attribute_rec objective (controller_trainer.py:231-239)
+# REPRODUCED REFERENCE QUIRK (not in SURVEY Appendix C): the age criterion's predict() returns [B] (deep_age_criterion.py:25-32) while the
+# controller's target is the controls tensor -- [B] in the reference's own call, but [B, 1] when a caller keeps the column axis, and
+# `self.mse(pred, target)` (:37-38) then BROADCASTS [B] against [B, 1] to [B, B] (torch only warns).  The criterion below is the same
+# unguarded mse_loss on purpose: tests/test_controller.py pins the [B] case against the reference; do not "fix" the shapes here.
 PREDICTORS = {
     'age_loss': (_expected_bin, lambda pred, target: torch.nn.functional.mse_loss(pred, target)),
     # hopenet_criterion.py:6-19, 38-43: three 66-bin heads -> degrees; L1 against the controls

@@ -60,7 +60,11 @@ class _StylePlan:
     def selector(self, device, n_latent):
         """[groups, n_latent] one-hot rows: ``selector @ latents`` is the per-layer gather as ONE GEMM call.  Exact (every product is 1 * x or
         0 * x) and -- unlike index_select, whose backward scatters with atomics -- deterministic in both directions: the gradient of a
-        latent read by several layers is summed in the GEMM's fixed order."""
+        latent read by several layers is summed in the GEMM's fixed order.  Two caveats: the product must run in full fp32 -- _gather_latents
+        pins the matmul precision around the forward product (a process-wide set_float32_matmul_precision('high') / allow_tf32 would round the
+        latents on this route only; the backward GEMM of such a process still follows the process setting) -- and a non-finite latent entry
+        reaches EVERY layer's style as NaN through 0 * inf, where a gather would confine it to the layers that read that latent (the image is
+        non-finite either way; GANCONTROL_FUSED_STYLE=0 selects the per-layer route)."""
         t = self._idx.get((device, n_latent))
         if t is None:
             t = torch.zeros(len(self.latent_index), n_latent, dtype=torch.float32)
@@ -84,6 +88,21 @@ def make_kernel(k):
     if k.ndim == 1:
         k = torch.outer(k, k)
     return k / k.sum()
+
+
+def _gather_latents(plan, latent):
+    """latent [B, n_latent, D] -> [groups, B * D]: row g = the latent layer g reads (StyleGroupPlan.selector: one exact GEMM).  The product is
+    pinned to full fp32 whatever the process-wide matmul precision says, so the grouped and the per-layer style paths see the same bits."""
+    flat = latent.transpose(0, 1).reshape(latent.shape[1], -1)
+    hi, tf32 = torch.get_float32_matmul_precision(), torch.backends.cuda.matmul.allow_tf32
+    if hi == 'highest' and not tf32:
+        return plan.selector(latent.device, latent.shape[1]) @ flat
+    torch.set_float32_matmul_precision('highest')
+    try:
+        return plan.selector(latent.device, latent.shape[1]) @ flat
+    finally:
+        torch.set_float32_matmul_precision(hi)
+        torch.backends.cuda.matmul.allow_tf32 = tf32
 
 
 class PixelNorm(nn.Module):
@@ -240,8 +259,8 @@ class StyledConv(nn.Module):
     def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False, blur_kernel=[1, 3, 3, 1],
                  demodulate=True, conv_transpose=False, overwrite_padding=None, noise_mode='normal'):
         super().__init__()
-        if noise_mode not in ('normal', 'same_for_same_id'):
-            raise NotImplementedError(f'noise_mode {noise_mode!r} is not built on the HIP path')
+        if noise_mode not in ('normal', 'same_for_same_id', 'zeros', 'id_zeros'):
+            raise ValueError(f'unknown noise_mode {noise_mode!r}')
         self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim, upsample=upsample,
                                     blur_kernel=blur_kernel, demodulate=demodulate, conv_transpose=conv_transpose,
                                     overwrite_padding=overwrite_padding)
@@ -253,6 +272,23 @@ class StyledConv(nn.Module):
         """mod: (s, d) computed ahead of time by ``conv.styles(style)`` (Generator.forward's style path)."""
         conv = self.conv
         s_pre, d_pre = mod if mod is not None else (None, None)
+        if self.noise_mode in ('zeros', 'id_zeros'):
+            # ModulatedNoiseInjection (gan_model.py:1019-1035): 'zeros' injects nothing (the strength parameter stays without a gradient),
+            # 'id_zeros' adds the noise to the first half of the channels (torch.chunk) only.  Not used by the shipped configs: the
+            # convolution and the activation are the HIP ops, the half-tensor add is left to ATen.
+            s = s_pre if mod is not None else conv.modulation(style)
+            if conv.upsample:
+                out = modulated_conv2d(input, conv.weight, s, demodulate=conv.demodulate, upsample=True, blur_kernel=conv.blur.kernel,
+                                       blur_pad=conv.blur.pad, demod=d_pre)
+            else:
+                out = modulated_conv2d(input, conv.weight, s, demodulate=conv.demodulate, padding=conv.padding, demod=d_pre)
+            if self.noise_mode == 'id_zeros':
+                if noise is None:
+                    b, _, h, w = out.shape
+                    noise = out.new_empty(b, 1, h, w).normal_()
+                pose, ident = torch.chunk(out, 2, dim=1)
+                out = torch.cat([pose + self.noise.weight * noise, ident], dim=1)
+            return self.activate(out)
         if noise is not None and noise.shape[0] == 1 and input.shape[0] > 1:
             # the registered [1, 1, h, w] buffers of randomize_noise=False broadcast over the batch (gan_model.py:343-345)
             noise = noise.expand(input.shape[0], -1, -1, -1)
@@ -482,7 +518,7 @@ class Generator(nn.Module):
         b = latent.shape[0]
         if latent.shape[1] <= max(plan.latent_index):
             return None
-        x = plan.selector(latent.device, latent.shape[1]) @ latent.transpose(0, 1).reshape(latent.shape[1], -1)      # [groups, B * style_dim]
+        x = _gather_latents(plan, latent)      # [groups, B * style_dim]
         s_flat = style_op.grouped_linear(x.reshape(-1), b, plan.mod_plan, [m.modulation.weight for m in plan.layers],
                                          [m.modulation.bias for m in plan.layers])
         s_blocks = style_op.blocks(s_flat, b, plan.s_cols)

@@ -897,6 +897,7 @@ class HipBackend:
 
 _active = HipBackend()
 weight_cache.batch_runner = lambda: getattr(_active, 'weight_prep_batch', None)
+weight_cache.pack_wanted = lambda: getattr(_active, 'conv_mode', 'f32') != 'f32'
 
 
 def get():

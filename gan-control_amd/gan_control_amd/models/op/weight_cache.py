@@ -49,8 +49,9 @@ _derived = {}    # data_ptr of a cached tensor -> (id(root), key)
 _group_of = {}   # id(root) -> group id (parameters registered together as one module)
 _group_members = {}   # group id -> [weakref(root)]
 _recipes = {}    # id(root) -> {key: recipe}: every derived form ever asked of this root and how to make it (survives invalidation)
-stats = {'hit': 0, 'miss': 0, 'bypass': 0, 'batched': 0}
+stats = {'hit': 0, 'miss': 0, 'bypass': 0, 'batched': 0, 'batch_failed': 0}
 batch_runner = None   # set by op/_backend.py: () -> callable(kind, items) -> [tensor] of the active backend, or None
+pack_wanted = None    # set by op/_backend.py: () -> bool, does the active convolution arithmetic read hi / lo packs at all
 
 
 generation = [0]      # bumped whenever anything is dropped: lets callers keep their own short-cuts over several cached tensors honest
@@ -145,9 +146,15 @@ def _refill_group(gid):
                         continue                        # its parent could not be made in this pass: the caller's own make() will do it
                 items.append((src,) + tuple(recipe[1:]))
                 owners.append((rid, key))
-            if not items:
+            if not items or (kind == 'pack' and pack_wanted is not None and not pack_wanted()):
+                continue            # (packs recorded under a split-bf16 mode are not rebuilt while the exact-fp32 mode is active)
+            try:
+                outs = run(kind, items)
+            except (RuntimeError, ValueError):
+                # one item the grouped entry cannot take (a pack whose descriptor has no packed form any more, a table limit) must not abort
+                # the forward pass: leave this kind to the callers' own make(), which handles each tensor on its own
+                stats['batch_failed'] += 1
                 continue
-            outs = run(kind, items)
             for (rid, key), out in zip(owners, outs):
                 if out is not None and out.numel() > 0 and out.data_ptr() not in _derived:
                     _roots[rid][2][key] = out

@@ -14,14 +14,21 @@ from . import weight_cache
 class _Relayout(Function):
     """spec = (taps, k, n, src_stride, dst_shape, dst_stride, flip); strides are for the logical axes (tap, k, n)."""
 
-    _memo = {}      # (storage address, version, cache generation, spec, scale) -> the cached re-layout: the ~100 hits per pass skip the cache's own look-up
+    # (storage address, version, spec, scale) -> the cached re-layout of the CURRENT cache generation: the ~100 hits per pass skip the cache's
+    # own look-up.  The memo owns its tensors, so it is emptied whenever the generation moves (every optimiser step / EMA accumulate): entries of
+    # an older generation could never hit again and would only keep the re-layouts alive that weight_cache._drop has just released.
+    _memo = {}
+    _memo_generation = [-1]
 
     @staticmethod
     def forward(ctx, src, spec, scale):
         taps, k, n, src_stride, dst_shape, dst_stride, flip = spec
         ctx.inverse = (taps, k, n, dst_stride, tuple(src.shape), src_stride, flip)
         ctx.scale = scale
-        fast = (src.data_ptr(), src._version, weight_cache.generation[0], spec, scale) if weight_cache.ENABLED else None
+        fast = (src.data_ptr(), src._version, spec, scale) if weight_cache.ENABLED else None
+        if _Relayout._memo_generation[0] != weight_cache.generation[0]:
+            _Relayout._memo.clear()
+            _Relayout._memo_generation[0] = weight_cache.generation[0]
         hit = _Relayout._memo.get(fast) if fast is not None else None
         if hit is not None:
             weight_cache.stats['hit'] += 1
@@ -32,11 +39,12 @@ class _Relayout(Function):
         out = weight_cache.derive(src, key, lambda: _backend.get().weight_layout(src.contiguous(), taps, k, n, src_stride, dst_shape, dst_stride, flip, scale),
                                   recipe=key)
         if fast is not None and weight_cache._derived.get(out.data_ptr()) is not None:
-            # only what the cache itself holds (a parameter's or a cached tensor's form: both outlive the entry); the generation in the key
-            # retires the entry with the next invalidation
-            if len(_Relayout._memo) > 4096:
+            # only what the cache itself holds (a parameter's or a cached tensor's form); derive() may have bumped the generation (a refill
+            # after an invalidation): the entry then belongs to the new generation
+            if _Relayout._memo_generation[0] != weight_cache.generation[0]:
                 _Relayout._memo.clear()
-            _Relayout._memo[(fast[0], fast[1], weight_cache.generation[0], spec, scale)] = out
+                _Relayout._memo_generation[0] = weight_cache.generation[0]
+            _Relayout._memo[fast] = out
         return out.detach()
 
     @staticmethod

@@ -17,6 +17,12 @@ bucket arrives, the gradients are gathered into it by a single multi-tensor copy
 all-reduced in place (RCCL averages in the collective itself), and ``.grad`` of each parameter
 is re-pointed at its slice of the buffer: no ``cat``, no copy back.
 
+Bucket order: buckets are first laid out in reverse registration order (an approximation of the order in which backward
+produces gradients) and RE-LAID, once, in the order the gradients were actually observed to arrive during the first reduced pass
+(G's backward interleaves to_rgbs / convs / modulation layers, which registration order does not follow): a bucket then holds
+gradients that arrive back to back and launches as soon as its own share of backward is done instead of waiting for a straggler
+registered next to its other members.  Rank 0's order is broadcast so that every rank builds the same buckets.
+
 Which gradients to wait for: the four backward passes of an iteration (D step, R1, G step,
 path-length) each touch a different subset of the parameters (R1 and path-length run under
 ``activation_grads_only`` for their first-order pass and leave the additive biases without a
@@ -65,7 +71,7 @@ def all_reduce_mean_(t):
 
 
 class _Bucket:
-    __slots__ = ('params', 'offsets', 'numel', 'flat', 'pending', 'work', 'ready', 'late', 'from_hook')
+    __slots__ = ('params', 'offsets', 'numel', 'flat', 'pending', 'work', 'ready', 'late', 'from_hook', 'launched_at')
 
     def __init__(self, params):
         self.params = params
@@ -75,7 +81,7 @@ class _Bucket:
             off += p.numel()
         self.numel = off
         self.flat = None          # allocated on first use (the parameters may still move to a device after construction)
-        self.pending, self.work, self.ready, self.late, self.from_hook = 0, None, [], [], False
+        self.pending, self.work, self.ready, self.late, self.from_hook, self.launched_at = 0, None, [], [], False, None
 
     def view(self, p):
         off = self.offsets[p]
@@ -86,30 +92,23 @@ class GradientReducer:
     """Mean-reduces ``.grad`` of ``module``'s parameters across ranks, bucket by bucket.
 
     Usage per optimiser step:  ``reducer.begin(phase=...)`` -> backward(s) -> ``reducer.finish()`` ->
-    optimiser.step().  With gradient accumulation call ``begin(sync=False)`` for all but the
-    last micro-batch.  Parameters whose grad stays None (identical on all ranks by construction)
+    optimiser.step().  With gradient accumulation call ``begin(sync=False)`` ... ``finish()`` for all but the
+    last micro-batch: the record of which parameters hold a gradient survives those non-synchronising
+    ``finish()`` calls and is cleared by the synchronising one.  Parameters whose grad stays None (identical on all ranks by construction)
     are skipped.  After ``finish()`` the ``.grad`` tensors are views into the bucket buffers.
     """
 
-    def __init__(self, module, bucket_bytes=32 << 20, group=None):
+    def __init__(self, module, bucket_bytes=32 << 20, group=None, order_by_arrival=True):
         self.group = group
         self.enabled = self._armed = False
-        params = [p for p in module.parameters()]
-        # reverse registration order approximates the order in which backward produces gradients
-        self.buckets, cur, size = [], [], 0
-        for p in reversed(params):
-            cur.append(p)
-            size += p.numel() * p.element_size()
-            if size >= bucket_bytes:
-                self.buckets.append(_Bucket(cur)); cur, size = [], 0
-        if cur:
-            self.buckets.append(_Bucket(cur))
-        self._bucket_of = {}
-        self._handles = []
-        for b in self.buckets:
-            for p in b.params:
-                self._bucket_of[p] = b
-                self._handles.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.bucket_bytes = bucket_bytes
+        self._params = [p for p in module.parameters()]
+        # reverse registration order approximates the order in which backward produces gradients; replaced by the OBSERVED order of
+        # the first reduced pass (_reorder)
+        self._layout(list(reversed(self._params)))
+        self._handles = [p.register_post_accumulate_grad_hook(self._on_grad) for p in self._params]
+        self._order_pending = bool(order_by_arrival)
+        self._arrival = []        # parameters in the order their gradients arrived in the current pass
         self._expected = {}       # phase -> set of parameters that received a gradient the last time the phase ran
         self._phase = None
         self._fired = set()
@@ -117,6 +116,36 @@ class GradientReducer:
         self.max_gap = (64 << 10) // 4   # elements: gaps up to 64 KiB ride along in one collective
         self.measure = False      # bench.py: tally payload bytes and the exposed (not overlapped) wait of every finish()
         self.bytes_reduced, self._stalls = 0, []
+
+    def _layout(self, ordered):
+        self.buckets, cur, size = [], [], 0
+        for p in ordered:
+            cur.append(p)
+            size += p.numel() * p.element_size()
+            if size >= self.bucket_bytes:
+                self.buckets.append(_Bucket(cur)); cur, size = [], 0
+        if cur:
+            self.buckets.append(_Bucket(cur))
+        self._bucket_of = {p: b for b in self.buckets for p in b.params}
+
+    def _reorder(self):
+        """Re-lay the buckets in the arrival order of the pass that has just run (once; before any bucket buffer is in use by a collective).
+        Parameters that gave no gradient in that pass keep their reverse-registration position at the tail.  Rank 0 decides for everybody."""
+        self._order_pending = False
+        index = {p: i for i, p in enumerate(self._params)}
+        seen, order = set(), []
+        for p in self._arrival:
+            if p not in seen:
+                seen.add(p); order.append(index[p])
+        order += [index[p] for p in reversed(self._params) if p not in seen]
+        if dist.get_world_size(self.group) > 1:
+            dev = self._params[0].device if dist.get_backend(self.group) == 'nccl' else 'cpu'
+            t = torch.tensor(order, dtype=torch.int64, device=dev)
+            dist.broadcast(t, dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            order = t.tolist()
+        # gradients an accumulation pass has already moved into an old bucket buffer keep their values: .grad owns its storage view
+        self._layout([self._params[i] for i in order])
+        self.arrival_order = order
 
     def remove(self):
         for h in self._handles:
@@ -131,17 +160,19 @@ class GradientReducer:
         self._phase = phase
         expected = self._expected.get(phase)
         self._cur_expected = expected if expected is not None else ()
+        self._arrival = []
         for b in self.buckets:
             if expected is None:
                 b.pending = -1                       # unknown pass: reduce everything from finish()
             else:
                 b.pending = sum(1 for p in b.params if p in expected)
-            b.work, b.ready, b.late, b.from_hook = None, [], [], False
+            b.work, b.ready, b.late, b.from_hook, b.launched_at = None, [], [], False, None
 
     def _on_grad(self, p):
         if not self._armed:
             return
         self._fired.add(p)           # also during accumulation passes (sync=False): the gradient exists from then on
+        self._arrival.append(p)
         if not self.enabled:
             return
         b = self._bucket_of[p]
@@ -154,6 +185,7 @@ class GradientReducer:
             if b.pending == 0:
                 self._launch(b, b.ready)
                 b.from_hook = True
+                b.launched_at = len(self._arrival)       # gradients seen so far in this pass (tests: how early the collectives start)
 
     def _reduce(self, t):
         world = dist.get_world_size(self.group)
@@ -193,9 +225,14 @@ class GradientReducer:
     def finish(self):
         """Launch what the hooks did not (unknown pass, stragglers), wait for every bucket."""
         if not self.enabled:
-            self._fired = set()
+            # An accumulation pass (begin(sync=False)) of a distributed run keeps its record: the gradients it produced exist from now on and
+            # must be part of the reduction the final, synchronising pass launches, even if that pass does not touch them again.
+            if not is_dist():
+                self._fired = set()
             self._armed = False
             return
+        if self._order_pending and all(b.work is None for b in self.buckets):
+            self._reorder()
         hook = fin = 0
         for b in self.buckets:
             if b.work is None:
@@ -225,7 +262,8 @@ class GradientReducer:
             self._stalls.append(ev)
         if self._phase is not None:
             self._expected[self._phase] = set(self._fired)
-        self.report[self._phase] = {'hook': hook, 'finish': fin, 'late': len(late)}
+        self.report[self._phase] = {'hook': hook, 'finish': fin, 'late': len(late), 'gradients': len(self._arrival),
+                                    'launched_at': [b.launched_at for b in self.buckets]}
         self._fired = set()
         self.enabled = self._armed = False        # gradient hooks of a backward outside begin() .. finish() are not this reducer's business
 

@@ -402,6 +402,42 @@ class GeneratorTrainer:
         self.discriminator_update(i, real_img)
         self.generator_update(i)
 
+    def save_nets(self, i, save_dir, best_fid=False):
+        """The reference's checkpoint file (save_nets, generator_trainer.py:852-865): ``<save_dir>/checkpoint/<i:06d>.pt`` (or ``best_fid.pt``)
+        holding 'g', 'd', 'g_ema', 'g_optim', 'd_optim' -- plus 'mean_path_length', which the reference forgets (an
+        extra key its loader ignores).  Written by rank 0 only: the replicas are identical."""
+        path = os.path.join(save_dir, 'checkpoint', 'best_fid.pt' if best_fid else '%s.pt' % str(i).zfill(6))
+        if self.rank == 0:
+            os.makedirs(os.path.dirname(path), exist_ok=True)
+            torch.save(self.state_dict(), path)
+        return path
+
+    def train(self, data=None, save_dir=None, iters=None, start_iter=None, save_every=None, on_iteration=None):
+        """The loop of the reference's ``train()`` (generator_trainer.py:329-355): for i in start_iter .. iter: discriminator_update(i),
+        generator_update(i), then the checkpoint cadence of end_iter_update (:728-731: ``i % save_nets_interval == 0``).  ``data`` is an iterator
+        of real batches already on the device (this rank's shard; None = a resident synthetic batch, what bench.py times); evaluation, image
+        grids, tensorboard and the CSV monitor of end_iter_update are outside the hot path and left to ``on_iteration(i, trainer)``.
+        Returns the iteration counter after the last step."""
+        tc = self.training_config
+        iters = tc.get('iter', 0) if iters is None else iters
+        start = tc.get('start_iter', 0) if start_iter is None else start_iter
+        every = tc.get('save_nets_interval', 0) if save_every is None else save_every
+        real = None if data is not None else self.synthetic_batch()
+        nxt = start
+        for idx in range(iters):
+            i = idx + start
+            if i > iters:                # the reference's own stop test (:346-349): a resumed run ends at `iter`, not `iter` steps later
+                break
+            batch = next(data) if data is not None else real
+            self.discriminator_update(i, batch)
+            self.generator_update(i)
+            if save_dir is not None and every and i % every == 0 and not tc.get('debug', False):
+                self.save_nets(i, save_dir)
+            if on_iteration is not None:
+                on_iteration(i, self)
+            nxt = i + 1
+        return nxt
+
     def reduced_stats(self):
         """Scalar statistics averaged over ranks (what the reference logs from its single process)."""
         out = {}

@@ -345,6 +345,36 @@ def golden_networks():
     print('networks ok')
 
 
+def golden_noise_modes():
+    """StyledConv's noise_mode 'zeros' / 'id_zeros' (gan_model.py:391-399, ModulatedNoiseInjection :1019-1035) at 32 x 32: the image, the
+    gradient of sum(image * probe) with respect to a few named parameters, and the parameters that receive no gradient at all."""
+    out = {}
+    for mode in ('zeros', 'id_zeros'):
+        g = ref_gm.Generator(32, 512, 8, channel_multiplier=2, conv_transpose=True, noise_mode=mode)
+        g_sd = networks.procedural_fill_(g.state_dict())
+        g.load_state_dict(g_sd)
+        g_sd = {k: v.clone() for k, v in g_sd.items()}
+        gen = torch.Generator().manual_seed(515)
+        z = torch.randn(2, 512, generator=gen)
+        probe = torch.randn(2, 3, 32, 32, generator=gen)
+        noise = seeded_noise(32, 2, 616)
+        img_ref, _ = g([z], noise=noise)
+        with torch.no_grad():
+            img_o, _ = networks.generator_forward(g_sd, [z], 32, noise=noise, noise_mode=mode)
+        close(img_o, img_ref, 1e-4, f'G(32, noise_mode={mode})')
+        (img_ref * probe).sum().backward()
+        none = sorted(n for n, p in g.named_parameters() if p.grad is None)
+        names = ['convs.0.noise.weight', 'convs.1.noise.weight', 'convs.0.conv.weight', 'convs.3.activate.bias', 'conv1.conv.modulation.weight']
+        names = [n for n in names if n not in none]
+        out.update({f'{mode}/z': z, f'{mode}/probe': probe, f'{mode}/noise_seed': 616, f'{mode}/img': img_ref.detach(),
+                    f'{mode}/none_grad': np.array(none), f'{mode}/grad_names': np.array(names),
+                    f'{mode}/grad_norms': np.array([float(dict(g.named_parameters())[n].grad.norm()) for n in names]),
+                    f'{mode}/noise_grads': np.array([float(p.grad) if p.grad is not None else np.nan
+                                                     for n, p in g.named_parameters() if n.endswith('noise.weight')])})
+    np.savez_compressed(os.path.join(GOLD, 'noise_modes.npz'), **to_np(out))
+    print('noise modes ok')
+
+
 def golden_step(size=32, batch=4, name='step'):
     """One full iteration (i = 0: D step, R1, G step, path-length, EMA) at 32x32, batch 4 by default; main() also
     runs it at the BASELINE resolutions (512x512 batch 4, 1024x1024 batch 2: what fits this container's 64 GiB).
@@ -521,12 +551,14 @@ def golden_step(size=32, batch=4, name='step'):
         del out['real'], out['pl_noise']
     out.update({f'stat/{k}': v for k, v in stats.items()})
     out['cfg'] = np.array([size, batch])
-    for phase, (names, norms) in grad_samples.items():          # per-parameter gradient norms of each of the four backward passes
+    for phase, (names, norms, elems) in grad_samples.items():   # per-parameter gradient norms (+ sampled elements) of each of the four backward passes
         out[f'gradnorm/{phase}/names'] = np.array(names)
         out[f'gradnorm/{phase}/vals'] = torch.stack(norms)
-    for phase, (names, norms) in iso.items():                    # ... and of the passes run in isolation
+        out[f'gradnorm/{phase}/elems'] = torch.stack(elems)
+    for phase, (names, norms, elems) in iso.items():             # ... and of the passes run in isolation
         out[f'iso/{phase}/names'] = np.array(names)
         out[f'iso/{phase}/vals'] = torch.stack(norms)
+        out[f'iso/{phase}/elems'] = torch.stack(elems)
     out.update({f'iso/stat/{k}': v for k, v in iso_stats.items()})
     for tag, mod in (('g', g), ('d', d), ('g_ema', g_ema)):
         names, vals = [], []
@@ -543,14 +575,112 @@ def golden_step(size=32, batch=4, name='step'):
     print(name, 'ok; none_g =', none_g, '; none_d =', none_d, '; zero-grad-under-R1 D params:', len(zero_d))
 
 
+ELEMS = 64
+
+
+def elem_index(name, numel):
+    """The ELEMS sampled positions of parameter ``name`` (seeded by the name: tests/step_checks.py redraws them)."""
+    import zlib
+    gen = torch.Generator().manual_seed(zlib.crc32(('elem:' + name).encode()) & 0x7FFFFFFF)
+    return torch.randint(0, numel, (ELEMS,), generator=gen)
+
+
 def sample_grads(module):
-    """(names, norms): the gradient norm of every parameter that has a gradient -- a per-layer pin of each backward pass."""
-    names, norms = [], []
+    """(names, norms, elems): the gradient norm of every parameter that has a gradient -- a per-layer pin of each backward pass -- and ELEMS
+    sampled ELEMENTS of it (positions from elem_index): norms alone would pass a permuted, transposed or sign-flipped gradient block."""
+    names, norms, elems = [], [], []
     for n, p in module.named_parameters():
         if p.grad is not None:
             names.append(n)
             norms.append(p.grad.detach().norm())
-    return names, norms
+            elems.append(p.grad.detach().reshape(-1)[elem_index(n, p.numel())].clone())
+    return names, norms, elems
+
+
+def golden_step_isolated(size=1024, batch=4, name='step_1024_b4'):
+    """The four backward passes of an iteration EACH IN ISOLATION from the un-updated procedural weights, at the workload bench.py times
+    (1024 x 1024, 4 images per GPU: one full minibatch-stddev group of 4, gan_model.py:1003-1012; step maths generator_trainer.py:645-719).
+    The sequential four-pass iteration of golden_step does not fit this container's 64 GiB at this size; one pass at a time does (the D
+    step's two discriminator calls -- fake and real batches are separate calls in the reference too -- are back-propagated one after the
+    other into the same .grad, which is what autograd's accumulation does in the joint backward).  Stored per pass: losses / predictions,
+    per-parameter gradient norms and ELEMS sampled gradient elements per parameter tensor."""
+    import gc
+    cfg = dict(r1=1, g_reg_every=4, d_reg_every=16, path_regularize=2)
+    gen = torch.Generator().manual_seed(4096)
+    real = torch.rand(batch, 3, size, size, generator=gen) * 2 - 1
+    z_d, z_g = torch.randn(batch, 512, generator=gen), torch.randn(batch, 512, generator=gen)
+    z_pl = torch.randn(batch // 2, 512, generator=gen)
+    pl_noise = torch.randn(batch // 2, 3, size, size, generator=gen)
+    noise_d, noise_g = seeded_noise(size, batch, 21), seeded_noise(size, batch, 22)
+    noise_pl = seeded_noise(size, batch // 2, 23)
+    g, d, g_sd, d_sd = build_ref(size)
+    # None-gradient name sets of the dry run (generator_trainer.py:301-327), at batch 1
+    fake, latent = g([torch.randn(1, 512, generator=gen)], return_latents=True)
+    RT.g_path_regularize(fake, latent, 0)[0].backward()
+    none_g = sorted(n for n, p in g.named_parameters() if p.grad is None)
+    g.zero_grad()
+    t_in = torch.randn(1, 3, size, size, generator=gen).requires_grad_(True)
+    pred, _ = d(t_in)
+    RT.d_r1_loss(None, pred, t_in).backward()
+    none_d = sorted(n for n, p in d.named_parameters() if p.grad is None)
+    d.zero_grad()
+    del fake, latent, pred, t_in
+    gc.collect()
+    out = {'cfg': np.array([size, batch]), 'input_seed': np.array(4096), 'noise_seeds': np.array([21, 22, 23]), 'z_d': z_d, 'z_g': z_g, 'z_pl': z_pl,
+           'none_g': np.array(none_g), 'none_d': np.array(none_d)}
+
+    def keep(phase, mod, **stats):
+        stats = {k: torch.as_tensor(v) for k, v in stats.items()}
+        names, norms, elems = sample_grads(mod)
+        out[f'iso/{phase}/names'] = np.array(names)
+        out[f'iso/{phase}/vals'] = torch.stack(norms)
+        out[f'iso/{phase}/elems'] = torch.stack(elems)
+        out.update({f'iso/stat/{k}': v for k, v in stats.items()})
+        print(name, phase, 'done:', {k: (float(v) if v.numel() == 1 else tuple(v.shape)) for k, v in stats.items()}, flush=True)
+
+    # D step (generator_trainer.py:645-667): d_logistic_loss / len(real), fake and real halves back-propagated one after the other
+    ref_tu.requires_grad(g, False); ref_tu.requires_grad(d, True)
+    with torch.no_grad():
+        fake, _ = g([z_d], noise=noise_d)
+    fake_pred, _ = d(fake)
+    (F.softplus(fake_pred).mean() / len(real)).backward()
+    fake_pred = fake_pred.detach()
+    gc.collect()
+    real_pred, _ = d(real)
+    (F.softplus(-real_pred).mean() / len(real)).backward()
+    real_pred = real_pred.detach()
+    d_loss = RT.d_logistic_loss(real_pred, fake_pred) / len(real)
+    keep('d', d, d_loss=d_loss, real_pred_d=real_pred, fake_pred_d=fake_pred)
+    del fake
+    d.zero_grad(); gc.collect()
+    # R1 (generator_trainer.py:690-719)
+    real_r = real.clone().requires_grad_(True)
+    real_pred, _ = d(real_r)
+    r1 = RT.d_r1_loss(None, real_pred, real_r)
+    (cfg['r1'] / 2 * r1 * cfg['d_reg_every'] + 0 * real_pred[0]).backward()
+    ref_tu.set_grad_none(d, none_d)
+    keep('r1', d, d_r1_loss=r1.detach())
+    del real_r, real_pred, r1
+    d.zero_grad(); gc.collect()
+    # G step (generator_trainer.py:407-436, vanilla)
+    ref_tu.requires_grad(g, True); ref_tu.requires_grad(d, False)
+    fake, _ = g([z_g], noise=noise_g)
+    fake_pred, _ = d(fake)
+    g_loss = RT.g_nonsaturating_loss(fake_pred)
+    g_loss.backward()
+    keep('g', g, g_adv_loss=g_loss.detach(), fake_pred_g=fake_pred.detach())
+    del fake, fake_pred, g_loss
+    g.zero_grad(); gc.collect()
+    # path length (generator_trainer.py:563-599, gan_model.py:803-811) with an injected pl_noise
+    fake, latent = g([z_pl], noise=noise_pl, return_latents=True)
+    with mock.patch.object(torch, 'randn_like', lambda t: pl_noise):
+        grad = ref_gm.Generator.g_path_regularize_grad(fake, latent)
+    path_loss, mean_path, lengths = RT.g_path_regularize_grad(grad, 0)
+    (cfg['path_regularize'] * cfg['g_reg_every'] * path_loss + 0 * fake[0, 0, 0, 0]).backward()
+    ref_tu.set_grad_none(g, none_g)
+    keep('pl', g, g_path_loss=path_loss.detach(), path_lengths=lengths.detach(), g_mean_path_length=mean_path)
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **to_np(out))
+    print(name, 'ok')
 
 
 def golden_augment():
@@ -900,9 +1030,11 @@ def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
     jobs = {'upfirdn2d': golden_upfirdn2d, 'bias_act': golden_bias_act, 'convs': golden_convs, 'misc': golden_misc,
-            'networks': golden_networks, 'step': golden_step,
+            'networks': golden_networks, 'noise_modes': golden_noise_modes, 'step': golden_step,
             # the BASELINE resolutions: ~15 min and ~40 GiB on 8 cores (1024x1024 at batch 4 does not fit this container's 64 GiB)
             'step_512': lambda: golden_step(512, 4, 'step_512'), 'step_1024': lambda: golden_step(1024, 2, 'step_1024'),
+            # the bench workload itself (1024 x 1024, 4 images), one backward pass at a time: ~25 min, < 60 GiB
+            'step_1024_b4': golden_step_isolated,
             'augment': golden_augment, 'fid': golden_fid, 'controller': golden_controller, 'configs': golden_configs, 'controller_afhq': golden_controller_afhq, 'losses': golden_losses, 'inception': golden_inception}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()

@@ -66,13 +66,19 @@ def _mapping(sd, z, lr_mlp=0.01, fc_groups=None):
     return torch.cat(outs, dim=1)
 
 
-def _styled_conv(sd, prefix, x, w, noise, upsample):
-    """Reference: StyledConv.forward gan_model.py:402-408, NoiseInjection gan_model.py:340-345."""
+def _styled_conv(sd, prefix, x, w, noise, upsample, noise_mode='normal'):
+    """Reference: StyledConv.forward gan_model.py:402-408, NoiseInjection gan_model.py:340-345; noise_mode 'zeros' / 'id_zeros' =
+    ModulatedNoiseInjection gan_model.py:1019-1035 (no noise at all / noise on the first half of the channels only)."""
     y = ops.modulated_conv2d(x, w, sd[f'{prefix}.conv.weight'], sd[f'{prefix}.conv.modulation.weight'],
                              sd[f'{prefix}.conv.modulation.bias'], demodulate=True, upsample=upsample)
-    if noise is None:
-        noise = torch.randn(y.shape[0], 1, y.shape[2], y.shape[3], dtype=y.dtype, device=y.device)
-    y = y + sd[f'{prefix}.noise.weight'] * noise
+    if noise_mode != 'zeros':
+        if noise is None:
+            noise = torch.randn(y.shape[0], 1, y.shape[2], y.shape[3], dtype=y.dtype, device=y.device)
+        if noise_mode == 'id_zeros':
+            pose, ident = torch.chunk(y, 2, dim=1)
+            y = torch.cat([pose + sd[f'{prefix}.noise.weight'] * noise, ident], dim=1)
+        else:
+            y = y + sd[f'{prefix}.noise.weight'] * noise
     return ops.fused_leaky_relu(y, sd[f'{prefix}.activate.bias'])
 
 
@@ -87,7 +93,7 @@ def _to_rgb(sd, prefix, x, w, skip):
 
 
 def generator_forward(sd, styles, size, noise=None, input_is_latent=False, inject_index=None,
-                      truncation=1.0, truncation_latent=None, fc_groups=None):
+                      truncation=1.0, truncation_latent=None, fc_groups=None, noise_mode='normal'):
     """Reference: Generator.forward gan_model.py:709-801.  Returns (image, latent [B, n_latent, D]).
 
     ``styles`` is a list of z (or w if input_is_latent) tensors; ``noise`` a list of
@@ -109,12 +115,12 @@ def generator_forward(sd, styles, size, noise=None, input_is_latent=False, injec
                             styles[1].unsqueeze(1).repeat(1, nl - inject_index, 1)], 1)
     b = latent.shape[0]
     x = sd['input.input'].repeat(b, 1, 1, 1)
-    x = _styled_conv(sd, 'conv1', x, latent[:, 0], noise[0], upsample=False)
+    x = _styled_conv(sd, 'conv1', x, latent[:, 0], noise[0], upsample=False, noise_mode=noise_mode)
     skip = _to_rgb(sd, 'to_rgb1', x, latent[:, 1], None)
     li = 1
     for blk in range(log_size - 2):
-        x = _styled_conv(sd, f'convs.{2 * blk}', x, latent[:, li], noise[1 + 2 * blk], upsample=True)
-        x = _styled_conv(sd, f'convs.{2 * blk + 1}', x, latent[:, li + 1], noise[2 + 2 * blk], upsample=False)
+        x = _styled_conv(sd, f'convs.{2 * blk}', x, latent[:, li], noise[1 + 2 * blk], upsample=True, noise_mode=noise_mode)
+        x = _styled_conv(sd, f'convs.{2 * blk + 1}', x, latent[:, li + 1], noise[2 + 2 * blk], upsample=False)      # the second convolution of a block is always built with the default mode (gan_model.py:606-610)
         skip = _to_rgb(sd, f'to_rgbs.{blk}', x, latent[:, li + 2], skip)
         li += 2
     return skip, latent

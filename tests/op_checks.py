@@ -160,6 +160,33 @@ def seeded_noise(size, batch, seed, device='cpu'):
     return [m.to(device) for m in maps]
 
 
+def check_noise_modes(device, tol=TOL):
+    """StyledConv noise_mode 'zeros' / 'id_zeros' (gan_model.py:391-399, ModulatedNoiseInjection :1019-1035) against the reference generator
+    built in that mode: image, the parameters left without a gradient, the gradient norms of a few named parameters, every noise strength's
+    gradient (only conv1 and the up-sampling layers take the mode; the second convolution of a block is always 'normal', gan_model.py:606-610)."""
+    from gan_control_amd.models.gan_model import Generator
+    from oracle.networks import procedural_fill_
+    gold = load_golden('noise_modes')
+    for mode in ('zeros', 'id_zeros'):
+        r = group(gold, mode)
+        g = Generator(32, 512, 8, channel_multiplier=2, conv_transpose=True, noise_mode=mode)
+        g.load_state_dict(procedural_fill_(g.state_dict()))
+        g = g.to(device)
+        img, _ = g([r['z'].to(device)], noise=seeded_noise(32, 2, int(r['noise_seed']), device))
+        assert rel_err(img, r['img']) <= tol, mode
+        (img * r['probe'].to(device)).sum().backward()
+        named = dict(g.named_parameters())
+        assert sorted(n for n, p in named.items() if p.grad is None) == [str(n) for n in gold[f'{mode}/none_grad']], mode
+        for n, want in zip(gold[f'{mode}/grad_names'], r['grad_norms']):
+            assert abs(float(named[str(n)].grad.norm()) - float(want)) <= 2 * tol * float(want), (mode, n)
+        got = [float(p.grad) if p.grad is not None else float('nan') for n, p in named.items() if n.endswith('noise.weight')]
+        want = r['noise_grads'].double().numpy()
+        assert len(got) == len(want)
+        scale = np.nanmax(np.abs(want))
+        for a, b in zip(got, want):
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= 2 * tol * scale, (mode, got, want)
+
+
 def build_models(size, device, fc_groups=None):
     from gan_control_amd.models.gan_model import Generator, Discriminator
     from gan_control_amd.utils.fc_config import FcConfig

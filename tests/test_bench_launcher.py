@@ -30,6 +30,23 @@ def test_gpus_2_self_launches_two_ranks():
     assert line['phases_fired'] == {'d': 2, 'g': 2, 'r1': 0, 'pl': 0, 'cadence': {'r1_every': 16, 'pl_every': 4}}      # iterations 1, 2
 
 
+def test_gpus_8_weak_scaling_line():
+    """BASELINE config 3's partitioning through the driver's own command shape: 8 ranks x 4 images = global batch 32, one JSON line from rank 0,
+    value = the whole job's images over the slowest rank's time."""
+    env = _env()
+    env['OMP_NUM_THREADS'] = '1'
+    out = subprocess.run([sys.executable, ENTRY, '--gpus', '8', '--steps', '1', '--warmup', '0', '--size', '16', '--batch-per-gpu', '4', '--no-cpu-baseline'],
+                         env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 8 and line['rccl']['ranks'] == 8
+    assert line['config']['global_batch'] == 32 and line['config']['parallelism'] == 'dp8' and line['scaling'] == 'weak'
+    assert abs(line['value'] - 32 / (line['ms_per_step'] * 1e-3)) < 1e-6 * line['value']
+    assert line['comm']['bytes_per_step'] > 0
+
+
 def test_child_failure_reaches_the_caller():
     """A failing rank makes the launcher exit non-zero (no JSON line, no silent success)."""
     out = subprocess.run([sys.executable, ENTRY, '--gpus', '2', '--size', '24'] + ARGS[:4] + ['--batch-per-gpu', '4', '--no-cpu-baseline'],

@@ -134,26 +134,133 @@ def test_reducer_with_a_changing_gradient_set():
                 assert torch.allclose(got[it][n], p.grad, atol=1e-6), (it, n)
 
 
-def _inputs():
+def _accumulation_worker(rank, world, port, out):
+    """Two micro-batches that touch DIFFERENT parameter subsets, finish() after each (the non-synchronising one first): the gradient the
+    first micro-batch alone produced must still be part of the reduction the second one launches."""
+    _setup(rank, world, port)
+    from gan_control_amd.trainers.ddp import GradientReducer
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(6, 20), torch.nn.Linear(6, 20)
+    net = torch.nn.ModuleList([a, b])
+    red = GradientReducer(net, bucket_bytes=256)
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(9))[rank::world]
+    results = []
+    for it in range(3):
+        net.zero_grad(set_to_none=True)
+        red.begin(sync=False, phase='acc'); a(x[:2]).square().mean().backward(); red.finish()      # only a
+        assert red._fired == set(a.parameters())
+        red.begin(sync=True, phase='acc'); b(x[2:]).square().mean().backward(); red.finish()       # only b
+        assert not red._fired
+        results.append({n: p.grad.clone() for n, p in net.named_parameters()})
+    if rank == 0:
+        torch.save(results, out)
+    dist.destroy_process_group()
+
+
+def test_accumulation_over_different_parameter_subsets():
+    port = 25500 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'a.pt')
+        mp.spawn(_accumulation_worker, args=(2, port, out), nprocs=2, join=True)
+        got = torch.load(out)
+    torch.manual_seed(0)
+    a, b = torch.nn.Linear(6, 20), torch.nn.Linear(6, 20)
+    x = torch.randn(8, 6, generator=torch.Generator().manual_seed(9))
+    # rank r holds x[r::2] = 4 rows: its first micro-batch is rows 0, 1 of the shard, the second rows 2, 3
+    sh = [x[r::2] for r in range(2)]
+    (sum(a(s[:2]).square().mean() for s in sh) / 2).backward()
+    (sum(b(s[2:]).square().mean() for s in sh) / 2).backward()
+    want = {'0.weight': a.weight.grad, '0.bias': a.bias.grad, '1.weight': b.weight.grad, '1.bias': b.bias.grad}
+    for it in range(3):
+        for n, g in want.items():
+            assert torch.allclose(got[it][n], g, atol=1e-6), (it, n)
+
+
+class _Interleaved(torch.nn.Module):
+    """Registration order unlike the order of use (the generator registers conv1, convs, to_rgbs, ... and uses them interleaved)."""
+
+    def __init__(self, n=8, width=48):
+        super().__init__()
+        self.heads = torch.nn.ModuleList([torch.nn.Linear(width, 3) for _ in range(n)])        # registered first, used all along
+        self.body = torch.nn.ModuleList([torch.nn.Linear(width, width) for _ in range(n)])
+
+    def forward(self, x):
+        out = 0
+        for body, head in zip(self.body, self.heads):
+            x = torch.tanh(body(x))
+            out = out + head(x)
+        return out
+
+
+def _arrival_worker(rank, world, port, out):
+    _setup(rank, world, port)
+    from gan_control_amd.trainers.ddp import GradientReducer
+    torch.manual_seed(0)
+    net = _Interleaved()
+    red = GradientReducer(net, bucket_bytes=2 * 48 * 48 * 4)
+    before = [list(b.params) for b in red.buckets]
+    x = torch.randn(8, 48, generator=torch.Generator().manual_seed(3))[rank::world]
+    reports = []
+    for it in range(3):
+        net.zero_grad(set_to_none=True)
+        red.begin(sync=True, phase='p'); net(x).square().mean().backward(); red.finish()
+        reports.append(dict(red.report['p']))
+    index = {id(p): i for i, p in enumerate(net.parameters())}
+    flat_order = [index[id(p)] for b in red.buckets for p in b.params]
+    assert flat_order == red.arrival_order                       # buckets hold the gradients in the order backward produced them
+    assert [[id(p) for p in b.params] for b in red.buckets] != [[id(p) for p in ps] for ps in before]       # ... which is not reverse registration order for this network
+    if rank == 0:
+        torch.save({'reports': reports, 'order': flat_order, 'grads': {n: p.grad.clone() for n, p in net.named_parameters()},
+                    'n_buckets': len(red.buckets)}, out)
+    dist.destroy_process_group()
+
+
+def test_buckets_follow_the_observed_arrival_order():
+    """After the first pass the buckets are re-laid in arrival order; from the second pass on every bucket launches from a hook, bucket k as
+    soon as the gradients of buckets 0..k have arrived -- all but the last before the final 10 % of backward."""
+    port = 23500 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'o.pt')
+        mp.spawn(_arrival_worker, args=(2, port, out), nprocs=2, join=True)
+        got = torch.load(out)
+    assert got['n_buckets'] >= 4
+    for rep in got['reports'][1:]:
+        assert rep['finish'] == 0 and rep['late'] == 0 and rep['hook'] == got['n_buckets'], rep
+        at, total = rep['launched_at'], rep['gradients']
+        assert at == sorted(at) and at[-1] == total
+        assert all(a <= 0.9 * total for a in at[:-1]), (at, total)
+        # evenly spread: a bucket never waits for a gradient that arrives after the next bucket's members
+        per = total / len(at)
+        assert all(abs(a - per * (i + 1)) <= per for i, a in enumerate(at)), (at, total)
+    torch.manual_seed(0)
+    net = _Interleaved()
+    x = torch.randn(8, 48, generator=torch.Generator().manual_seed(3))
+    net(x).square().mean().backward()
+    # (the mean over ranks of the per-rank means of equal shards is the full-batch mean)
+    for n, p in net.named_parameters():
+        assert torch.allclose(got['grads'][n], p.grad, atol=1e-6), n
+
+
+def _inputs(size=SIZE, global_b=GLOBAL_B):
     import op_checks as oc
     gen = torch.Generator().manual_seed(77)
-    real = torch.rand(GLOBAL_B, 3, SIZE, SIZE, generator=gen) * 2 - 1
-    z_d, z_g = torch.randn(GLOBAL_B, 512, generator=gen), torch.randn(GLOBAL_B, 512, generator=gen)
-    z_pl = torch.randn(GLOBAL_B // 2, 512, generator=gen)
-    pl_noise = torch.randn(GLOBAL_B // 2, 3, SIZE, SIZE, generator=gen)
-    return dict(real=real, z_d=z_d, z_g=z_g, z_pl=z_pl, pl_noise=pl_noise, n_d=oc.seeded_noise(SIZE, GLOBAL_B, 1),
-                n_g=oc.seeded_noise(SIZE, GLOBAL_B, 2), n_pl=oc.seeded_noise(SIZE, GLOBAL_B // 2, 3))
+    real = torch.rand(global_b, 3, size, size, generator=gen) * 2 - 1
+    z_d, z_g = torch.randn(global_b, 512, generator=gen), torch.randn(global_b, 512, generator=gen)
+    z_pl = torch.randn(global_b // 2, 512, generator=gen)
+    pl_noise = torch.randn(global_b // 2, 3, size, size, generator=gen)
+    return dict(real=real, z_d=z_d, z_g=z_g, z_pl=z_pl, pl_noise=pl_noise, n_d=oc.seeded_noise(size, global_b, 1),
+                n_g=oc.seeded_noise(size, global_b, 2), n_pl=oc.seeded_noise(size, global_b // 2, 3))
 
 
-def _run_iteration(rank, world, device='cpu'):
+def _run_iteration(rank, world, device='cpu', size=SIZE, global_b=GLOBAL_B):
     import step_checks
     from gan_control_amd.models.op import _backend
     from gan_control_amd.trainers.utils import requires_grad, accumulate
     if device == 'cpu':
         _backend._install_for_tests(EmulatedBackend())
-    tr = step_checks.make_trainer(device, size=SIZE, batch=GLOBAL_B)
-    assert tr.local_batch == GLOBAL_B // world
-    inp = _inputs()
+    tr = step_checks.make_trainer(device, size=size, batch=global_b)
+    assert tr.local_batch == global_b // world
+    inp = _inputs(size, global_b)
     sh = lambda t: t[rank::world].contiguous().to(device)            # strided shard keeps the stddev groups of the 1-rank run
     shl = lambda maps: [sh(m) for m in maps]
     requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
@@ -166,12 +273,17 @@ def _run_iteration(rank, world, device='cpu'):
     state = {'g': {k: v.clone() for k, v in tr.generator.named_parameters()},
              'd': {k: v.clone() for k, v in tr.discriminator.named_parameters()},
              'mean_path_length': float(tr.mean_path_length), 'd_loss': tr.reduced_stats()['d_loss']}
+    if tr.g_reducer is not None:
+        state['reports'] = {'g': dict(tr.g_reducer.report), 'd': dict(tr.d_reducer.report),
+                            'buckets': (len(tr.g_reducer.buckets), len(tr.d_reducer.buckets))}
     return state
 
 
-def _trainer_worker(rank, world, port, out, device='cpu'):
+def _trainer_worker(rank, world, port, out, device='cpu', size=SIZE, global_b=GLOBAL_B):
     _setup(rank, world, port)
-    state = _run_iteration(rank, world, device)
+    if world > 4:
+        torch.set_num_threads(1)
+    state = _run_iteration(rank, world, device, size, global_b)
     # every rank draws its own noise from the global generators (NoiseInjection, path-length noise, ADA transforms) ...
     draw = torch.randn(16, device=device).cpu()
     both = [torch.empty(16) for _ in range(world)]
@@ -184,7 +296,7 @@ def _trainer_worker(rank, world, port, out, device='cpu'):
         assert torch.equal(ref, v.detach()), k
     if rank == 0:
         torch.save({'g': {k: v.detach().cpu() for k, v in state['g'].items()}, 'd': {k: v.detach().cpu() for k, v in state['d'].items()},
-                    'mean_path_length': state['mean_path_length'], 'd_loss': state['d_loss']}, out)
+                    'mean_path_length': state['mean_path_length'], 'd_loss': state['d_loss'], 'reports': state.get('reports')}, out)
     dist.destroy_process_group()
 
 
@@ -209,6 +321,34 @@ def test_two_ranks_equal_one_rank():
             big += int((diff > 1e-3).sum()); n += diff.numel()
     # Adam's first steps are sign-like: identical up to fp32 summation order except where a gradient is ~0
     assert big <= n * 1e-3, (big, n, worst)
+
+
+@pytest.mark.parametrize('world,size,global_b', [(4, 16, 16), (8, 32, 32)])
+def test_four_and_eight_ranks_equal_one_rank(world, size, global_b):
+    """The bucket / phase logic at the world sizes of BASELINE configs 3 and 4: 4 ranks x 4 images, and 8 ranks x 4 images = global batch
+    32 (config 3's literal partitioning, at 32 x 32 so that eight CPU processes finish in a minute), against the one-rank iteration over
+    the whole batch.  Every rank's shard is one complete minibatch-stddev group (members are `global_b / 4` apart)."""
+    sys.path.insert(0, os.path.join(REPO, 'tests'))
+    port = 35500 + os.getpid() % 2000 + world
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 's.pt')
+        mp.spawn(_trainer_worker, args=(world, port, out, 'cpu', size, global_b), nprocs=world, join=True)
+        many = torch.load(out)
+    one = _run_iteration(0, 1, 'cpu', size, global_b)
+    from gan_control_amd.models.op import _backend
+    _backend._install_for_tests(_backend.HipBackend())
+    assert abs(many['mean_path_length'] - one['mean_path_length']) < 1e-5 * max(1, abs(one['mean_path_length']))
+    assert abs(many['d_loss'] - one['d_loss']) < 1e-5
+    big = n = 0
+    for tag in ('g', 'd'):
+        for k, v in one[tag].items():
+            diff = (many[tag][k] - v.detach()).abs()
+            big += int((diff > 1e-3).sum()); n += diff.numel()
+    assert big <= n * 1e-3, (big, n)
+    # all four phases reduced something, nothing arrived late
+    rep = many['reports']
+    assert set(rep['d']) >= {'d', 'r1'} and set(rep['g']) >= {'g', 'pl'}, rep
+    assert all(r['late'] == 0 for net in ('g', 'd') for r in rep[net].values())
 
 
 @pytest.mark.gpu

@@ -60,6 +60,10 @@ def test_mixing_truncation_and_stored_noise(emu_backend):
     oc.check_mixing_truncation('cpu')
 
 
+def test_noise_modes_zeros_and_id_zeros(emu_backend):
+    oc.check_noise_modes('cpu')
+
+
 def test_transfer_learning_load(emu_backend):
     oc.check_transfer_learning('cpu')
 

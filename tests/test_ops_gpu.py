@@ -771,6 +771,10 @@ def test_mixing_truncation_and_stored_noise_gpu():
     oc.check_mixing_truncation(DEV)
 
 
+def test_noise_modes_zeros_and_id_zeros_gpu():
+    oc.check_noise_modes(DEV)
+
+
 def test_transfer_learning_load_gpu():
     oc.check_transfer_learning(DEV)
 

@@ -139,6 +139,16 @@ def test_network_split_fc_and_mixing():
     assert rel_err(img, r['img']) < 1e-5
 
 
+def test_noise_modes():
+    gold = load_golden('noise_modes')
+    for mode in ('zeros', 'id_zeros'):
+        r = group(gold, mode)
+        g_sd, _ = build_sd(32)
+        with torch.no_grad():
+            img, _ = networks.generator_forward(g_sd, [r['z']], 32, noise=seeded_noise(32, 2, int(r['noise_seed'])), noise_mode=mode)
+        assert rel_err(img, r['img']) < 1e-5, mode
+
+
 def test_step():
     s = load_golden('step')
     g_sd, d_sd = build_sd(32)

@@ -39,3 +39,47 @@ def test_iteration_with_ada_and_style_mixing(emu_backend):
     for k in ('d_loss', 'd_r1_loss', 'g_adv_loss', 'g_path_loss'):
         assert stats[k] == stats[k] and abs(stats[k]) < 1e6, (k, stats[k])
     assert float(tr.ada.accum[1]) == 4.0 and tr.ada.p == 0.5
+
+
+def test_train_loop_writes_the_reference_checkpoint_layout_and_resumes(emu_backend, tmp_path):
+    """GeneratorTrainer.train (generator_trainer.py:329-355) + save_nets (:852-865): files ``checkpoint/<i:06d>.pt`` at the
+    ``save_nets_interval`` cadence with the reference's five keys; a trainer restored from one continues bit-for-bit like the
+    uninterrupted run."""
+    import os
+    import random
+    import torch
+    from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
+
+    def fresh():
+        cfg = default_config(16, 4)
+        cfg['training_config']['iter'] = 5
+        cfg['training_config']['save_nets_interval'] = 2
+        random.seed(0); torch.manual_seed(0)
+        return GeneratorTrainer(cfg, device='cpu', seed=0, fused_adam=False)
+
+    seen = []
+    a = fresh()
+    real = a.synthetic_batch()
+    end = a.train(data=iter(lambda: real, None), save_dir=str(tmp_path), on_iteration=lambda i, t: seen.append(i))
+    assert seen == [0, 1, 2, 3, 4] and end == 5
+    assert sorted(os.listdir(tmp_path / 'checkpoint')) == ['000000.pt', '000002.pt', '000004.pt']
+    ckpt = torch.load(tmp_path / 'checkpoint' / '000002.pt')
+    assert {'g', 'd', 'g_ema', 'g_optim', 'd_optim'} <= set(ckpt)
+    assert set(ckpt['g']) == set(a.generator.state_dict()) and set(ckpt['d']) == set(a.discriminator.state_dict())
+    # resume after iteration 2 with the random streams of the uninterrupted run replayed up to that point
+    b = fresh()
+    assert torch.equal(b.synthetic_batch(), real)                        # (the same draw from the trainer's own generator as in `a`)
+    b.train(data=iter(lambda: real, None), iters=3)                      # iterations 0..2 (draws the same random numbers)
+    b.load_state_dict(ckpt)                                              # ... and every tensor of the checkpoint on top
+    # the reference's stop test is `i > iter` (:346), so a resumed run ends AFTER iteration `iter`: 3, 4 with iter = 4
+    assert b.train(data=iter(lambda: real, None), start_iter=3, iters=4) == 5
+    for (n, p), (_, q) in zip(a.generator.named_parameters(), b.generator.named_parameters()):
+        assert torch.equal(p, q), n
+    for (n, p), (_, q) in zip(a.g_ema.named_parameters(), b.g_ema.named_parameters()):
+        assert torch.equal(p, q), n
+    assert float(a.mean_path_length) == float(b.mean_path_length)
+    # debug runs never write checkpoints (:728)
+    c = fresh()
+    c.training_config['debug'] = True
+    c.train(iters=1, save_dir=str(tmp_path / 'dbg'))
+    assert not os.path.exists(tmp_path / 'dbg')
