@@ -108,7 +108,7 @@ _SIMPLE = (
     ('rccl', re.compile(r'rccl|nccl', re.I)),
     ('wgrad', re.compile(r'wgrad_')),
     ('pointwise', re.compile(r'pw_(narrow|widen|wgrad)')),
-    ('convt', re.compile(r'convt_fused')),
+    ('convt', re.compile(r'convt_')),
     ('fir', re.compile(r'fir44|firK|generic_kernel|affine_warp|reflect_pad')),
     ('bias_act', re.compile(r'bias_act|plane_dot|channel_sum|rows_sum_div')),
     ('weights', re.compile(r'weight_layout|pack_weights')),

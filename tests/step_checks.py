@@ -39,9 +39,50 @@ class _Measure(dict):
         self[key] = max(self.get(key, 0.0), float(err))
 
 
-def _check_grads(module, s, prefix, ref_total, tol, param_tol=None, measure=None):
-    """Gradients of one backward pass against the reference's: the set of parameters that have one, the global norm and the
-    norm of every single parameter's gradient (``<prefix>/names``, ``<prefix>/vals``)."""
+ELEMS = 64
+
+
+def elem_index(name, numel):
+    """The sampled positions of parameter ``name`` (oracle/make_golden.py::elem_index: seeded by the name)."""
+    import zlib
+    gen = torch.Generator().manual_seed(zlib.crc32(('elem:' + name).encode()) & 0x7FFFFFFF)
+    return torch.randint(0, numel, (ELEMS,), generator=gen)
+
+
+def _check_elems(got, s, prefix, names, refs, ref_total, elem_tol, measure):
+    """DIRECTION of every parameter's gradient, not just its length: 64 sampled elements per tensor (``<prefix>/elems``) against the
+    reference's, as the relative L2 distance of the two sample vectors.  A permuted, transposed or sign-flipped block with the right norm
+    passes the norm check; it cannot pass this one.  Tensors whose whole gradient is below 0.1 % of the pass's norm are bounded against
+    that floor (their samples sit in the rounding noise of the pass), the scalar noise strengths are compared together as one vector."""
+    if f'{prefix}/elems' not in s:
+        return 0.0
+    elems = torch.from_numpy(s[f'{prefix}/elems']).double()
+    worst, scal_got, scal_ref = 0.0, [], []
+    for i, n in enumerate(names):
+        g = got[n].detach().reshape(-1)
+        ref = elems[i]
+        mine = g[elem_index(n, g.numel()).to(g.device)].double().cpu()
+        if g.numel() == 1:
+            scal_got.append(mine[0]); scal_ref.append(ref[0])
+            continue
+        # the expected length of a 64-sample vector of a tensor at the floor norm
+        floor = 1e-3 * ref_total * (ELEMS / g.numel()) ** 0.5
+        err = float((mine - ref).norm() / max(float(ref.norm()), floor))
+        worst = max(worst, err)
+        assert measure is not None or err <= elem_tol, (prefix, n, 'sampled gradient elements', err, elem_tol)
+    if scal_ref:
+        a, b = torch.stack(scal_got), torch.stack(scal_ref)
+        err = float((a - b).norm() / b.norm().clamp_min(1e-3 * ref_total))
+        worst = max(worst, err)
+        assert measure is not None or err <= elem_tol, (prefix, 'scalar parameters, elementwise', err)
+    if measure is not None:
+        measure.note(prefix + ':elems', worst)
+    return worst
+
+
+def _check_grads(module, s, prefix, ref_total, tol, param_tol=None, measure=None, elem_tol=None):
+    """Gradients of one backward pass against the reference's: the set of parameters that have one, the global norm, the
+    norm of every single parameter's gradient (``<prefix>/names``, ``<prefix>/vals``) and 64 sampled elements of each (``<prefix>/elems``)."""
     got = {n: p.grad for n, p in module.named_parameters() if p.grad is not None}
     names = [str(n) for n in s[f'{prefix}/names']]
     assert sorted(names) == sorted(got), (prefix, set(names) ^ set(got))
@@ -76,7 +117,83 @@ def _check_grads(module, s, prefix, ref_total, tol, param_tol=None, measure=None
         assert measure is not None or err <= param_tol, (prefix, 'scalar parameters', scalars)
     if measure is not None:
         measure.note(prefix + ':param', worst)
+    # sampled elements: a sample vector's relative error is bounded like a per-parameter norm's (the same cancellation argument), with the
+    # sqrt(2) of a difference of two roundings
+    _check_elems(got, s, prefix, names, refs, ref_total, (2 * param_tol) if elem_tol is None else elem_tol, measure)
     return worst
+
+
+def check_isolated(device, name='step_1024_b4', tol=2e-3, param_tol=None, measure=None, trainer=None):
+    """The four backward passes of an iteration, EACH IN ISOLATION from the procedural weights, against ``tests/golden/<name>.npz``
+    (oracle/make_golden.py::golden_step_isolated: the reference's own modules and trainer maths at the workload bench.py times -- 1024 x 1024,
+    4 images).  ``trainer``: a factory ``(size, batch) -> GeneratorTrainer`` -- the headline test passes bench.py's own construction (fused Adam,
+    every default knob); the weights are then overwritten with the procedural ones the fixture was generated from.  Checked per pass: loss /
+    prediction statistics, the set of parameters with a gradient, global and per-parameter gradient norms, 64 sampled gradient elements per
+    parameter tensor.  The Adam steps the trainer takes after each backward are undone by reloading the weights (gradients are read first)."""
+    from gan_control_amd.trainers.utils import requires_grad
+    from oracle.networks import procedural_fill_
+    pt = param_tol if param_tol is not None else tol
+    m = measure
+    s = load_golden(name)
+    size, batch = [int(v) for v in s['cfg']]
+    gen = torch.Generator().manual_seed(int(s['input_seed']))
+    real = torch.rand(batch, 3, size, size, generator=gen) * 2 - 1
+    z_d, z_g = torch.randn(batch, 512, generator=gen), torch.randn(batch, 512, generator=gen)
+    z_pl = torch.randn(batch // 2, 512, generator=gen)
+    pl_noise = torch.randn(batch // 2, 3, size, size, generator=gen)
+    for k, v in (('z_d', z_d), ('z_g', z_g), ('z_pl', z_pl)):
+        assert torch.equal(v, torch.from_numpy(s[k])), 'the seeded redraw does not reproduce the fixture: ' + k
+    tr = trainer(size, batch) if trainer is not None else make_trainer(device, size=size, batch=batch)
+    fresh_g = procedural_fill_({k: v.detach().clone() for k, v in tr.generator.state_dict().items()})
+    fresh_d = procedural_fill_({k: v.detach().clone() for k, v in tr.discriminator.state_dict().items()})
+    assert sorted(tr.none_g_grads) == sorted(str(n) for n in s['none_g'])
+    assert sorted(tr.none_d_grads) == sorted(str(n) for n in s['none_d'])
+    seeds = [int(v) for v in s['noise_seeds']]
+    noise = lambda b, i: oc.seeded_noise(size, b, seeds[i], device)
+    real, z_d, z_g, z_pl, pl_noise = (t.to(device) for t in (real, z_d, z_g, z_pl, pl_noise))
+
+    def within(key, err, bound):
+        if m is not None:
+            m.note(key, err)
+        else:
+            assert err <= bound, (key, err, bound)
+
+    def reset():
+        tr.generator.load_state_dict(fresh_g)
+        tr.discriminator.load_state_dict(fresh_d)
+        tr.g_ema.load_state_dict(fresh_g)
+        tr.mean_path_length = 0
+
+    def stat(key, scale=1.0):
+        ref = torch.from_numpy(s['iso/stat/' + key]).double().reshape(-1)
+        return ref, max(scale, float(ref.abs().max()))
+
+    worst = {}
+    reset()
+    requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
+    tr.discriminator_step([[z_d]], [real], noise=noise(batch, 0))
+    worst['d'] = _check_grads(tr.discriminator, s, 'iso/d', None, tol, pt, m)
+    ref, sc = stat('d_loss')
+    within('iso d_loss', abs(float(tr.stats['d_loss']) - float(ref)) / sc, tol)
+    reset()
+    tr.discriminator_regularize_step([real])
+    worst['r1'] = _check_grads(tr.discriminator, s, 'iso/r1', None, 3 * tol, 3 * pt, m)
+    ref, _ = stat('d_r1_loss')
+    within('iso d_r1_loss', abs(float(tr.stats['d_r1_loss']) - float(ref)) / max(1e-3, abs(float(ref))), 3 * tol)
+    reset()
+    requires_grad(tr.generator, True); requires_grad(tr.discriminator, False)
+    tr.generator_step([[z_g]], noise=noise(batch, 1))
+    worst['g'] = _check_grads(tr.generator, s, 'iso/g', None, tol, pt, m)
+    ref, sc = stat('g_adv_loss')
+    within('iso g_adv_loss', abs(float(tr.stats['g_adv_loss']) - float(ref)) / sc, tol)
+    reset()
+    tr.generator_regularize_step(noise=noise(batch // 2, 2), pl_noise=pl_noise, z=[z_pl])
+    worst['pl'] = _check_grads(tr.generator, s, 'iso/pl', None, 3 * tol, 3 * pt, m)
+    ref, sc = stat('g_path_loss')
+    within('iso g_path_loss', abs(float(tr.stats['g_path_loss']) - float(ref)) / sc, tol)
+    within('iso path_lengths', rel_err(tr.stats['path_lengths'], torch.from_numpy(s['iso/stat/path_lengths'])), tol)
+    print(name, 'worst per-parameter gradient-norm error per pass:', {k: '%.2e' % v for k, v in worst.items()})
+    return tr
 
 
 def check_step(device, tol=2e-3, name='step', param_tol=None, measure=None):
