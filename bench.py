@@ -66,6 +66,7 @@ def parse(argv=None):
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--timer', default='roofline', choices=['roofline', 'all'], help='which launches get HIP-event brackets in the timed region')
     ap.add_argument('--cpu-baseline-size', type=int, default=None, help='resolution of the CPU sample (default: --size)')
+    ap.add_argument('--no-host-issue', action='store_true', help='skip the untimed host-issue-time pass ("host_issue_ms_per_step")')
     ap.add_argument('--no-families', action='store_true', help='skip the untimed profiler pass behind "families" / "step_roofline"')
     return ap.parse_args(argv)
 
@@ -319,7 +320,7 @@ def main(argv=None, entry=None):
     from gan_control_amd.utils.profiling import KernelTimer
 
     if cpu_test:
-        args.no_kernel_timer = args.no_families = args.no_fp32_leg = True
+        args.no_kernel_timer = args.no_families = args.no_fp32_leg = args.no_host_issue = True
     elif args.precision:
         _backend.get().conv_mode = args.precision
     precision = getattr(_backend.get(), 'conv_mode', 'emulated')
@@ -448,6 +449,24 @@ def main(argv=None, entry=None):
 
     if families is None:
         step_flops = None
+    # Untimed: HOST issue time per step -- one cadence cycle of 16 iterations, each issued into a drained device and timed on the host clock
+    # up to the return of train_iteration (no synchronisation inside): what Python / ctypes / autograd cost per step when nothing blocks.
+    # The step is device-bound as long as this stays below ms_per_step; it is the floor a faster kernel set would hit.
+    host_issue = None
+    if not args.no_host_issue:
+        cycle, acc_ms = 16, 0.0
+        worst_ms = 0.0
+        for _ in range(cycle):
+            _sync()
+            t0 = time.perf_counter()
+            trainer.train_iteration(it, real)
+            dt = (time.perf_counter() - t0) * 1e3
+            acc_ms += dt
+            worst_ms = max(worst_ms, dt)
+            it += 1
+        barrier()
+        host_issue = {'ms_per_step': acc_ms / cycle, 'max_ms': worst_ms, 'iterations': cycle,
+                      'note': 'host wall time of train_iteration() issued into a drained device, mean over one cadence cycle (16 iterations: 1 R1 + 4 path-length passes)'}
     if rank == 0:
         images = args.steps * args.batch_per_gpu * world
         out = {
@@ -460,6 +479,9 @@ def main(argv=None, entry=None):
             'losses': {k: round(v, 5) for k, v in stats.items()},
             'phases_fired': phases_fired,
         }
+        if host_issue is not None:
+            out['host_issue_ms_per_step'] = round(host_issue['ms_per_step'], 3)
+            out['host_issue'] = host_issue
         if rccl is not None:
             out['rccl'] = rccl
         if comm is not None:

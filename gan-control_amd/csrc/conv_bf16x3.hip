@@ -1681,12 +1681,20 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
 // start of item i), and completion is counted by hand -- at the end of item i a wave waits `vmcnt(n)` with n = the DMA instructions it has
 // just issued for item i + 2; loads complete in order, so everything older (the rows of item i + 1, and any store of a finished tile) is
 // done, whatever the stores' own completion order.
+// MEASURED AND NOT ENABLED (round 4, tools/kbench.py, B = 4, same box; profiles/convt_ws_r04.md): correct on every test shape and bit-identical
+// run to run, but no faster than the one-role kernel -- 512 -> 256 @64^2 199 vs 213 us, 256 -> 128 @128^2 190 vs 180, 128 -> 64 @256^2 205 vs 191,
+// 64 -> 32 @512^2 302 vs 243.  Ablation builds (GC_CTWS_ABL) say why: with neither patch staging nor weight DMA the multiplying side alone
+// runs 159 / 131 / 125 / 173 us -- (i) the (H + 1)^2 q-space of a (2H + 1)-wide output tiles badly (65 = 4 x 16 + 1: 66 % of the MFMA work of a
+// 512 -> 256 @64^2 launch is useful) and one long-lived workgroup per CU quantises what is left (208 of 256 CUs busy); (ii) at <= 128 input
+// channels the second pass re-reads the patch the layer is HBM-bound on (64 -> 32: 170 us without patch staging).  An edge-row / edge-column
+// path that would make the main region H x H (perfect tiling: ~115 us projected for 512 -> 256) is the open continuation.
 #ifndef GC_CTWS
-#define GC_CTWS 1             // 0: the transposed convolutions stay on convt_fused_bf16x3_kernel
+#define GC_CTWS 0             // 1: transposed 3x3 convolutions with K % 16 == 0, N % 32 == 0 on convt_bf16x3_ws_kernel
 #endif
 #ifndef GC_CTWS_ABL
 #define GC_CTWS_ABL 0         // dev ablations (wrong results): 1 no patch staging, 2 no weight DMA, 8 no stores
 #endif
+#if GC_CTWS
 template <int WOCB, int TPW>
 struct TWCfg {
     static constexpr int OCT = 32 * WOCB, RPB = 32 / TPW, RG = 8 / WOCB;      // RG row groups; a multiplying wave owns 32 oc x 2 blocks of RPB rows x TPW q-columns
@@ -2031,9 +2039,6 @@ int launch_tws(Bf16Args a, hipStream_t s) {
 // the transposed layers the wave-specialised kernel takes: whole 16-channel chunks, whole 32- / 64-channel output blocks, enough chunks
 // per item sequence to amortise its start-up, enough tiles to give most CUs a workgroup
 inline bool tws_eligible(const Bf16Args& a) {
-#if !GC_CTWS
-    return false;
-#endif
     const ConvArgs& c = a.c;
     if (a.k_per_split || c.K % KCB != 0 || c.K < 32 || c.N % 32 != 0) return false;
     if (c.bias || c.noise || c.act || c.residual) return false;       // the full fused epilogue (no caller in the training step) stays on the one-role kernel
@@ -2043,6 +2048,7 @@ inline bool tws_eligible(const Bf16Args& a) {
     const long long wgs = (long long)gc::ceil_div(qw, 32) * gc::ceil_div(qh, oct == 64 ? 8 : 16) * c.B * (c.N / oct);
     return wgs >= 192;
 }
+#endif      // GC_CTWS
 
 template <int WG_OC, int WG_PX, int WPX, int TPW>
 int launch_t(Bf16Args a, hipStream_t s) {
@@ -2073,10 +2079,12 @@ int launch_t(Bf16Args a, hipStream_t s) {
 int dispatch_t(const Bf16Args& a, hipStream_t s) {
     const int qw = gc::ceil_div(a.c.out_w, 2);
     const bool narrow = GC_CONVT_NARROW && gc::ceil_div(qw, 16) * 16 < gc::ceil_div(qw, 32) * 32;
+#if GC_CTWS
     if (tws_eligible(a)) {
         if (a.c.N % 64 != 0) return launch_tws<1, 32>(a, s);                 // 32 oc x 16 rows x 32 q-columns
         return narrow ? launch_tws<2, 16>(a, s) : launch_tws<2, 32>(a, s);    // 64 oc x (16 x 16 | 8 x 32) q-pixels
     }
+#endif
     // <= 32 output channels: the layer is bound by its stores, and 32-column q-tiles write 256-byte runs per row instead of 128-byte
     // ones (64 -> 32 @512^2: 254 -> 232 us) -- worth more than the 16 columns of lanes a 513-wide q-row wastes
     if (a.c.N <= 32) return launch_t<1, 4, 2, 32>(a, s);

@@ -450,7 +450,8 @@ BF16_CASES = CONV_CASES + [
 # several tiles per workgroup, odd chunk counts, ragged rows (width % 4 != 0), heights that end inside a 16-row tile, 1x1 taps
 WS_CASES = [(3, 64, 128, 130, 190, 3, 1, 1, 1), (2, 80, 64, 257, 259, 3, 1, 1, 1), (2, 128, 192, 100, 132, 1, 1, 1, 0), (4, 256, 256, 64, 96, 3, 1, 1, 1),
             (2, 32, 32, 200, 262, 3, 1, 1, 1), (2, 64, 96, 130, 190, 3, 1, 1, 1), (4, 48, 32, 150, 170, 1, 1, 1, 0)]      # ... and its 32-output-channel variant
-# shapes the wave-specialised TRANSPOSED kernel takes (convt_bf16x3_ws_kernel: up = 2, K % 16 == 0, N % 32 == 0, >= 192 workgroups): its three
+# shapes the wave-specialised TRANSPOSED kernel would take (convt_bf16x3_ws_kernel, built only with -DGC_CTWS=1: measured no faster than the
+# one-role kernel; the cases stay as transposed-convolution coverage): up = 2, K % 16 == 0, N % 32 == 0, >= 192 workgroups -- its three
 # tile shapes (64 oc x 16 x 16 | 64 oc x 8 x 32 | 32 oc x 16 x 32 q-pixels), several tiles per workgroup, odd chunk counts, ragged widths
 TWS_CASES = [(4, 64, 128, 64, 64, 3, 2, 1, 2), (3, 48, 128, 100, 127, 3, 2, 1, 2), (3, 64, 32, 200, 130, 3, 2, 1, 2), (4, 32, 96, 70, 100, 3, 2, 1, 2),
              (4, 64, 64, 200, 260, 3, 2, 1, 2)]
@@ -476,15 +477,16 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
     if case in SMALL_CASES:
         from gan_control_amd.utils.profiling import conv_variant
         assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_f32_small_kernel'), 'this shape is meant to reach the small-plane kernel (exact fp32 in this mode too)'
+    tws = False
     if case in TWS_CASES:
         from gan_control_amd.utils.profiling import conv_variant
-        assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('convt_bf16x3_ws_kernel'), 'this shape is meant to reach the wave-specialised transposed kernel'
+        tws = conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('convt_bf16x3_ws_kernel')      # only in a library built with -DGC_CTWS=1
     for use_scales in (False, True):
         a = (si, so) if use_scales else (None, None)
         ref = emu.conv2d(x.double(), wt.double(), *[None if t is None else t.double() for t in a], geom)
         out = hip.conv2d(x.to(DEV), wt.to(DEV), *[None if t is None else t.to(DEV) for t in a], geom)
         assert rel_err(out, ref) < 5e-5, use_scales
-        if case in TWS_CASES:
+        if tws:
             # LDS-DMA data reaches its readers by a counted vmcnt wait + a barrier: a misplaced wait passes whenever the DMA happens to land
             # first, so the launch is repeated next to other traffic and every output must be bit-identical to the first
             junk = torch.randn(16 << 20, device=DEV)
