@@ -24,14 +24,15 @@ __global__ __launch_bounds__(256) void bias_act_plane_kernel(
     if (VEC) {
         const int64_t n4 = inner >> 2;
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-            float4 v = reinterpret_cast<const float4*>(xp)[i];
+            const gc::f32x4_t xv = gc::stream_load4(xp + 4 * i);
+            float4 v = make_float4(xv.x, xv.y, xv.z, xv.w);
             if (NOISE) {
                 const float4 nz = reinterpret_cast<const float4*>(np)[i];
                 v.x = fmaf(nw, nz.x, v.x); v.y = fmaf(nw, nz.y, v.y); v.z = fmaf(nw, nz.z, v.z); v.w = fmaf(nw, nz.w, v.w);
             }
             v.x = lrelu_gain(v.x + bv, slope, gain); v.y = lrelu_gain(v.y + bv, slope, gain);
             v.z = lrelu_gain(v.z + bv, slope, gain); v.w = lrelu_gain(v.w + bv, slope, gain);
-            reinterpret_cast<float4*>(yp)[i] = v;
+            gc::stream_store4(yp + 4 * i, v.x, v.y, v.z, v.w);
         }
     } else {
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < inner; i += (int64_t)gridDim.x * 256) {
@@ -72,12 +73,12 @@ __global__ __launch_bounds__(256) void bias_act_bwd_kernel(
         const int64_t n4 = count >> 2;
         const int64_t lo = (int64_t)blockIdx.x * BWD_RUN, hi = min(n4, lo + BWD_RUN);
         for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-            const float4 g = reinterpret_cast<const float4*>(dy)[i];
-            const float4 r = reinterpret_cast<const float4*>(yref)[i];
+            const gc::f32x4_t g = gc::stream_load4(dy + 4 * i);
+            const gc::f32x4_t r = gc::stream_load4(yref + 4 * i);
             float4 o;
             o.x = g.x * (r.x > 0.f ? pos : neg); o.y = g.y * (r.y > 0.f ? pos : neg);
             o.z = g.z * (r.z > 0.f ? pos : neg); o.w = g.w * (r.w > 0.f ? pos : neg);
-            reinterpret_cast<float4*>(dx)[i] = o;
+            gc::stream_store4(dx + 4 * i, o.x, o.y, o.z, o.w);
         }
         if (blockIdx.x == 0)
             for (int64_t i = (n4 << 2) + threadIdx.x; i < count; i += 256) dx[i] = dy[i] * (yref[i] > 0.f ? pos : neg);
@@ -137,11 +138,11 @@ __global__ __launch_bounds__(256) void bias_act_bwd_reduce_kernel(
     const int64_t n4 = (hi - lo) >> 2;
     for (int64_t v = threadIdx.x; v < n4; v += 256) {
         const int64_t i = lo + 4 * v;
-        const f4u y4 = *reinterpret_cast<const f4u*>(yref + base + i), g4 = *reinterpret_cast<const f4u*>(dy + base + i);
+        const f4u y4 = gc::stream_load4u(yref + base + i), g4 = gc::stream_load4u(dy + base + i);
         f4u z4 = {0.f, 0.f, 0.f, 0.f};
         if (NOISE) z4 = *reinterpret_cast<const f4u*>(np + i);
         const f4u o4 = {one(y4.x, g4.x, z4.x), one(y4.y, g4.y, z4.y), one(y4.z, g4.z, z4.z), one(y4.w, g4.w, z4.w)};
-        *reinterpret_cast<f4u*>(dx + base + i) = o4;
+        gc::stream_store4u(dx + base + i, o4.x, o4.y, o4.z, o4.w);
     }
     for (int64_t i = lo + 4 * n4 + threadIdx.x; i < hi; i += 256)
         dx[base + i] = one(yref[base + i], dy[base + i], NOISE ? np[i] : 0.f);
@@ -189,14 +190,14 @@ __global__ __launch_bounds__(256) void bias_act_bwd_reduce_adjoint_kernel(
     for (int64_t v = threadIdx.x; v < n4; v += 256) {
         const int64_t i = lo + 4 * v;
         const f4u y4 = *reinterpret_cast<const f4u*>(yref + base + i);
-        f4u g4 = {0.f, 0.f, 0.f, 0.f}, x4 = g4, z4 = g4, r4;
+        f4u g4 = {0.f, 0.f, 0.f, 0.f}, x4 = g4, z4 = g4;
         if (ggx) g4 = *reinterpret_cast<const f4u*>(ggx + base + i);
         if (cw) x4 = *reinterpret_cast<const f4u*>(dx + base + i);
         if (np) z4 = *reinterpret_cast<const f4u*>(np + i);
         float r0, r1, r2, r3;
         const f4u o4 = {one(y4.x, g4.x, x4.x, z4.x, &r0), one(y4.y, g4.y, x4.y, z4.y, &r1), one(y4.z, g4.z, x4.z, z4.z, &r2), one(y4.w, g4.w, x4.w, z4.w, &r3)};
-        *reinterpret_cast<f4u*>(g_dy + base + i) = o4;
-        if (g_yref) { r4 = {r0, r1, r2, r3}; *reinterpret_cast<f4u*>(g_yref + base + i) = r4; }
+        gc::stream_store4u(g_dy + base + i, o4.x, o4.y, o4.z, o4.w);
+        if (g_yref) gc::stream_store4u(g_yref + base + i, r0, r1, r2, r3);
     }
     for (int64_t i = lo + 4 * n4 + threadIdx.x; i < hi; i += 256) {
         float r;
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(256) void plane_dot_kernel(const float* __restrict_
     const int64_t n4 = (hi - lo) >> 2;
     for (int64_t v = threadIdx.x; v < n4; v += 256) {
         const int64_t i = lo + 4 * v;
-        const f4u a4 = *reinterpret_cast<const f4u*>(a + base + i), b4 = *reinterpret_cast<const f4u*>(b + base + i);
+        const f4u a4 = gc::stream_load4u(a + base + i), b4 = gc::stream_load4u(b + base + i);
         acc = fmaf(a4.x, b4.x, acc); acc = fmaf(a4.y, b4.y, acc); acc = fmaf(a4.z, b4.z, acc); acc = fmaf(a4.w, b4.w, acc);
     }
     for (int64_t i = lo + 4 * n4 + threadIdx.x; i < hi; i += 256) acc = fmaf(a[base + i], b[base + i], acc);
@@ -295,7 +296,7 @@ __global__ __launch_bounds__(256) void channel_sum_stage1(const float* __restric
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
 #pragma unroll 4
         for (int64_t i = lo / 4 + threadIdx.x; i < hi / 4; i += 256) {
-            const float4 v = x4[i];
+            const gc::f32x4_t v = gc::stream_load4(reinterpret_cast<const float*>(x4 + i));
             a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
         }
         acc = (a0 + a1) + (a2 + a3);

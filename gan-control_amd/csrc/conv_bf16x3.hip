@@ -92,6 +92,14 @@
 #endif
 #include <type_traits>
 
+// Output stores of the convolution kernels: non-temporal (aux bit 1 = the `nt` bit of gfx94x / gfx950 buffer stores) when GC_CONV_NT is set.
+// Round 4, same-box A/B on the whole step (two alternations): 75.15 -> 75.44 images/s on top of the streaming kernels' own non-temporal stores
+// (GC_NT_STORE, common.h: 74.17 -> 75.15).
+#ifndef GC_CONV_NT
+#define GC_CONV_NT 1
+#endif
+#define GC_CONV_ST_AUX (GC_CONV_NT ? 2 : 0)
+
 namespace {
 
 using namespace gcconv;
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
                     const int ocs = n0 + (wave_oc_u * WOC + i) * 32 + (r & 3) + 8 * (r >> 2);
                     float v = conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz);
                     if (p.residual) v += res[i][r];
-                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff, (int)((unsigned)ocs * oplane), 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff, (int)((unsigned)ocs * oplane), GC_CONV_ST_AUX);
                     acc[i][j][r] = 0.f;
                 }
             }
@@ -737,7 +745,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
                     const int ocl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const int ocs = nb + i * 32 + (r & 3) + 8 * (r >> 2);
                     const float v = p.residual ? acc[i][j][r] : conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz[j]);
-                    if (!(GC_WS_ABL & 8) || v == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff[j], (int)((unsigned)ocs * oplane), 0);
+                    if (!(GC_WS_ABL & 8) || v == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff[j], (int)((unsigned)ocs * oplane), GC_CONV_ST_AUX);
                     acc[i][j][r] = 0.f;
                 }
             }
@@ -1657,8 +1665,13 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
                     if (EPI == 2 && p.residual) { v0 += res[0][r]; v1 += res[1][r]; }
                     float* yp = yb + ((size_t)(n0 + ocl) * p.out_h + oy) * opitch + ox;
                     if ((GC_CT_ABL & 1) && v0 != 12345.678f) continue;
+#if GC_CONV_NT
+                    if (pair) { f2u v = {v0, v1}; __builtin_nontemporal_store(v, reinterpret_cast<f2u*>(yp)); }
+                    else __builtin_nontemporal_store(v0, yp);
+#else
                     if (pair) { f2u v = {v0, v1}; *reinterpret_cast<f2u*>(yp) = v; }
                     else yp[0] = v0;
+#endif
                 }
             }
         }
@@ -1936,8 +1949,8 @@ __global__ __launch_bounds__(768) void convt_bf16x3_ws_kernel(Bf16Args a) {
                 const int soff = (int)((unsigned)(nb + (r & 3) + 8 * (r >> 2)) * oplane);
                 if (!(GC_CTWS_ABL & 8) || v0 == 12345.678f) {
                     typedef int i32x2 __attribute__((ext_vector_type(2)));
-                    if (pair[j]) __builtin_amdgcn_raw_buffer_store_b64(i32x2{__builtin_bit_cast(int, v0), __builtin_bit_cast(int, v1)}, ry, (int)voff[j], soff, 0);
-                    else         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v0), ry, (int)voff[j], soff, 0);
+                    if (pair[j]) __builtin_amdgcn_raw_buffer_store_b64(i32x2{__builtin_bit_cast(int, v0), __builtin_bit_cast(int, v1)}, ry, (int)voff[j], soff, GC_CONV_ST_AUX);
+                    else         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v0), ry, (int)voff[j], soff, GC_CONV_ST_AUX);
                 }
                 acc[0][j][r] = 0.f; acc[1][j][r] = 0.f;
             }

@@ -37,7 +37,7 @@ __device__ __forceinline__ float4 ld4(const float* p, long long i, long long n) 
 }
 template <bool VEC>
 __device__ __forceinline__ void st4(float* p, long long i, long long n, float4 v) {
-    if (VEC) { *reinterpret_cast<float4*>(p + i) = v; return; }
+    if (VEC) { gc::stream_store4(p + i, v.x, v.y, v.z, v.w); return; }
     if (i < n) p[i] = v.x;
     if (i + 1 < n) p[i + 1] = v.y;
     if (i + 2 < n) p[i + 2] = v.z;

@@ -43,8 +43,16 @@ struct FirEpilogue {
 #define GC_FIR_NT 1
 #endif
 
+#ifndef GC_FIR_OCC
+#define GC_FIR_OCC 0          // dev knob: > 0 = waves per SIMD the tile kernel is compiled for (register cap 512 / OCC)
+#endif
+#if GC_FIR_OCC > 0
+#define GC_FIR_BOUNDS __launch_bounds__(256, GC_FIR_OCC)
+#else
+#define GC_FIR_BOUNDS __launch_bounds__(256)
+#endif
 template <bool VEC, int EPI, bool PRO = false>
-__global__ __launch_bounds__(256) void fir44_tile_kernel(
+__global__ GC_FIR_BOUNDS void fir44_tile_kernel(
     const float* __restrict__ x, const float* __restrict__ taps, float* __restrict__ y,
     int in_h, int in_w, int out_h, int out_w, int pad_x0, int pad_y0, int flip, FirEpilogue ep, int in_pitch, int out_pitch) {
     __shared__ __attribute__((aligned(16))) float patch[PH * PITCH];
@@ -225,7 +233,7 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
             if (oy >= out_h) break;
             float* dst = yp + (size_t)oy * out_pitch + ox;
             if (VEC) {
-                if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+                if (ox + 3 < out_w) gc::stream_store4(dst, acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
                 else {
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
@@ -234,7 +242,7 @@ __global__ __launch_bounds__(256) void fir44_tile_kernel(
             } else if (ox + 3 < out_w) {
                 // odd widths (1025, 513, ...): rows are only 4-byte aligned, which a 16-byte store accepts on gfx9 (as the
                 // 16-byte loads of the weight-gradient kernels do): one store instruction instead of four
-                *reinterpret_cast<f4u*>(dst) = f4u{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+                gc::stream_store4u(dst, acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -330,10 +338,9 @@ __global__ __launch_bounds__(256) void fir44_down2_kernel(
         if (oy >= out_h) break;
         float* dst = yp + (size_t)oy * out_w + ox;
         if (VEC) {
-            if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+            if (ox + 3 < out_w) gc::stream_store4(dst, acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
         } else if (ox + 3 < out_w) {
-            typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
-            *reinterpret_cast<f4s*>(dst) = f4s{acc[r][0], acc[r][1], acc[r][2], acc[r][3]};
+            gc::stream_store4u(dst, acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
         } else {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -412,10 +419,9 @@ __global__ __launch_bounds__(256) void fir44_up2_kernel(
         if (oy < out_h) {
             float* dst = yp + (size_t)oy * out_w + ox;
             if (VEC) {
-                if (ox + 3 < out_w) *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+                if (ox + 3 < out_w) gc::stream_store4(dst, o[0], o[1], o[2], o[3]);
             } else if (ox + 3 < out_w) {
-                typedef float f4s __attribute__((ext_vector_type(4), aligned(4)));
-                *reinterpret_cast<f4s*>(dst) = f4s{o[0], o[1], o[2], o[3]};
+                gc::stream_store4u(dst, o[0], o[1], o[2], o[3]);
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
