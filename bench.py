@@ -218,54 +218,65 @@ def cpu_baseline(size):
         avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
-    # How many threads?  Measured, not asserted: one D step (forward + backward: 89 % of a CPU iteration is convolution forward /
-    # backward) of the oracle at 256x256, batch 1, at each candidate count; the fastest runs the sample.  The sweep
-    # goes into the JSON line ("thread_sweep"); profiles/cpu_threads_r03.json holds a longer one at the sample's own resolution.
+    # How many threads?  Measured, not asserted, AT THE SAMPLE'S OWN RESOLUTION: one discriminator forward of the oracle (the convolution-heavy
+    # half of every phase) at `size`, batch 1, at each candidate count; the fastest runs the sample.  The sweep goes into the JSON line
+    # ("thread_sweep").  Candidates stop at 64: profiles/cpu_threads_r03.json holds the full sweep of this host class (128 threads 2.9x, all
+    # 256 threads 62x slower than the best -- oversubscribed MKL-DNN on per-sample convolutions), which would also cost minutes of bench time.
+    from oracle import networks as onet
     sweep = {}
-    torch.manual_seed(0)
-    cal = 256
-    g = Generator(cal, 512, 8, channel_multiplier=2, conv_transpose=True)
-    d = Discriminator(cal, channel_multiplier=2)
-    o = OracleStep(g.state_dict(), d.state_dict(), cal, 1)
-    gen = torch.Generator().manual_seed(0)
-    real = torch.rand(1, 3, cal, cal, generator=gen) * 2 - 1
-    z = torch.randn(1, 512, generator=gen)
-    # candidates stop at 64: profiles/cpu_threads_r03.json has the full sweep of this host class (128 threads 2.9x, all 256 threads 62x
-    # slower than the best -- oversubscribed MKL-DNN on small per-sample convolutions), which would also cost minutes of bench time
-    for n in sorted({c for c in (8, 16, 32, 64) if 1 <= c <= avail} or {avail}):
-        torch.set_num_threads(n)
-        o.d_step(real, z)                 # first call at this count: thread pool start-up, primitive caches
-        t0 = time.perf_counter()
-        o.d_step(real, z)
-        sweep[n] = time.perf_counter() - t0
-    cores = min(sweep, key=sweep.get)
-    torch.set_num_threads(cores)
     torch.manual_seed(0)
     g = Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True)
     d = Discriminator(size, channel_multiplier=2)
-    o = OracleStep(g.state_dict(), d.state_dict(), size, 1)
+    g_sd, d_sd = g.state_dict(), d.state_dict()
     gen = torch.Generator().manual_seed(0)
     real = torch.rand(1, 3, size, size, generator=gen) * 2 - 1
-    phases = {}
+    with torch.no_grad():
+        for n in sorted({c for c in (8, 16, 32, 64) if 1 <= c <= avail} or {avail}):
+            torch.set_num_threads(n)
+            onet.discriminator_forward(d_sd, real)          # first call at this count: thread pool start-up, primitive caches
+            t0 = time.perf_counter()
+            onet.discriminator_forward(d_sd, real)
+            sweep[n] = time.perf_counter() - t0
+    cores = min(sweep, key=sweep.get)
+    torch.set_num_threads(cores)
 
-    def timed(name, fn, *a):
-        t0 = time.perf_counter()
-        fn(*a)
-        phases[name] = time.perf_counter() - t0
+    def run_phases(batch, which):
+        o = OracleStep(g_sd, d_sd, size, batch)
+        x = torch.rand(batch, 3, size, size, generator=gen) * 2 - 1
+        out = {}
+        for name in which:
+            t0 = time.perf_counter()
+            if name == 'd_step':
+                o.d_step(x, torch.randn(batch, 512, generator=gen))
+            elif name == 'r1_step':
+                o.d_reg(x)
+            elif name == 'g_step':
+                o.g_step(torch.randn(batch, 512, generator=gen))
+            else:
+                o.g_reg(torch.randn(max(1, batch // 2), 512, generator=gen))
+            out[name] = time.perf_counter() - t0
+        return out
 
-    timed('d_step', o.d_step, real, torch.randn(1, 512, generator=gen))
-    timed('r1_step', o.d_reg, real)
-    timed('g_step', o.g_step, torch.randn(1, 512, generator=gen))
-    timed('pl_step', o.g_reg, torch.randn(1, 512, generator=gen))
+    phases = run_phases(1, ('d_step', 'r1_step', 'g_step', 'pl_step'))
     per_iter = phases['d_step'] + phases['g_step'] + phases['r1_step'] / 16 + phases['pl_step'] / 4
     plain = phases['d_step'] + phases['g_step']
-    return {'value': 1.0 / per_iter, 'unit': 'images/sec', 'cores': cores, 'host_cores': host_cores, 'kind': 'port',
-            'thread_sweep': {'workload': 'oracle D step (forward + backward) at 256x256, batch 1, seconds', 'seconds': {str(k): round(v, 3) for k, v in sweep.items()}},
-            'phase_seconds': {k: round(v, 2) for k, v in phases.items()},
-            'value_without_regularisers': 1.0 / plain,
-            'sample': f'one call of each phase (D step, R1, G step, path length) at {size}x{size}, batch 1, fp32, oracle/step.py OracleStep on '
-                      f'{cores} of {host_cores} host threads (the fastest of the thread sweep in this line), {sum(phases.values()):.1f} s; images/sec = 1 / (t_D + t_G + t_R1/16 + t_PL/4), '
-                      f'the cadence of the GPU step (the lazy regularisers are {100 * (per_iter / plain - 1):.0f} % of the CPU iteration)'}
+    out = {'value': 1.0 / per_iter, 'unit': 'images/sec', 'cores': cores, 'host_cores': host_cores, 'kind': 'port',
+           'thread_sweep': {'workload': 'oracle discriminator forward at %dx%d, batch 1, seconds' % (size, size), 'seconds': {str(k): round(v, 3) for k, v in sweep.items()}},
+           'phase_seconds': {k: round(v, 2) for k, v in phases.items()},
+           'value_without_regularisers': 1.0 / plain,
+           'sample': f'one call of each phase (D step, R1, G step, path length) at {size}x{size}, batch 1, fp32, oracle/step.py OracleStep on '
+                     f'{cores} of {host_cores} host threads (the fastest of the thread sweep in this line), {sum(phases.values()):.1f} s; images/sec = 1 / (t_D + t_G + t_R1/16 + t_PL/4), '
+                     f'the cadence of the GPU step (the lazy regularisers are {100 * (per_iter / plain - 1):.0f} % of the CPU iteration)'}
+    # The GPU step works on 4 images: the same plain iteration (D step + G step) once more at batch 4, where the host's cores have four
+    # samples to spread over -- skipped when the batch-1 sample was already slow, so that the default bench stays within a few minutes.
+    if plain <= 45.0:
+        four = run_phases(4, ('d_step', 'g_step'))
+        t4 = four['d_step'] + four['g_step']
+        out['batch4'] = {'value_without_regularisers': 4.0 / t4, 'phase_seconds': {k: round(v, 2) for k, v in four.items()},
+                         'note': 'D step + G step at batch 4 on the same threads; with the batch-1 share of the lazy regularisers: %.4f images/sec'
+                                 % (4.0 / (t4 * per_iter / plain))}
+        out['value_batch4'] = 4.0 / (t4 * per_iter / plain)
+    return out
 
 
 # Tests only (tests/bench_emulated_entry.py): the launcher / rank plumbing of this file exercised on CPUs over gloo with the emulated
