@@ -99,6 +99,10 @@
 #define GC_CONV_NT 1
 #endif
 #define GC_CONV_ST_AUX (GC_CONV_NT ? 2 : 0)
+#ifndef GC_WS_NT_LOAD
+#define GC_WS_NT_LOAD 0      // non-temporal patch loads in the wave-specialised forward kernel: measured SLOWER (dominant kernel 409 -> 386 TF/s, step -2 %):
+                             // every patch is re-read by the other output-channel blocks and by the neighbouring tiles' halos
+#endif
 
 namespace {
 
@@ -632,7 +636,8 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
                 const unsigned boff = ok ? (unsigned)(iy * p.in_w + ix) * 4u : OOB;
 #pragma unroll
                 for (int q = 0; q < 8; ++q)
-                    preg[j][q] = buf_load_u128(rx, boff, (unsigned)(k0 + kgl * 8 + q) * chan * 4u);     // channels past K: beyond the descriptor, zeros
+                    preg[j][q] = GC_WS_NT_LOAD ? __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)boff, (int)__builtin_amdgcn_readfirstlane((unsigned)(k0 + kgl * 8 + q) * chan * 4u), 2))
+                                               : buf_load_u128(rx, boff, (unsigned)(k0 + kgl * 8 + q) * chan * 4u);     // channels past K: beyond the descriptor, zeros
             }
         };
         auto convert = [&](uint4 (&preg)[C::NT][8], int tile, int k0, int buf) {

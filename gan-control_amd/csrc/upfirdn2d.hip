@@ -46,6 +46,10 @@ struct FirEpilogue {
 #ifndef GC_FIR_OCC
 #define GC_FIR_OCC 0          // dev knob: > 0 = waves per SIMD the tile kernel is compiled for (register cap 512 / OCC)
 #endif
+#ifndef GC_FIR_NT_LOAD
+#define GC_FIR_NT_LOAD 0      // 1 = non-temporal loads of the input patch: measured SLOWER (whole step 75.78 -> 75.10 images/s, in-step FIR 4.70 -> 4.35 TB/s):
+                              // the halo rows are re-read by the neighbouring tiles out of L2
+#endif
 #if GC_FIR_OCC > 0
 #define GC_FIR_BOUNDS __launch_bounds__(256, GC_FIR_OCC)
 #else
@@ -82,7 +86,11 @@ __global__ GC_FIR_BOUNDS void fir44_tile_kernel(
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         const float* src = rowp + ix;
         if (ix >= 0 && ix + 3 < width) {
+#if GC_FIR_NT_LOAD
+            const f4u t = __builtin_nontemporal_load(reinterpret_cast<const f4u*>(src));
+#else
             const f4u t = *reinterpret_cast<const f4u*>(src);
+#endif
             v = make_float4(t.x, t.y, t.z, t.w);
         } else {
             if (ix >= 0 && ix < width) v.x = src[0];

@@ -31,4 +31,25 @@ for (B, K, N, res, k) in [(4, 512, 512, 64, 3), (8, 256, 256, 128, 3), (4, 128, 
     torch.cuda.synchronize()
     print(f'{B}x{K}->{N} @{res} k{k}: {reps} launches, {n_bad} differ from the first; checksum {float(first.double().sum()):.6f} finite={bool(torch.isfinite(first).all())}')
     bad += n_bad
+# The weight-gradient kernels (round 4): deterministic two-stage reductions over pixel splits, no atomics -- every launch must reproduce the
+# first bit for bit, stride 1 and stride 2, with and without per-sample scales, and the per-sample form (dw + its B shares).
+for (B, K, N, res, k, down) in [(4, 512, 512, 64, 3, 1), (8, 256, 256, 128, 3, 1), (4, 32, 32, 1024, 3, 1), (8, 128, 256, 257, 3, 2), (8, 32, 64, 1025, 3, 2), (4, 128, 256, 128, 1, 1)]:
+    pad = k // 2 if down == 1 else 0
+    oh = (res + 2 * pad - k) // down + 1
+    g = ConvGeom(k, k, 1, down, pad, pad, oh, oh)
+    x = torch.randn(B, K, res, res, generator=gen).cuda(); dy = torch.randn(B, N, oh, oh, generator=gen).cuda()
+    si = torch.randn(B, K, generator=gen).cuda(); so = (torch.rand(B, N, generator=gen) + 0.5).cuda()
+    for scales in ((None, None), (si, so)):
+        first = be.conv2d_wgrad(x, dy, scales[0], scales[1], g).clone()
+        n_bad = 0
+        wreps = max(reps // 5, 20)
+        for i in range(wreps):
+            if i % 3 == 0:
+                junk.mul_(1.0001)
+            if not torch.equal(be.conv2d_wgrad(x, dy, scales[0], scales[1], g), first):
+                n_bad += 1
+        torch.cuda.synchronize()
+        print(f'wgrad {B}x{K}->{N} @{res} k{k} down{down} scales={scales[0] is not None}: {wreps} launches, {n_bad} differ from the first; finite={bool(torch.isfinite(first).all())}')
+        bad += n_bad
+    del x, dy
 print('RACE SCREEN', 'FAILED' if bad else 'clean')
