@@ -26,7 +26,7 @@ from ..models.gan_model import Generator, Discriminator
 from ..models.op import _backend
 from ..utils.fc_config import fc_config_from_sub_groups
 from . import ddp
-from .utils import accumulate, requires_grad, mixing_noise, make_mini_batch_from_noise, set_grad_none
+from .utils import accumulate, requires_grad, mixing_noise, make_mini_batch_from_noise, set_grad_none, named_params, zero_grad_none
 from .non_leaking import augment, AdaptiveAugmentState
 
 
@@ -227,7 +227,7 @@ class GeneratorTrainer:
         """Reference autograd yields ZERO (not None) gradients for parameters that only reach a
         regulariser through an activation mask (Appendix C #6), so Adam still steps them on
         momentum.  The fused ops cut those dead paths; restore the zeros here."""
-        for n, p in module.named_parameters():
+        for n, p in named_params(module):
             if p.requires_grad and p.grad is None and n not in none_names:
                 p.grad = torch.zeros_like(p)
 
@@ -238,7 +238,7 @@ class GeneratorTrainer:
 
     def _discriminator_step(self, mini_noise_inputs, mini_real_inputs, noise=None):
         self.stats['d_loss'] = 0
-        self.discriminator.zero_grad(set_to_none=True)
+        zero_grad_none(self.discriminator)
         n = len(mini_real_inputs)
         for k, (real, z) in enumerate(zip(mini_real_inputs, mini_noise_inputs)):
             self.d_reducer.begin(sync=(k == n - 1), phase='d')
@@ -282,7 +282,7 @@ class GeneratorTrainer:
     def discriminator_regularize_step(self, mini_real_inputs):
         tc = self.training_config
         self.stats['d_r1_loss'] = 0
-        self.discriminator.zero_grad(set_to_none=True)
+        zero_grad_none(self.discriminator)
         n = len(mini_real_inputs)
         for k, real in enumerate(mini_real_inputs):
             self.d_reducer.begin(sync=(k == n - 1), phase='r1')
@@ -310,7 +310,7 @@ class GeneratorTrainer:
     # -- generator ----------------------------------------------------------------------------------
     def generator_step(self, mini_noise_inputs, noise=None):
         self.stats['g_adv_loss'] = 0
-        self.generator.zero_grad(set_to_none=True)
+        zero_grad_none(self.generator)
         n = len(mini_noise_inputs)
         for name in (self.loss_models if self.batch_utils is not None else ()):
             self.stats['g_' + name] = 0
@@ -355,7 +355,7 @@ class GeneratorTrainer:
             z = self.sample_z(path_batch)
         # the reference chunks the path batch with the full-batch chunk count (:574-575)
         mini_z = make_mini_batch_from_noise(z, self.local_batch, self.local_mini_batch)
-        self.generator.zero_grad(set_to_none=True)
+        zero_grad_none(self.generator)
         n = len(mini_z)
         reduce_mean = ddp.all_reduce_mean_ if ddp.is_dist() else None
         self.stats['g_path_loss'] = self.stats['g_path_length'] = self.stats['g_mean_path_length'] = 0

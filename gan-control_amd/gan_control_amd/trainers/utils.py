@@ -5,15 +5,36 @@ for device-resident execution: the EMA is two foreach kernels over all parameter
 per-tensor ops, and latent sampling takes an explicit device generator so every rank draws its own stream.
 """
 import random
+import weakref
 
 import torch
+
+# (name, parameter) lists per network, built once: Module.named_parameters() walks the whole module tree on every call, and one training
+# iteration asks for it ~20 times (freeze / unfreeze, zero_grad, EMA, the None-gradient bookkeeping) -- ~3 ms of host time per step at
+# FFHQ-1024 (tools/host_profile.py iter).  The parameter SET of a network does not change while it trains; a network whose set does change
+# (load_state_dict(assign=True), added modules) is re-listed because the count no longer matches.
+_NAMED = weakref.WeakKeyDictionary()
+
+
+def named_params(model):
+    hit = _NAMED.get(model)
+    if hit is None or hit[0] != sum(len(m._parameters) for m in model.modules()) or any(p is not q for (_, p), q in zip(hit[1][:4], hit[2][:4])):
+        lst = list(model.named_parameters())
+        hit = _NAMED[model] = (sum(len(m._parameters) for m in model.modules()), lst, [p for _, p in lst])
+    return hit[1]
+
+
+def zero_grad_none(model):
+    """model.zero_grad(set_to_none=True) without the module-tree walk."""
+    for _, p in named_params(model):
+        p.grad = None
 
 
 def accumulate(model1, model2, decay=0.999):
     """model1 <- decay * model1 + (1 - decay) * model2 over NAMED PARAMETERS only; buffers (the per-layer noise
     maps, blur kernels) are not averaged (reference utils.py:8-12; SURVEY Appendix C #7)."""
-    target = dict(model1.named_parameters())
-    source = dict(model2.named_parameters())
+    target = dict(named_params(model1))
+    source = dict(named_params(model2))
     names = sorted(target)
     dst = [target[n].data for n in names]
     src = [source[n].data for n in names]
@@ -25,7 +46,7 @@ def accumulate(model1, model2, decay=0.999):
 
 def requires_grad(model, flag=True):
     """Freeze / unfreeze every parameter of a network (reference utils.py:14-16)."""
-    for param in model.parameters():
+    for _, param in named_params(model):
         param.requires_grad_(flag)
 
 
@@ -56,6 +77,6 @@ def make_mini_batch_from_noise(noise, batch, mini_batch):
 
 def set_grad_none(model, targets):
     """Drop the gradients of the named parameters so Adam skips them (reference utils.py:45-48)."""
-    for name, param in model.named_parameters():
+    for name, param in named_params(model):
         if name in targets:
             param.grad = None

@@ -22,7 +22,16 @@ for i in range(2):
     tr.train_iteration(i * 16, real)
 
 
+_it = [1]
+
+
 def run():
+    if phase == 'iter':          # a plain iteration (no lazy regulariser): i = 1, 2, 3, 5, ...
+        while _it[0] % 4 == 0:
+            _it[0] += 1
+        tr.train_iteration(_it[0], real)
+        _it[0] += 1
+        return
     if phase == 'd_step':
         requires_grad(tr.generator, False); requires_grad(tr.discriminator, True)
         tr.discriminator_step(make_mini_batch_from_noise(tr.sample_z(batch), batch, batch), [real])
