@@ -83,6 +83,39 @@ def pitch_allowed():
     return _PITCHED_OUTPUT and _PITCH_ALLOWED[0]
 
 
+# Function.apply() costs ~15-25 us of host time per call (ctx, saved tensors, output wrapping) whether or not a graph is recorded, and one
+# training iteration makes ~320 such calls going forward and ~500 more NESTED inside backward passes (every backward of this package is written
+# with differentiable Functions so that R1 / path-length double-backward work).  When no graph CAN result -- grad mode is off (a plain backward),
+# or no tensor argument requires a gradient (the generator forward of the D step, the discriminator of the G step's ... frozen parameters) --
+# the Function's forward is called directly with a context that swallows the bookkeeping: same kernels, same values, none of the overhead.
+class _NoGraphCtx:
+    __slots__ = ('__dict__',)
+
+    def save_for_backward(self, *tensors):
+        pass
+
+    def set_materialize_grads(self, value):
+        pass
+
+    def mark_non_differentiable(self, *tensors):
+        pass
+
+
+_DIRECT = os.environ.get('GANCONTROL_DIRECT_FORWARD', '1') != '0'      # dev knob: 0 = always Function.apply
+
+
+def call(fn, *args):
+    """fn.apply(*args), or fn.forward(...) directly when autograd would record nothing."""
+    if _DIRECT:
+        if not torch.is_grad_enabled():
+            return fn.forward(_NoGraphCtx(), *args)
+        for a in args:
+            if isinstance(a, torch.Tensor) and a.requires_grad:
+                return fn.apply(*args)
+        return fn.forward(_NoGraphCtx(), *args)
+    return fn.apply(*args)
+
+
 # Geometry of the generalised convolution (gc_conv_desc minus batch/channels/in-size, which come from tensors)
 ConvGeom = namedtuple('ConvGeom', 'kh kw up down pad_y pad_x out_h out_w')
 

@@ -58,7 +58,7 @@ class _GConv(Function):
         g = ctx.geom
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _GConv.apply(gy, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw))
+            gx = _backend.call(_GConv, gy, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw))
         if ctx.needs_input_grad[1] and _backend.want_param_grads():
             gw = _weight_grad(x, gy, g)
         want_res = len(ctx.needs_input_grad) > 3 and ctx.needs_input_grad[3]
@@ -67,10 +67,10 @@ class _GConv(Function):
 
 def _weight_grad(x, gy, g):
     if g.up == 1:
-        return _WGrad.apply(x, gy, g)
+        return _backend.call(_WGrad, x, gy, g)
     # transposed conv: correlate gy (as the "input", decimated by `up`) with x (as the "output gradient")
     swapped = ConvGeom(g.kh, g.kw, 1, g.up, g.kh - 1 - g.pad_y, g.kw - 1 - g.pad_x, x.shape[2], x.shape[3])
-    return adjoint_layout(_WGrad.apply(gy, x, swapped))
+    return adjoint_layout(_backend.call(_WGrad, gy, x, swapped))
 
 
 class _WGrad(Function):
@@ -90,9 +90,9 @@ class _WGrad(Function):
         g = ctx.geom
         gx = ggy = None
         if ctx.needs_input_grad[0]:
-            gx = _GConv.apply(gy, _adjoint_weight(ggw), _adjoint_geom(g, *ctx.in_hw))
+            gx = _backend.call(_GConv, gy, _adjoint_weight(ggw), _adjoint_geom(g, *ctx.in_hw))
         if ctx.needs_input_grad[1]:
-            ggy = _GConv.apply(x, ggw.contiguous(), g)
+            ggy = _backend.call(_GConv, x, ggw.contiguous(), g)
         return gx, ggy, None
 
 
@@ -149,12 +149,12 @@ class _GConvAct(Function):
             if ctx.needs_input_grad[2] and params:
                 gb = _channel_sum(gy)
         elif ctx.needs_input_grad[2] and params:
-            g_pre, psum = _BiasActGradReduce.apply(gy, out, None, slope, gain)[:2]
+            g_pre, psum = _backend.call(_BiasActGradReduce, gy, out, None, slope, gain)[:2]
             gb = psum.sum((0, 2))
         else:
-            g_pre = _BiasActGrad.apply(gy, out, slope, gain)
+            g_pre = _backend.call(_BiasActGrad, gy, out, slope, gain)
         if ctx.needs_input_grad[0]:
-            gx = _GConv.apply(g_pre, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw), gfork)
+            gx = _backend.call(_GConv, g_pre, _adjoint_weight(w_t), _adjoint_geom(g, *ctx.in_hw), gfork)
         if ctx.needs_input_grad[1] and params:
             gw = _weight_grad(x, g_pre, g)
         return gx, gw, gb, None, None, None, None, None
@@ -180,7 +180,7 @@ def conv2d_t(x, w_t, stride=1, padding=0, residual=None):
     kh, kw = w_t.shape[0], w_t.shape[1]
     oh = (x.shape[2] + 2 * padding - kh) // stride + 1
     ow = (x.shape[3] + 2 * padding - kw) // stride + 1
-    return _GConv.apply(x, w_t, ConvGeom(kh, kw, 1, stride, padding, padding, oh, ow), residual)
+    return _backend.call(_GConv, x, w_t, ConvGeom(kh, kw, 1, stride, padding, padding, oh, ow), residual)
 
 
 def conv_transpose2d_t(x, w_t, stride=1, padding=0):
@@ -188,7 +188,7 @@ def conv_transpose2d_t(x, w_t, stride=1, padding=0):
     kh, kw = w_t.shape[0], w_t.shape[1]
     oh = (x.shape[2] - 1) * stride - 2 * padding + kh
     ow = (x.shape[3] - 1) * stride - 2 * padding + kw
-    return _GConv.apply(x, w_t, ConvGeom(kh, kw, stride, 1, kh - 1 - padding, kw - 1 - padding, oh, ow))
+    return _backend.call(_GConv, x, w_t, ConvGeom(kh, kw, stride, 1, kh - 1 - padding, kw - 1 - padding, oh, ow))
 
 
 def conv2d(input, weight, bias=None, stride=1, padding=0, dilation=1, groups=1, weight_scale=1.0, residual=None):
@@ -215,7 +215,7 @@ def conv2d_bias_act(input, weight, bias, stride=1, padding=0, weight_scale=1.0, 
     kh, kw = weight.shape[2], weight.shape[3]
     oh = (input.shape[2] + 2 * p - kh) // s + 1
     ow = (input.shape[3] + 2 * p - kw) // s + 1
-    return _GConvAct.apply(input, kernel_layout(weight, weight_scale), bias.reshape(-1).contiguous(),
+    return _backend.call(_GConvAct, input, kernel_layout(weight, weight_scale), bias.reshape(-1).contiguous(),
                            ConvGeom(kh, kw, 1, s, p, p, oh, ow), float(negative_slope), float(scale), bool(fork), bool(grad_premasked))
 
 

@@ -13,7 +13,7 @@ from . import _backend
 
 
 def _channel_sum(t):
-    return _ChannelSum.apply(t)
+    return _backend.call(_ChannelSum, t)
 
 
 class _ChannelSum(Function):
@@ -57,13 +57,13 @@ class _BiasAct(Function):
         want_nw = ctx.has_noise and ctx.needs_input_grad[3] and params
         if (want_b or want_nw) and not want_n:
             # one pass: activation gradient + per-plane partial sums for the bias / noise-strength gradients
-            gx, psum, pdot = _BiasActGradReduce.apply(gy, y, noise if want_nw else None, slope, gain)[:3]
+            gx, psum, pdot = _backend.call(_BiasActGradReduce, gy, y, noise if want_nw else None, slope, gain)[:3]
             if want_b:
                 gb = psum.sum((0, 2))
             if want_nw:
                 gnw = pdot.sum().reshape(noise_w.shape)
         else:
-            gx = _BiasActGrad.apply(gy, y, slope, gain)
+            gx = _backend.call(_BiasActGrad, gy, y, slope, gain)
             if want_b:
                 gb = _channel_sum(gx)
             if want_n or want_nw:
@@ -165,7 +165,7 @@ class _BiasActGradReduce(Function):
                 g_bias = -wg.sum([d for d in range(y.ndim) if d != 1])
             if ctx.has_noise and ctx.needs_input_grad[6]:
                 g_nw = -(wg * noise4).sum().reshape(noise_w.shape)
-        g_gy = _BiasActGrad.apply(total, y, slope, gain) if ctx.needs_input_grad[0] else None
+        g_gy = _backend.call(_BiasActGrad, total, y, slope, gain) if ctx.needs_input_grad[0] else None
         if g_y is None and ctx.needs_input_grad[1] and _backend.strict_zeros():
             g_y = torch.zeros_like(y)
         return g_gy, g_y, None, None, None, g_bias, g_nw, None
@@ -187,7 +187,7 @@ class _BiasActGrad(Function):
             return None, None, None, None
         y, = ctx.saved_tensors
         slope, gain = ctx.cfg
-        ggy = _BiasActGrad.apply(ggx, y, slope, gain) if ctx.needs_input_grad[0] else None
+        ggy = _backend.call(_BiasActGrad, ggx, y, slope, gain) if ctx.needs_input_grad[0] else None
         # d/dy of the mask is zero almost everywhere: no gradient flows to the forward output (zeros only for the dry run)
         return ggy, (torch.zeros_like(y) if (ctx.needs_input_grad[1] and _backend.strict_zeros()) else None), None, None
 
@@ -204,7 +204,7 @@ def fused_noise_bias_act(input, bias=None, noise=None, noise_weight=None, negati
         if noise.shape[0] != input.shape[0] or noise.numel() * input.shape[1] != input.numel():
             raise ValueError(f'noise shape {tuple(noise.shape)} does not match input {tuple(input.shape)}')
         noise_weight = noise_weight.reshape(-1).contiguous()
-    return _BiasAct.apply(input, bias, noise, noise_weight, float(negative_slope), float(scale))
+    return _backend.call(_BiasAct, input, bias, noise, noise_weight, float(negative_slope), float(scale))
 
 
 def fused_leaky_relu(input, bias, negative_slope=0.2, scale=2 ** 0.5):

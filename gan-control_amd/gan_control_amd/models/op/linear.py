@@ -10,6 +10,7 @@ import os
 
 import torch
 from torch import autograd
+from . import _backend
 
 _SMALL_GEMM = os.environ.get('GANCONTROL_SMALL_GEMM', '1') != '0'
 
@@ -51,8 +52,8 @@ class _ScaledMM(autograd.Function):
     @staticmethod
     def backward(ctx, g):
         a, b = ctx.saved_tensors
-        ga = _ScaledMM.apply(g, b.t(), ctx.alpha) if ctx.needs_input_grad[0] else None
-        gb = _ScaledMM.apply(a.t(), g, ctx.alpha) if ctx.needs_input_grad[1] else None
+        ga = _backend.call(_ScaledMM, g, b.t(), ctx.alpha) if ctx.needs_input_grad[0] else None
+        gb = _backend.call(_ScaledMM, a.t(), g, ctx.alpha) if ctx.needs_input_grad[1] else None
         return ga, gb, None
 
 
@@ -68,8 +69,8 @@ class _EqualLinearFn(autograd.Function):
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
-        gx = _ScaledMM.apply(g, weight, ctx.alpha) if ctx.needs_input_grad[0] else None
-        gw = _ScaledMM.apply(g.t(), x, ctx.alpha) if ctx.needs_input_grad[1] else None
+        gx = _backend.call(_ScaledMM, g, weight, ctx.alpha) if ctx.needs_input_grad[0] else None
+        gw = _backend.call(_ScaledMM, g.t(), x, ctx.alpha) if ctx.needs_input_grad[1] else None
         gb = (g.sum(0) * ctx.beta if ctx.beta != 1 else g.sum(0)) if ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None
 
@@ -77,9 +78,9 @@ class _EqualLinearFn(autograd.Function):
 
 
 def scaled_mm(a, b, alpha):
-    return _ScaledMM.apply(a, b, float(alpha))
+    return _backend.call(_ScaledMM, a, b, float(alpha))
 
 
 def equal_linear(x, weight, bias, alpha, beta):
     """beta * bias [N] + alpha * (x [M, K] @ weight[N, K]^T)."""
-    return _EqualLinearFn.apply(x, weight, bias, float(alpha), float(beta))
+    return _backend.call(_EqualLinearFn, x, weight, bias, float(alpha), float(beta))

@@ -141,12 +141,12 @@ class _WeightSqAll(Function):
 
 def weight_sq_all(weights):
     """[sum over the taps of W^2, [OC, IC]] for every [1, OC, IC, k, k] (or [OC, IC, k, k]) weight of the list."""
-    return list(_WeightSqAll.apply(*[w.view(w.shape[-4:]) for w in weights]))
+    return list(_backend.call(_WeightSqAll, *[w.view(w.shape[-4:]) for w in weights]))
 
 
 def demod_coefficients(weight, s, scale, eps=1e-8):
     """d[b,oc] = rsqrt(sum_{ic,k} (scale * W[oc,ic,k] * s[b,ic])^2 + eps); weight is [1,OC,IC,k,k], s is [B,IC]."""
-    wsq = _WeightSq.apply(weight.view(weight.shape[1:]))       # [OC, IC]  (view, not weight[0]: its backward is free)
+    wsq = _backend.call(_WeightSq, weight.view(weight.shape[1:]))       # [OC, IC]  (view, not weight[0]: its backward is free)
     # scale^2 * (s^2 @ wsq^T) + eps as ONE GEMM call (alpha, bias epilogue) in every direction of differentiation (op/linear.py)
     from .linear import equal_linear
     return torch.rsqrt(equal_linear(s.pow(2), wsq, _eps_vector(s, wsq.shape[0], eps), scale * scale, 1.0))
@@ -179,7 +179,7 @@ class _SafeDiv(Function):
         if g is None:
             return None, None
         den, out = ctx.saved_tensors
-        gq = _SafeDiv.apply(g, den)
+        gq = _backend.call(_SafeDiv, g, den)
         return (gq if ctx.needs_input_grad[0] else None), (-(gq * out) if ctx.needs_input_grad[1] else None)
 
 
@@ -200,7 +200,7 @@ class _SumDiv(Function):
         if g is None:
             return None, None
         den, out = ctx.saved_tensors
-        gq = _SafeDiv.apply(g, den)
+        gq = _backend.call(_SafeDiv, g, den)
         return (gq.unsqueeze(-1).expand(*gq.shape, ctx.chunks) if ctx.needs_input_grad[0] else None), (-(gq * out) if ctx.needs_input_grad[1] else None)
 
 
@@ -220,7 +220,7 @@ class _PlaneDot(Function):
         if g is None:
             return None, None, None
         a, b, den, out = ctx.saved_tensors
-        gq = _SafeDiv.apply(g, den) if ctx.has_den else g
+        gq = _backend.call(_SafeDiv, g, den) if ctx.has_den else g
         g4 = gq[:, :, None, None]
         return (g4 * b if ctx.needs_input_grad[0] else None), (g4 * a if ctx.needs_input_grad[1] else None), \
             (-(gq * out) if ctx.has_den and ctx.needs_input_grad[2] else None)
@@ -267,7 +267,7 @@ class _ModConv(Function):
         need_so = ctx.has_so and need[3]
         fused = need[1] and _backend.want_param_grads() and _samples_route(x, gy, g, need_si, need_so, ctx.derived)
         if need[0] or (need_si and not fused):
-            gx = _ModConv.apply(gy, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw), None, gfork if need[0] else None, False, True)
+            gx = _backend.call(_ModConv, gy, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw), None, gfork if need[0] else None, False, True)
         if fused:
             gw, gsi, gso = _weight_and_scale_grads(x, gy, w_t, si, so, g, need_si, need_so)
             need_si = need_so = False
@@ -276,14 +276,14 @@ class _ModConv(Function):
         if need_si:
             # d/dsi sees the convolution only, not the forked gradient that was added in the epilogue
             conv_part = gx if (gfork is None or not need[0]) else gx - gfork
-            gsi = _PlaneDot.apply(x, conv_part, si)
+            gsi = _backend.call(_PlaneDot, x, conv_part, si)
         if need_so:
             conv_part = y
             if ctx.has_res:
                 conv_part = conv_part - res
             if ctx.has_bias:
                 conv_part = conv_part - bias.reshape(1, -1, 1, 1)
-            gso = _PlaneDot.apply(gy, conv_part, so)
+            gso = _backend.call(_PlaneDot, gy, conv_part, so)
         if ctx.has_bias and need[5] and _backend.want_param_grads():
             from .fused_act import _channel_sum
             gb = _channel_sum(gy)
@@ -330,25 +330,25 @@ class _ModConvAct(Function):
             need = list(need)
             need[1] = need[4] = need[6] = False          # weight, bias, noise strength
         if (has_bias and need[4]) or (has_noise and need[6]) or want_so:
-            g_pre, psum, pdot, pself = _BiasActGradReduce.apply(gy, out, noise, slope, gain, bias, noise_w, want_so)
+            g_pre, psum, pdot, pself = _backend.call(_BiasActGradReduce, gy, out, noise, slope, gain, bias, noise_w, want_so)
             if has_bias and need[4]:
                 gb = psum.sum((0, 2))
             if has_noise and need[6]:
                 gnw = pdot.sum().reshape(noise_w.shape)
             if want_so:
-                gso = _SumDiv.apply(pself, so)
+                gso = _backend.call(_SumDiv, pself, so)
         else:
-            g_pre = _BiasActGrad.apply(gy, out, slope, gain)
+            g_pre = _backend.call(_BiasActGrad, gy, out, slope, gain)
         need_si = has_si and need[2]
         fused = need[1] and _samples_route(x, g_pre, g, need_si, False)
         if need[0] or (need_si and not fused):
-            gx = _ModConv.apply(g_pre, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw), None, None, False, True)
+            gx = _backend.call(_ModConv, g_pre, _adjoint_weight(w_t), so, si, _adjoint_geom(g, *ctx.in_hw), None, None, False, True)
         if fused:
             gw, gsi, _ = _weight_and_scale_grads(x, g_pre, w_t, si, so, g, True, False)
         elif need[1]:
             gw = _mod_weight_grad(x, g_pre, si, so, g)
         if need_si and not fused:
-            gsi = _PlaneDot.apply(x, gx, si)
+            gsi = _backend.call(_PlaneDot, x, gx, si)
         return (gx if need[0] else None), gw, gsi, gso, gb, None, gnw, None, None, None
 
 
@@ -359,8 +359,8 @@ def _swapped_geom(g, x):
 
 def _mod_weight_grad(x, gy, si, so, g):
     if g.up == 1:
-        return _ModWGrad.apply(x, gy, si, so, g)
-    return _adjoint_weight(_ModWGrad.apply(gy, x, so, si, _swapped_geom(g, x)))
+        return _backend.call(_ModWGrad, x, gy, si, so, g)
+    return _adjoint_weight(_backend.call(_ModWGrad, gy, x, so, si, _swapped_geom(g, x)))
 
 
 class _ModWGrad(Function):
@@ -388,13 +388,13 @@ class _ModWGrad(Function):
         need_si = ctx.has_si and ctx.needs_input_grad[2]
         need_so = ctx.has_so and ctx.needs_input_grad[3]
         if ctx.needs_input_grad[0] or need_si:
-            gx = _ModConv.apply(gy, _adjoint_weight(ggw), so, si, _adjoint_geom(g, *ctx.in_hw), None, None, False, True)
+            gx = _backend.call(_ModConv, gy, _adjoint_weight(ggw), so, si, _adjoint_geom(g, *ctx.in_hw), None, None, False, True)
         if ctx.needs_input_grad[1] or need_so:
-            ggy = _ModConv.apply(x, ggw.contiguous(), si, so, g, None, None, False, True)
+            ggy = _backend.call(_ModConv, x, ggw.contiguous(), si, so, g, None, None, False, True)
         if need_si:
-            gsi = _PlaneDot.apply(x, gx, si)
+            gsi = _backend.call(_PlaneDot, x, gx, si)
         if need_so:
-            gso = _PlaneDot.apply(gy, ggy, so)
+            gso = _backend.call(_PlaneDot, gy, ggy, so)
         return (gx if ctx.needs_input_grad[0] else None), (ggy if ctx.needs_input_grad[1] else None), gsi, gso, None
 
 
@@ -414,16 +414,16 @@ def modulated_conv2d(x, weight, s, demodulate=True, upsample=False, blur_kernel=
             raise NotImplementedError('modulated_conv2d: bias / residual / fork are built for the plain branch only')
         w_t = kernel_layout(weight.view(oc, ic, k, k), scale, flip=True)                   # correlation form, [k,k,IC,OC]
         oh, ow = (x.shape[2] - 1) * 2 + k, (x.shape[3] - 1) * 2 + k
-        y = _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 2, 1, k - 1, k - 1, oh, ow))
+        y = _backend.call(_ModConv, x, w_t, s, d, ConvGeom(k, k, 2, 1, k - 1, k - 1, oh, ow))
         # apply_blur=False (StyledConv): the caller fuses the Blur with what follows and reads the (possibly row-pitched) tensor in place
         return upfirdn2d(y, blur_kernel, pad=blur_pad) if apply_blur else y
     pad = k // 2 if padding is None else padding
     w_t = kernel_layout(weight.view(oc, ic, k, k), scale)
     oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1
     if bias is None and residual is None and not fork:
-        return _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow))
+        return _backend.call(_ModConv, x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow))
     # plain branch only: `+ bias` / `+ residual` in the convolution's epilogue, fork = (y, x for its other consumer)
-    return _ModConv.apply(x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow), None if bias is None else bias.reshape(-1).contiguous(), residual, bool(fork))
+    return _backend.call(_ModConv, x, w_t, s, d, ConvGeom(k, k, 1, 1, pad, pad, oh, ow), None if bias is None else bias.reshape(-1).contiguous(), residual, bool(fork))
 
 
 def modulated_conv2d_act(x, weight, s, bias, noise, noise_weight, demodulate=True, padding=None, negative_slope=0.2, act_scale=2 ** 0.5, demod=None):
@@ -436,5 +436,5 @@ def modulated_conv2d_act(x, weight, s, bias, noise, noise_weight, demodulate=Tru
     oh, ow = x.shape[2] + 2 * pad - k + 1, x.shape[3] + 2 * pad - k + 1
     if noise.shape[0] != x.shape[0] or noise.numel() != x.shape[0] * oh * ow:
         raise ValueError(f'noise shape {tuple(noise.shape)} does not match the output [{x.shape[0]}, {oc}, {oh}, {ow}]')
-    return _ModConvAct.apply(x, w_t, s, d, bias.reshape(-1).contiguous(), noise, noise_weight.reshape(-1).contiguous(),
+    return _backend.call(_ModConvAct, x, w_t, s, d, bias.reshape(-1).contiguous(), noise, noise_weight.reshape(-1).contiguous(),
                              ConvGeom(k, k, 1, 1, pad, pad, oh, ow), float(negative_slope), float(act_scale))

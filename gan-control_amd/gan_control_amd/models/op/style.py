@@ -75,11 +75,11 @@ class _GLFwd(Function):
         plan, batch = ctx.plan, ctx.batch
         g = len(plan.specs)
         need = ctx.needs_input_grad
-        gx = _GLBwdX.apply(gy, plan, batch, *weights) if need[0] else None
+        gx = _backend.call(_GLBwdX, gy, plan, batch, *weights) if need[0] else None
         gws, gbs = [None] * g, [None] * g
         want_w = any(need[3:3 + g]) or any(need[3 + g:])
         if want_w and _backend.want_param_grads():
-            outs = _GLBwdW.apply(gy, x, plan, batch, tuple(ctx.has_bias))
+            outs = _backend.call(_GLBwdW, gy, x, plan, batch, tuple(ctx.has_bias))
             gws = list(outs[:g])
             it = iter(outs[g:])
             gbs = [next(it) if hb else None for hb in ctx.has_bias]
@@ -101,10 +101,10 @@ class _GLBwdX(Function):
         plan, batch = ctx.plan, ctx.batch
         g = len(plan.specs)
         need = ctx.needs_input_grad
-        g_gy = _GLFwd.apply(ggx, plan, batch, *weights, *([None] * g)) if need[0] else None
+        g_gy = _backend.call(_GLFwd, ggx, plan, batch, *weights, *([None] * g)) if need[0] else None
         gws = [None] * g
         if any(need[3:]) and _backend.want_param_grads():
-            gws = list(_GLBwdW.apply(gy, ggx, plan, batch, (False,) * g)[:g])
+            gws = list(_backend.call(_GLBwdW, gy, ggx, plan, batch, (False,) * g)[:g])
         return (g_gy, None, None, *gws)
 
 
@@ -126,8 +126,8 @@ class _GLBwdW(Function):
         ggw = list(gg[:g])
         it = iter(gg[g:])
         ggb = [next(it) if hb else None for hb in ctx.has_bias]
-        g_gy = _GLFwd.apply(x, plan, batch, *ggw, *ggb) if ctx.needs_input_grad[0] else None
-        g_x = _GLBwdX.apply(gy, plan, batch, *ggw) if ctx.needs_input_grad[1] else None
+        g_gy = _backend.call(_GLFwd, x, plan, batch, *ggw, *ggb) if ctx.needs_input_grad[0] else None
+        g_x = _backend.call(_GLBwdX, gy, plan, batch, *ggw) if ctx.needs_input_grad[1] else None
         return g_gy, g_x, None, None, None
 
 
@@ -138,7 +138,7 @@ def grouped_linear(x_flat, batch, plan, weights, biases):
         raise ValueError('grouped_linear: %d groups, %d weights, %d biases' % (len(plan.specs), len(weights), len(biases)))
     if x_flat.numel() != batch * plan.in_cols:
         raise ValueError('grouped_linear: input has %d elements, the plan expects %d x %d' % (x_flat.numel(), batch, plan.in_cols))
-    return _GLFwd.apply(x_flat, plan, batch, *weights, *biases)
+    return _backend.call(_GLFwd, x_flat, plan, batch, *weights, *biases)
 
 
 def blocks(flat, batch, cols):

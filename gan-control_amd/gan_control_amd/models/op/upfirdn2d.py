@@ -39,7 +39,7 @@ class _UpFirDn2d(Function):
     @staticmethod
     def backward(ctx, gy):
         kernel, = ctx.saved_tensors
-        gx = _UpFirDn2dAdjoint.apply(gy, kernel, ctx.cfg) if (ctx.needs_input_grad[0] and gy is not None) else None
+        gx = _backend.call(_UpFirDn2dAdjoint, gy, kernel, ctx.cfg) if (ctx.needs_input_grad[0] and gy is not None) else None
         return gx, None, None, None, None, None
 
 
@@ -60,7 +60,7 @@ class _UpFirDn2dAdjoint(Function):
         kernel, = ctx.saved_tensors
         up, down, p0, p1, h, w = ctx.cfg
         # the adjoint of the adjoint is the forward operator
-        ggy = _UpFirDn2d.apply(ggx, kernel, up, down, p0, p1) if (ctx.needs_input_grad[0] and ggx is not None) else None
+        ggy = _backend.call(_UpFirDn2d, ggx, kernel, up, down, p0, p1) if (ctx.needs_input_grad[0] and ggx is not None) else None
         return ggy, None, None
 
 
@@ -68,9 +68,9 @@ def upfirdn2d(input, kernel, up=1, down=1, pad=(0, 0), _internal=False):
     """The reference's socket signature.  ``_internal`` (modules of this package whose consumer reads a row pitch) lets the odd-width
     output of a Blur come back as a row-pitched view; every other caller gets an ordinary dense tensor."""
     if _internal:
-        return _UpFirDn2d.apply(input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
+        return _backend.call(_UpFirDn2d, input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
     with _backend.pitched_outputs(False):
-        return _UpFirDn2d.apply(input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
+        return _backend.call(_UpFirDn2d, input, kernel, int(up), int(down), int(pad[0]), int(pad[1]))
 
 
 class _BlurOfActivation(Function):
@@ -96,7 +96,7 @@ class _BlurOfActivation(Function):
         kernel, a = ctx.saved_tensors
         if gy is None or not ctx.needs_input_grad[0]:
             return None, None, None, None, None, None
-        return _BlurAdjointMasked.apply(gy, kernel, ctx.cfg, a, *ctx.act), None, None, None, None, None
+        return _backend.call(_BlurAdjointMasked, gy, kernel, ctx.cfg, a, *ctx.act), None, None, None, None, None
 
 
 class _BlurAdjointMasked(Function):
@@ -125,7 +125,7 @@ class _BlurAdjointMasked(Function):
             return None, None, None, None, None, None
         up, down, p0, p1, h, w = ctx.cfg
         slope, gain = ctx.act
-        ggy = _UpFirDn2d.apply(_BiasActGrad.apply(gg, a, slope, gain), kernel, up, down, p0, p1) if ctx.needs_input_grad[0] else None
+        ggy = _backend.call(_UpFirDn2d, _backend.call(_BiasActGrad, gg, a, slope, gain), kernel, up, down, p0, p1) if ctx.needs_input_grad[0] else None
         # d/da of the mask is zero almost everywhere (zeros only for the trainer's dry run, as in _BiasActGrad)
         ga = torch.zeros_like(a) if (ctx.needs_input_grad[3] and _backend.strict_zeros()) else None
         return ggy, None, None, ga, None, None
@@ -133,7 +133,7 @@ class _BlurAdjointMasked(Function):
 
 def blur_of_activation(a, kernel, pad, negative_slope, scale):
     """upfirdn2d(a, kernel, pad=pad) for an ``a`` produced with ``grad_premasked=True`` (see _BlurOfActivation)."""
-    return _BlurOfActivation.apply(a, kernel, int(pad[0]), int(pad[1]), float(negative_slope), float(scale))
+    return _backend.call(_BlurOfActivation, a, kernel, int(pad[0]), int(pad[1]), float(negative_slope), float(scale))
 
 
 class _UpFirDn2dAct(Function):
@@ -181,15 +181,15 @@ class _UpFirDn2dAct(Function):
                 gnw = pdot.sum().reshape(noise_w.shape)
             return gx, None, None, None, gb, None, gnw, None, None
         if want_b or want_nw:
-            g_pre, psum, pdot = _BiasActGradReduce.apply(gy, out, noise if want_nw else None, slope, gain)[:3]
+            g_pre, psum, pdot = _backend.call(_BiasActGradReduce, gy, out, noise if want_nw else None, slope, gain)[:3]
             if want_b:
                 gb = psum.sum((0, 2))
             if want_nw:
                 gnw = pdot.sum().reshape(noise_w.shape)
         else:
-            g_pre = _BiasActGrad.apply(gy, out, slope, gain)
+            g_pre = _backend.call(_BiasActGrad, gy, out, slope, gain)
         if need[0]:
-            gx = _UpFirDn2dAdjoint.apply(g_pre, kernel, ctx.cfg)
+            gx = _backend.call(_UpFirDn2dAdjoint, g_pre, kernel, ctx.cfg)
         return gx, None, None, None, gb, None, gnw, None, None
 
 
@@ -205,6 +205,6 @@ def upfirdn2d_bias_act(input, kernel, pad, bias, noise=None, noise_weight=None, 
             raise ValueError('noise and noise_weight go together')
         if noise is not None and (noise.shape[0] != input.shape[0] or noise.numel() != input.shape[0] * oh * ow):
             raise ValueError(f'noise shape {tuple(noise.shape)} does not match the output [{input.shape[0]}, {input.shape[1]}, {oh}, {ow}]')
-        return _UpFirDn2dAct.apply(input, kernel, p0, p1, None if bias is None else bias.reshape(-1).contiguous(), noise,
+        return _backend.call(_UpFirDn2dAct, input, kernel, p0, p1, None if bias is None else bias.reshape(-1).contiguous(), noise,
                                    None if noise_weight is None else noise_weight.reshape(-1).contiguous(), float(negative_slope), float(scale))
     return fused_noise_bias_act(upfirdn2d(input, kernel, pad=pad), bias, noise, noise_weight, negative_slope, scale)

@@ -24,12 +24,12 @@ class _AffineWarp(Function):
             return (None,) * 7
         mat, = ctx.saved_tensors
         out_h, out_w, adjoint, in_h, in_w = ctx.cfg
-        return _AffineWarp.apply(g, mat, out_h, out_w, not adjoint, in_h, in_w), None, None, None, None, None, None
+        return _backend.call(_AffineWarp, g, mat, out_h, out_w, not adjoint, in_h, in_w), None, None, None, None, None, None
 
 
 def affine_warp_bilinear(x, mat, out_h, out_w):
     """x [B, C, H, W], mat [B, 6] (device, float32): F.grid_sample(bilinear, zeros, align_corners=False) for an affine grid."""
-    return _AffineWarp.apply(x, mat.contiguous(), int(out_h), int(out_w), False, int(x.shape[2]), int(x.shape[3]))
+    return _backend.call(_AffineWarp, x, mat.contiguous(), int(out_h), int(out_w), False, int(x.shape[2]), int(x.shape[3]))
 
 
 class _ReflectPad(Function):
@@ -44,7 +44,7 @@ class _ReflectPad(Function):
         if g is None or not ctx.needs_input_grad[0]:
             return None, None, None, None
         pads, adjoint, in_hw = ctx.cfg
-        return _ReflectPad.apply(g, pads, not adjoint, in_hw), None, None, None
+        return _backend.call(_ReflectPad, g, pads, not adjoint, in_hw), None, None, None
 
 
 def reflect_pad(x, pads):
@@ -53,4 +53,4 @@ def reflect_pad(x, pads):
     h, w = int(x.shape[2]), int(x.shape[3])
     if min(left, right, top, bottom) < 0 or max(left, right) >= w or max(top, bottom) >= h:
         raise ValueError(f'reflect_pad: padding {(left, right, top, bottom)} must be non-negative and smaller than the image {h} x {w}')
-    return _ReflectPad.apply(x, (left, right, top, bottom), False, (h, w))
+    return _backend.call(_ReflectPad, x, (left, right, top, bottom), False, (h, w))

@@ -49,7 +49,7 @@ class _Relayout(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _Relayout.apply(g, ctx.inverse, ctx.scale), None, None
+        return _backend.call(_Relayout, g, ctx.inverse, ctx.scale), None, None
 
 
 def kernel_layout(weight, scale=1.0, flip=False, in_major=False):
@@ -65,10 +65,10 @@ def kernel_layout(weight, scale=1.0, flip=False, in_major=False):
     else:
         n, k = d0, d1
         src_stride = (1, taps, k * taps)
-    return _Relayout.apply(weight, (taps, k, n, src_stride, (kh, kw, k, n), (k * n, n, 1), bool(flip)), float(scale))
+    return _backend.call(_Relayout, weight, (taps, k, n, src_stride, (kh, kw, k, n), (k * n, n, 1), bool(flip)), float(scale))
 
 
 def adjoint_layout(w_t):
     """[kh, kw, K, N] -> [kh, kw, N, K] with mirrored taps: the weights of d/dx of the convolution."""
     kh, kw, k, n = w_t.shape
-    return _Relayout.apply(w_t, (kh * kw, k, n, (k * n, n, 1), (kh, kw, n, k), (n * k, 1, k), True), 1.0)
+    return _backend.call(_Relayout, w_t, (kh * kw, k, n, (k * n, n, 1), (kh, kw, n, k), (n * k, 1, k), True), 1.0)
