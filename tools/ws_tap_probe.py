@@ -1,5 +1,11 @@
+#!/usr/bin/env python3
+"""Dev tool (GPU): what do four staging waves sustain?  The wave-specialised forward kernel with ONE tap per staged 16-channel chunk (its 1 x 1
+instantiation) next to the 3 x 3 form, at the FFHQ-1024 channel counts.  A 1 x 1 item stages ~1 000 patch units for 12 MFMAs per multiplying wave,
+so its time per item (1.7 us measured) is the staging pipeline's own: the price list for any kernel that feeds fewer taps per staged unit than a
+stride-1 3 x 3 layer does (a phase-plane stride-2 kernel: 2.25 taps per chunk on average -- DESIGN.md section 6, round 4)."""
 import os, sys
-sys.path.insert(0, '/root/repo/gan-control_amd'); sys.path.insert(0, os.path.join(os.environ.get('GRAFT_REPO_ROOT', '/root/repo'), 'gan-control_amd'))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(REPO, 'gan-control_amd'))
 import torch
 from gan_control_amd.models.op import _backend
 from gan_control_amd.models.op._backend import ConvGeom
