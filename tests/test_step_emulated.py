@@ -83,3 +83,30 @@ def test_train_loop_writes_the_reference_checkpoint_layout_and_resumes(emu_backe
     c.training_config['debug'] = True
     c.train(iters=1, save_dir=str(tmp_path / 'dbg'))
     assert not os.path.exists(tmp_path / 'dbg')
+
+
+def test_direct_forward_equals_function_apply(emu_backend):
+    """op/_backend.py::call -- a Function's forward called directly when autograd would record nothing (grad mode off inside a plain backward,
+    or no argument requires a gradient) -- must not change a bit: two iterations (both lazy regularisers) with the short-cut on and off."""
+    import random
+    import torch
+    from gan_control_amd.models.op import _backend
+    from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
+
+    def run(direct):
+        keep, _backend._DIRECT = _backend._DIRECT, direct
+        try:
+            random.seed(0); torch.manual_seed(0)
+            tr = GeneratorTrainer(default_config(16, 4), device='cpu', seed=0, fused_adam=False)
+            real = tr.synthetic_batch()
+            for i in range(2):
+                tr.train_iteration(i * 16, real)
+            return tr
+        finally:
+            _backend._DIRECT = keep
+
+    a, b = run(True), run(False)
+    for net in ('generator', 'discriminator', 'g_ema'):
+        for (n, p), (_, q) in zip(getattr(a, net).named_parameters(), getattr(b, net).named_parameters()):
+            assert torch.equal(p, q), (net, n)
+    assert float(a.mean_path_length) == float(b.mean_path_length)
