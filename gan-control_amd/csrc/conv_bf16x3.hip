@@ -99,6 +99,9 @@
 #define GC_CONV_NT 1
 #endif
 #define GC_CONV_ST_AUX (GC_CONV_NT ? 2 : 0)
+#ifndef GC_WS_BARE
+#define GC_WS_BARE 1         // reduced epilogues (EPK 1 / 2) of the wave-specialised kernel for launches without bias / noise / activation (0: always the full epilogue)
+#endif
 #ifndef GC_WS_NT_LOAD
 #define GC_WS_NT_LOAD 0      // non-temporal patch loads in the wave-specialised forward kernel: measured SLOWER (dominant kernel 409 -> 386 TF/s, step -2 %):
                              // every patch is re-read by the other output-channel blocks and by the neighbouring tiles' halos
@@ -547,7 +550,17 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, const
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
-template <int KS, int WOC, int CB>
+// a * s + r with the product rounded on its own, as conv_epilogue rounds it (no contraction into one fma)
+__device__ __forceinline__ float scaled_plus(float a, float s, float r) {
+#pragma clang fp contract(off)
+    const float v = a * s;
+    return v + r;
+}
+
+// EPK: 0 = the full fused epilogue; 1 = out_scale and / or residual only (the input-gradient launches: G's modulated layers, D's ResBlock
+// convolutions); 2 = nothing to apply.  Compile-time: the epilogue runs on the MULTIPLYING waves (6 vector instructions + 2 LDS reads per output
+// element in its full form, 384 per lane and tile, both waves of a SIMD at the same moment) next to only 108 MFMAs per tile at 32 input channels.
+template <int KS, int WOC, int CB, int EPK = 0>
 __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     using C = BCfg<1, 8, WOC, 2, 1, 1, KS, CB>;      // CB = 1: 16 rows x 32 px tiles; CB = 2: 8 rows x 64 px (longer contiguous runs per row: the HBM-bound layers)
     constexpr int OCT = 32 * WOC, TPH = C::TPH, PLANE = C::PLANE, WPX = 2, NTAP = KS * KS;
@@ -730,6 +743,33 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
             const bool inside = qy < p.out_h && qx < p.out_w;
             voff[j] = inside ? (unsigned)(qy * p.out_w + qx) * 4u + (unsigned)(4 * hi) * oplane : OOB;
             nz[j] = (p.noise && inside) ? p.noise[((size_t)b * p.out_h + qy) * p.out_w + qx] : 0.f;
+        }
+        if (EPK > 0) {
+            // (a template parameter: as a run-time branch the store sequences of the two paths were merged into one control-flow tangle that stored
+            // zeros.)  Values differ from the full epilogue's only in the sign of an exact zero (it adds +0 for the absent bias).
+            if (EPK == 1 && p.residual) {
+#pragma unroll
+                for (int j = 0; j < WPX; ++j)
+#pragma unroll
+                    for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            acc[i][j][r] = scaled_plus(acc[i][j][r], s_so[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi],
+                                                       buf_load_f32(rres, voff[j], (unsigned)(nb + i * 32 + (r & 3) + 8 * (r >> 2)) * oplane));
+            }
+#pragma unroll
+            for (int j = 0; j < WPX; ++j)
+#pragma unroll
+                for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ocs = nb + i * 32 + (r & 3) + 8 * (r >> 2);
+                        float v = acc[i][j][r];
+                        if (EPK == 1 && !p.residual) v *= s_so[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
+                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff[j], (int)((unsigned)ocs * oplane), GC_CONV_ST_AUX);
+                        acc[i][j][r] = 0.f;
+                    }
+            return;
         }
         if (p.residual) {
 #pragma unroll
@@ -2151,7 +2191,11 @@ int launch_ws(Bf16Args a, hipStream_t s) {
     const long long gx = (long long)a.groups * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
     if (gc::probing()) return gc::probe_name("conv_bf16x3_ws_kernel<%d,%d,%d>|up1,down1,k%d", KS, WOC, CB, KS);
-    hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    const bool plain = GC_WS_BARE && !a.c.bias && !a.c.noise && !a.c.act;
+    const int epk = !plain ? 0 : ((a.c.so || a.c.residual) ? 1 : 2);
+    if (epk == 2)      hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 2>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    else if (epk == 1) hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 1>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    else               hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 0>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
     return gc::check_launch("gc_conv2d_bf16x3_f32(ws)");
 }
 
