@@ -8,7 +8,7 @@ MIX = (batch, channels, resolution, launches per 16 training iterations), from t
 import csv, glob, json, os, sys
 MIX = [(4, 128, 256, 84), (4, 256, 128, 84), (4, 512, 64, 84), (8, 128, 256, 32), (8, 256, 128, 32), (8, 512, 64, 32), (2, 128, 256, 16), (2, 256, 128, 16)]
 # (the 64-channel layers of round 1's mix run on the wide-tile instantiation <3,2,2> since round 2: a kernel of its own)
-KERNEL = os.environ.get('PMC_KERNEL', 'conv_bf16x3_ws_kernel<3, 2, 1>')                 # substring of the rocprofv3 kernel name
+KERNEL = os.environ.get('PMC_KERNEL', 'conv_bf16x3_ws_kernel<3, 2, 1,')                 # substring of the rocprofv3 kernel name (round 4: a fourth template argument, the epilogue kind)
 KERNEL_LABEL = os.environ.get('PMC_KERNEL_LABEL', 'conv_bf16x3_ws_kernel<3,2,1>|up1,down1,k3')     # the name bench.py reports
 
 
