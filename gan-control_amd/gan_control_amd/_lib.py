@@ -162,7 +162,15 @@ def ptr(t):
     return None if t is None else t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def stream_of(t):
+    """The raw handle of the CURRENT stream of t's device (what the kernels launch on).  torch._C._cuda_getCurrentRawStream is the same query
+    torch.cuda.current_stream(device).cuda_stream makes, without building a Stream object per call (~5 us, ~580 calls per training iteration)."""
+    if _raw_stream is not None:
+        idx = t.device.index
+        return _raw_stream(idx if idx is not None else torch.cuda.current_device())
     return torch.cuda.current_stream(t.device).cuda_stream
 
 

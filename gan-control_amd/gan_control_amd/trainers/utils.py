@@ -17,11 +17,30 @@ _NAMED = weakref.WeakKeyDictionary()
 
 
 def named_params(model):
+    """list(model.named_parameters()), cached.  Validated in O(1): the first and the last parameter must still be the objects registered under
+    their names (a swapped parameter object -- load_state_dict(assign=True), .to() on a meta model -- re-lists); call forget_params(model) after
+    adding or removing modules."""
     hit = _NAMED.get(model)
-    if hit is None or hit[0] != sum(len(m._parameters) for m in model.modules()) or any(p is not q for (_, p), q in zip(hit[1][:4], hit[2][:4])):
+    if hit is not None:
+        lst, probes = hit
+        for owner, attr, p in probes:
+            if owner._parameters.get(attr) is not p:
+                hit = None
+                break
+    if hit is None:
         lst = list(model.named_parameters())
-        hit = _NAMED[model] = (sum(len(m._parameters) for m in model.modules()), lst, [p for _, p in lst])
-    return hit[1]
+        probes = []
+        if lst:
+            mods = dict(model.named_modules())
+            for name, p in (lst[0], lst[-1]):
+                owner, _, attr = name.rpartition('.')
+                probes.append((mods[owner], attr, p))
+        _NAMED[model] = (lst, probes)
+    return lst
+
+
+def forget_params(model):
+    _NAMED.pop(model, None)
 
 
 def zero_grad_none(model):

@@ -14,6 +14,8 @@ from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default
 from gan_control_amd.trainers.utils import requires_grad, make_mini_batch_from_noise  # noqa: E402
 
 phase = sys.argv[1] if len(sys.argv) > 1 else 'pl'
+if len(sys.argv) > 2 and sys.argv[2] == 'inline':       # run backward on the calling thread so that cProfile sees the backward functions too
+    torch.autograd.set_multithreading_enabled(False)
 _backend.get().conv_mode = 'bf16x3'
 size, batch = 1024, 4
 tr = GeneratorTrainer(default_config(size, batch), device='cuda', seed=0)
@@ -58,4 +60,4 @@ torch.cuda.synchronize()
 st = pstats.Stats(prof)
 st.sort_stats('tottime')
 print('phase', phase, ': host time per repetition %.2f ms' % (st.total_tt / n * 1e3))
-st.print_stats(28)
+st.print_stats(int(os.environ.get('TOP', '28')))
