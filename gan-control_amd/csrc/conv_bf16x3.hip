@@ -99,6 +99,11 @@
 #define GC_CONV_NT 1
 #endif
 #define GC_CONV_ST_AUX (GC_CONV_NT ? 2 : 0)
+#ifndef GC_WS_SHIFT
+#define GC_WS_SHIFT 0        // 1: patch fragments of the jx > 0 taps by a whole-wave DPP shift of the previous tap's instead of an LDS read: correct (all
+                             // convolution tests) and SLOWER -- 512 -> 512 @64^2 181 -> 216 us, 64 -> 64 @512^2 197 -> 280 (round 4, same box): 16 v_mov_b32_dpp per tap
+                             // on the MULTIPLYING waves (and 20 spilled registers) cost more than the 4 ds_read_b128 they replace
+#endif
 #ifndef GC_WS_BARE
 #define GC_WS_BARE 1         // reduced epilogues (EPK 1 / 2) of the wave-specialised kernel for launches without bias / noise / activation (0: always the full epilogue)
 #endif
@@ -819,11 +824,32 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
                 fa[set][i] = *reinterpret_cast<const bf16x8*>(&uh);
                 GC_LO(const uint4 ul = wl_l[wbase + i * 32]; fa[set][WOC + i] = *reinterpret_cast<const bf16x8*>(&ul);)
             }
+            if (GC_WS_SHIFT && KS == 3 && jx > 0) {
+                // The patch fragment of tap (jy, jx) is that of (jy, jx - 1) one pixel on: lane l wants what lane l + 1 holds.  A whole-wave DPP
+                // shift (gfx9: wave_shl) moves it between registers -- four v_mov_b32_dpp per fragment -- instead of a second and third LDS
+                // read of the same units; only the last pixel of the 32 (lanes 31 and 63: the shift brings the other channel group's / nothing)
+                // is fetched from LDS, by an exec-masked read.
 #pragma unroll
-            for (int j = 0; j < WPX; ++j) {
-                const uint4 uh = p_h[pbase + boff[j]];
-                fb[set][j] = *reinterpret_cast<const bf16x8*>(&uh);
-                GC_LO(const uint4 ul = p_l[pbase + boff[j]]; fb[set][WPX + j] = *reinterpret_cast<const bf16x8*>(&ul);)
+                for (int f = 0; f < (2 * WPX); ++f) {
+#ifdef GC_SINGLE
+                    if (f >= WPX) continue;
+#endif
+                    const uint4 prev = *reinterpret_cast<const uint4*>(&fb[set ^ 1][f]);
+                    uint4 cur;
+                    cur.x = (unsigned)__builtin_amdgcn_update_dpp(0, (int)prev.x, 0x130, 0xf, 0xf, false);
+                    cur.y = (unsigned)__builtin_amdgcn_update_dpp(0, (int)prev.y, 0x130, 0xf, 0xf, false);
+                    cur.z = (unsigned)__builtin_amdgcn_update_dpp(0, (int)prev.z, 0x130, 0xf, 0xf, false);
+                    cur.w = (unsigned)__builtin_amdgcn_update_dpp(0, (int)prev.w, 0x130, 0xf, 0xf, false);
+                    if (l31 == 31) cur = (f < WPX ? p_h : p_l)[pbase + boff[f % WPX]];
+                    fb[set][f] = *reinterpret_cast<const bf16x8*>(&cur);
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) {
+                    const uint4 uh = p_h[pbase + boff[j]];
+                    fb[set][j] = *reinterpret_cast<const bf16x8*>(&uh);
+                    GC_LO(const uint4 ul = p_l[pbase + boff[j]]; fb[set][WPX + j] = *reinterpret_cast<const bf16x8*>(&ul);)
+                }
             }
         };
         load_tap(0, 0);
