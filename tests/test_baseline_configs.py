@@ -218,3 +218,38 @@ def test_bf16_mode_step_512(bf16_mode):
     for k, bound in BF16_STEP_512.items():
         assert m[k] <= bound, (k, m[k], bound)
     assert m['param outliers'] <= BF16_STEP_512_OUTLIERS, m['param outliers']
+
+
+# ------------------------------------------------------------------------------------------------ config 2 at its own batch
+@pytest.mark.gpu
+def test_config2_512_batch16_iterations_in_both_arithmetics():
+    """BASELINE config 2 -- FFHQ 512 x 512, batch 16 on ONE GPU -- at its own batch (the reference fixtures of this size stop at batch 4:
+    `step_512.npz`): the trainer as `bench.py --size 512 --batch-per-gpu 16` builds it runs iterations 0 (both lazy regularisers) and 1 in
+    split-bf16 and in exact fp32 arithmetic from the same seeds; every statistic is finite and the two arithmetics agree on the losses of the
+    FIRST iteration (identical weights and inputs there; later ones inherit sign-like Adam steps) to the tolerance of the 512 x 512 step fixture."""
+    import random
+    from gan_control_amd.models.op import _backend
+    from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
+    hip = _backend.get()
+    prev = hip.conv_mode
+    stats = {}
+    try:
+        for mode in ('f32', 'bf16x3'):
+            hip.conv_mode = mode
+            random.seed(0); torch.manual_seed(0)
+            tr = GeneratorTrainer(default_config(512, 16), device=DEV, seed=0)
+            assert tr.local_batch == 16
+            real = tr.synthetic_batch()
+            tr.train_iteration(0, real)
+            first = {k: float(v) for k, v in tr.reduced_stats().items()}
+            tr.train_iteration(1, real)
+            _finite(tr.reduced_stats(), ('d_loss', 'g_adv_loss', 'd_r1_loss', 'g_path_loss', 'g_mean_path_length'))
+            assert all(bool(torch.isfinite(p).all()) for p in tr.generator.parameters())
+            stats[mode] = first
+            del tr
+            torch.cuda.empty_cache()
+    finally:
+        hip.conv_mode = prev
+    for k in ('d_loss', 'g_adv_loss', 'd_r1_loss', 'g_path_loss', 'g_mean_path_length'):
+        a, b = stats['bf16x3'][k], stats['f32'][k]
+        assert abs(a - b) <= 6e-3 * max(1.0, abs(b)), (k, a, b)
