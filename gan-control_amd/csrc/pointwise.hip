@@ -15,7 +15,10 @@ namespace {
 using namespace gcconv;
 
 constexpr int MAXS = 4;          // channels on the thin side
-constexpr int CHUNK = 16;        // wide-side channels whose loads are in flight together
+#ifndef GC_PW_CHUNK
+#define GC_PW_CHUNK 16
+#endif
+constexpr int CHUNK = GC_PW_CHUNK;        // wide-side channels whose loads are in flight together
 
 struct PwArgs {
     ConvArgs c;
