@@ -882,6 +882,16 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
 #else
 #define WG_LOAD(r, off, imm) buf_load_u128(r, off, imm)
 #endif
+// non-temporal variant (dev knob GC_WG_NT_LOAD: 1 = every weight-gradient load, 2 = only where the operands are read once: K = N = 32).
+// Measured much SLOWER in both forms (round 4, B = 4: 32 -> 32 @1024^2 344 -> 555 us; with 1 also 64 -> 64 @512^2 267 -> 427, stride 2 233 -> 426):
+// the halo rows of a tile and the neighbouring pixel splits re-read the lines the hint evicts.
+#ifndef GC_WG_NT_LOAD
+#define GC_WG_NT_LOAD 0
+#endif
+__device__ __forceinline__ uint4 buf_load_u128_nt(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)__builtin_amdgcn_readfirstlane(soff), 2));
+}
+#define WG_LOAD1(once, r, off, imm) ((GC_WG_NT_LOAD == 1 || (GC_WG_NT_LOAD == 2 && (once))) ? buf_load_u128_nt(r, off, imm) : WG_LOAD(r, off, imm))
 // XCD-aware block order for the weight-gradient grids (k blocks x n blocks x pixel splits).  Workgroups go to the eight XCDs round-robin
 // in linear block order, so the 8 x 8 (k, n) blocks of ONE pixel split -- which all stream the same X and dY tiles -- land on eight
 // different L2s and every tile crosses the fabric eight times.  Re-deal the linear ids so that each XCD gets a contiguous range of
@@ -1035,8 +1045,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
 #else
             const unsigned off = ((int)d >= 0 && (unsigned)(iy0 + r) < (unsigned)p.in_h) ? (unsigned)max(lin, 0) : OUTSIDE;
 #endif
-            xreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 0));
-            xreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 16));
+            xreg[j][0] = __builtin_bit_cast(float4, WG_LOAD1(WK * WN == 1, rx, off, 0));
+            xreg[j][1] = __builtin_bit_cast(float4, WG_LOAD1(WK * WN == 1, rx, off, 16));
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
@@ -1044,8 +1054,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             const int r = (int)((d >> 20) & 15u);
             const int lin = (int)((d >> 24) & 63u) * (ychan * 4) + r * (p.out_w * 4) + (int)((d >> 16) & 15u) * 32 + yoff;
             const unsigned off = ((int)d >= 0 && oy0 + r < p.out_h) ? (unsigned)lin : OUTSIDE;
-            yreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 0));
-            yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 16));
+            yreg[j][0] = __builtin_bit_cast(float4, WG_LOAD1(WK * WN == 1, ry, off, 0));
+            yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD1(WK * WN == 1, ry, off, 16));
         }
     };
     auto unit8 = [&](auto scaled_t, const float4 (&r)[2], int col0, int width, float scale, uint4* h, uint4* l) {
@@ -1288,7 +1298,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             const int lin = (int)((d >> 24) & 63u) * (xchan * 4) + r * (p.x_pitch * 4) + (int)((d >> 16) & 15u) * 64 + xoff;
             const unsigned off = ((int)d >= 0 && iy0 + r < p.in_h) ? (unsigned)lin : OUTSIDE;
 #pragma unroll
-            for (int v = 0; v < 4; ++v) xreg[j][v] = __builtin_bit_cast(float4, WG_LOAD(rx, off, 16 * v));
+            for (int v = 0; v < 4; ++v) xreg[j][v] = __builtin_bit_cast(float4, WG_LOAD1(false, rx, off, 16 * v));
         }
 #pragma unroll
         for (int j = 0; j < C::NPY; ++j) {
@@ -1296,8 +1306,8 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             const int r = (int)((d >> 20) & 15u);
             const int lin = (int)((d >> 24) & 63u) * (ychan * 4) + r * (p.out_w * 4) + (int)((d >> 16) & 15u) * 32 + yoff;
             const unsigned off = ((int)d >= 0 && oy0 + r < p.out_h) ? (unsigned)lin : OUTSIDE;
-            yreg[j][0] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 0));
-            yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD(ry, off, 16));
+            yreg[j][0] = __builtin_bit_cast(float4, WG_LOAD1(false, ry, off, 0));
+            yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD1(false, ry, off, 16));
         }
     };
     auto commit = [&](int tile) {
