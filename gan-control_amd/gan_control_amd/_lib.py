@@ -152,10 +152,15 @@ def load():
     return lib
 
 
+class UnsupportedError(RuntimeError):
+    """GC_ERR_UNSUPPORTED: a legal request outside what the kernels implement -- the one failure a caller may answer with another route."""
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().gc_last_error()
-        raise RuntimeError(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
+        kind = UnsupportedError if rc == -2 else RuntimeError
+        raise kind(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
 
 
 def ptr(t):

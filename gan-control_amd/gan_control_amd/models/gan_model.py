@@ -60,9 +60,9 @@ class _StylePlan:
     def selector(self, device, n_latent):
         """[groups, n_latent] one-hot rows: ``selector @ latents`` is the per-layer gather as ONE GEMM call.  Exact (every product is 1 * x or
         0 * x) and -- unlike index_select, whose backward scatters with atomics -- deterministic in both directions: the gradient of a
-        latent read by several layers is summed in the GEMM's fixed order.  Two caveats: the product must run in full fp32 -- _gather_latents
-        pins the matmul precision around the forward product (a process-wide set_float32_matmul_precision('high') / allow_tf32 would round the
-        latents on this route only; the backward GEMM of such a process still follows the process setting) -- and a non-finite latent entry
+        latent read by several layers is summed in the GEMM's fixed order.  Two caveats: the product must be exact -- _gather_latents
+        runs it in float64, forward and backward, when the process-wide matmul precision is not the default (set_float32_matmul_precision('high')
+        / allow_tf32 would otherwise round the latents on this route only) -- and a non-finite latent entry
         reaches EVERY layer's style as NaN through 0 * inf, where a gather would confine it to the layers that read that latent (the image is
         non-finite either way; GANCONTROL_FUSED_STYLE=0 selects the per-layer route)."""
         t = self._idx.get((device, n_latent))
@@ -91,18 +91,16 @@ def make_kernel(k):
 
 
 def _gather_latents(plan, latent):
-    """latent [B, n_latent, D] -> [groups, B * D]: row g = the latent layer g reads (StyleGroupPlan.selector: one exact GEMM).  The product is
-    pinned to full fp32 whatever the process-wide matmul precision says, so the grouped and the per-layer style paths see the same bits."""
+    """latent [B, n_latent, D] -> [groups, B * D]: row g = the latent layer g reads (StyleGroupPlan.selector: one exact GEMM).  The product
+    has to be exact whatever the process-wide matmul precision says, so that the grouped and the per-layer style paths see the same bits:
+    under the default ('highest', no TF32) it is one fp32 GEMM; under any other setting it runs in float64 (every product is 1 * x or 0 * x,
+    [groups, n_latent] @ [n_latent, B * D] is tiny) -- no process-wide state is touched (writing the setting back through the legacy
+    ``allow_tf32`` attribute poisons ``get_float32_matmul_precision`` on current torch)."""
     flat = latent.transpose(0, 1).reshape(latent.shape[1], -1)
-    hi, tf32 = torch.get_float32_matmul_precision(), torch.backends.cuda.matmul.allow_tf32
-    if hi == 'highest' and not tf32:
-        return plan.selector(latent.device, latent.shape[1]) @ flat
-    torch.set_float32_matmul_precision('highest')
-    try:
-        return plan.selector(latent.device, latent.shape[1]) @ flat
-    finally:
-        torch.set_float32_matmul_precision(hi)
-        torch.backends.cuda.matmul.allow_tf32 = tf32
+    sel = plan.selector(latent.device, latent.shape[1])
+    if torch.get_float32_matmul_precision() == 'highest' and not torch.backends.cuda.matmul.allow_tf32:
+        return sel @ flat
+    return (sel.double() @ flat.double()).to(flat.dtype)
 
 
 class PixelNorm(nn.Module):

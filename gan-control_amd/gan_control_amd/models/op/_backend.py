@@ -112,7 +112,14 @@ def call(fn, *args):
         for a in args:
             if isinstance(a, torch.Tensor) and a.requires_grad:
                 return fn.apply(*args)
-        return fn.forward(_NoGraphCtx(), *args)
+        # Function.apply runs forward under no_grad: do the same, or an ATen op inside a forward that touches a tensor which is NOT an
+        # argument (a root parameter behind the weight cache, module state held by a plan) would record a graph and hand back an output
+        # with requires_grad set
+        torch._C._set_grad_enabled(False)
+        try:
+            return fn.forward(_NoGraphCtx(), *args)
+        finally:
+            torch._C._set_grad_enabled(True)
     return fn.apply(*args)
 
 

@@ -36,9 +36,12 @@ trainers/utils.py:8-12), a leaf tensor a caller passes in -- is recomputed on ev
 (``module.to()``, ``load_state_dict(assign=True)``) is dropped on sight.
 """
 import os
+import warnings
 import weakref
 
 import torch
+
+from ... import _lib
 
 ENABLED = os.environ.get('GANCONTROL_WEIGHT_CACHE', '1') != '0'
 BATCHED = os.environ.get('GANCONTROL_WEIGHT_BATCH', '1') != '0'
@@ -49,6 +52,7 @@ _derived = {}    # data_ptr of a cached tensor -> (id(root), key)
 _group_of = {}   # id(root) -> group id (parameters registered together as one module)
 _group_members = {}   # group id -> [weakref(root)]
 _recipes = {}    # id(root) -> {key: recipe}: every derived form ever asked of this root and how to make it (survives invalidation)
+_warned = set()  # kinds of batched refill already reported as unsupported
 stats = {'hit': 0, 'miss': 0, 'bypass': 0, 'batched': 0, 'batch_failed': 0}
 batch_runner = None   # set by op/_backend.py: () -> callable(kind, items) -> [tensor] of the active backend, or None
 pack_wanted = None    # set by op/_backend.py: () -> bool, does the active convolution arithmetic read hi / lo packs at all
@@ -150,10 +154,15 @@ def _refill_group(gid):
                 continue            # (packs recorded under a split-bf16 mode are not rebuilt while the exact-fp32 mode is active)
             try:
                 outs = run(kind, items)
-            except (RuntimeError, ValueError):
+            except _lib.UnsupportedError as e:
                 # one item the grouped entry cannot take (a pack whose descriptor has no packed form any more, a table limit) must not abort
-                # the forward pass: leave this kind to the callers' own make(), which handles each tensor on its own
+                # the forward pass: leave this kind to the callers' own make(), which handles each tensor on its own.  Only the library's
+                # "unsupported" answer is taken this way: a HIP failure, a bad descriptor or a host-side error is raised where it happened
                 stats['batch_failed'] += 1
+                if kind not in _warned:
+                    _warned.add(kind)
+                    warnings.warn('gan_control_amd: batched refill of the %r weight forms is unsupported for this network (%s); '
+                                  'falling back to one launch per tensor' % (kind, e))
                 continue
             for (rid, key), out in zip(owners, outs):
                 if out is not None and out.numel() > 0 and out.data_ptr() not in _derived:

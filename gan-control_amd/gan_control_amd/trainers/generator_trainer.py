@@ -85,6 +85,31 @@ def none_grad_names(generator, discriminator, latent_size=512, img_channels=3, s
     return none_g, none_d
 
 
+def unused_parameter_names(generator, latent_size=512):
+    """Parameters the generator's forward does not read at all in its configuration -- the ``*.noise.weight`` strengths of the layers built
+    with noise_mode 'zeros' / 'id_zeros' (gan_model.py:391-399): a plain backward leaves them ``None`` in the reference, so Adam never creates
+    state for them.  Found the way the dry run finds its sets: one latent, one plain backward."""
+    dev = next(generator.parameters()).device
+    saved = [(p, p.grad, p.requires_grad) for p in generator.parameters()]
+    rng = torch.get_rng_state()
+    cuda_rng = torch.cuda.get_rng_state(dev) if dev.type == 'cuda' else None
+    try:
+        for p, _, _ in saved:
+            p.grad = None
+            p.requires_grad_(True)
+        with _backend.strict_zero_grads():
+            fake, _ = generator([torch.randn(1, latent_size, device=dev)])
+            fake.sum().backward()
+        return {n for n, p in generator.named_parameters() if p.grad is None}
+    finally:
+        for p, g, r in saved:
+            p.grad = g
+            p.requires_grad_(r)
+        torch.set_rng_state(rng)
+        if cuda_rng is not None:
+            torch.cuda.set_rng_state(cuda_rng, dev)
+
+
 class GeneratorTrainer:
     def __init__(self, config, device='cuda', seed=0, fused_adam=None, fuse_d_pair=True, loss_models=None):
         """loss_models: {config name ('embedding_loss', 'orientation_loss', ...): losses.LossModelClass} -- the attribute /
@@ -168,6 +193,8 @@ class GeneratorTrainer:
         single-process semantics the reference intends (SURVEY.md Appendix C #5)."""
         mc = self.model_config
         self.none_g_grads, self.none_d_grads = none_grad_names(self.generator, self.discriminator, mc['latent_size'], mc['img_channels'], mc['size'])
+        # only a non-default noise mode leaves parameters out of the forward pass (no second dry pass in the default configuration)
+        self.unused_g = unused_parameter_names(self.generator, mc['latent_size']) if mc.get('g_noise_mode', 'normal') != 'normal' else set()
 
     def state_dict(self):
         """Checkpoint layout of save_nets (:852-865) plus the state the reference forgets (Appendix C #4)."""
@@ -330,7 +357,7 @@ class GeneratorTrainer:
                 g_loss = g_loss + self.attribute_losses(fake_img, n)                    # calc_id_losses + calc_pose_losses :432-435
             g_loss.backward()
         self.g_reducer.finish()
-        self._fill_missing_grads(self.generator, ())
+        self._fill_missing_grads(self.generator, self.unused_g)   # parameters outside the forward keep None, as in the reference (no Adam state)
         self.g_optim.step()
 
     def attribute_losses(self, fake_img, n_mini_batches):

@@ -14,19 +14,32 @@ import torch
 # FFHQ-1024 (tools/host_profile.py iter).  The parameter SET of a network does not change while it trains; a network whose set does change
 # (load_state_dict(assign=True), added modules) is re-listed because the count no longer matches.
 _NAMED = weakref.WeakKeyDictionary()
+_HOOKED = weakref.WeakSet()  # networks whose load_state_dict already drops their entry
+
+
+_FULL_CHECK_EVERY = 256      # calls between two complete re-listings (~13 training iterations)
 
 
 def named_params(model):
-    """list(model.named_parameters()), cached.  Validated in O(1): the first and the last parameter must still be the objects registered under
-    their names (a swapped parameter object -- load_state_dict(assign=True), .to() on a meta model -- re-lists); call forget_params(model) after
-    adding or removing modules."""
+    """list(model.named_parameters()), cached.  Validated in O(1) per call: the first and the last parameter must still be the objects
+    registered under their names (a swapped parameter object -- load_state_dict(assign=True), .to() on a meta model -- re-lists).  A parameter
+    or submodule replaced in the MIDDLE of the list is caught by the complete re-listing every _FULL_CHECK_EVERY calls and by the
+    load_state_dict hook installed on first use; call forget_params(model) after adding or removing modules by hand.  The cache holds the
+    owning modules weakly (an entry must not keep its own key -- the root module -- alive)."""
     hit = _NAMED.get(model)
     if hit is not None:
-        lst, probes = hit
-        for owner, attr, p in probes:
-            if owner._parameters.get(attr) is not p:
+        lst, probes, calls = hit
+        calls[0] += 1
+        if calls[0] % _FULL_CHECK_EVERY == 0:
+            fresh = list(model.named_parameters())
+            if len(fresh) != len(lst) or any(a[1] is not b[1] or a[0] != b[0] for a, b in zip(fresh, lst)):
                 hit = None
-                break
+        if hit is not None:
+            for owner, attr, p in probes:
+                owner = owner()
+                if owner is None or owner._parameters.get(attr) is not p:
+                    hit = None
+                    break
     if hit is None:
         lst = list(model.named_parameters())
         probes = []
@@ -34,8 +47,11 @@ def named_params(model):
             mods = dict(model.named_modules())
             for name, p in (lst[0], lst[-1]):
                 owner, _, attr = name.rpartition('.')
-                probes.append((mods[owner], attr, p))
-        _NAMED[model] = (lst, probes)
+                probes.append((weakref.ref(mods[owner]), attr, p))
+        _NAMED[model] = (lst, probes, [0])
+        if model not in _HOOKED and hasattr(model, 'register_load_state_dict_post_hook'):
+            _HOOKED.add(model)
+            model.register_load_state_dict_post_hook(lambda module, incompatible: forget_params(module))
     return lst
 
 

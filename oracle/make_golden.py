@@ -683,6 +683,206 @@ def golden_step_isolated(size=1024, batch=4, name='step_1024_b4'):
     print(name, 'ok')
 
 
+def _chunked_passes(g, d, size, batch, inputs, none_g, none_d, cfg, sub):
+    """The four backward passes of golden_step_isolated with every network call cut into sub-batches of ``sub`` images, each chunk's
+    gradient accumulated into ``.grad`` -- for batches whose joint graph does not fit the build container (512 x 512 x 16 images carries
+    twice the activations of 1024 x 1024 x 4).  Exact by construction, not an approximation:
+
+    * the generator has no cross-sample operation (gan_model.py:709-801), and the discriminator's only one is the minibatch standard deviation,
+      whose ``view(group, -1, ...)`` (gan_model.py:1003-1012) puts samples {m, m + B/4, m + 2B/4, m + 3B/4} into one group: chunk m = ``[m::B/4]``
+      is one complete group, so D(chunk) equals the rows of D(batch);
+    * the loss over the whole batch is the reference's own function (d_logistic_loss / g_nonsaturating_loss / g_path_regularize_grad,
+      generator_trainer.py:563-566, 618-624, 683-688) applied to the re-assembled network outputs as a leaf: its backward gives the cotangent of every
+      output element (incl. the path-length mean's own gradient, :622-623), which each chunk's recomputed graph is then back-propagated with --
+      the chain rule, cut at the network output.  R1 (:712-719) is a mean of per-sample penalties and is accumulated directly.
+
+    golden_step_isolated_chunked asserts chunked == joint in float64 at a small size before using it.
+    Yields (phase, module, stats) after each pass; the caller records and zeroes the gradients."""
+    real, z_d, z_g, z_pl, pl_noise, noise_d, noise_g, noise_pl = inputs
+    n_sub = batch // sub
+    groups = [torch.arange(m, batch, n_sub) for m in range(n_sub)]          # complete minibatch-stddev groups
+    pick = lambda maps, idx: [t[idx] for t in maps]
+    # D step (generator_trainer.py:645-667)
+    ref_tu.requires_grad(g, False); ref_tu.requires_grad(d, True)
+    with torch.no_grad():
+        fake = torch.cat([g([z_d[i:i + sub]], noise=[t[i:i + sub] for t in noise_d])[0] for i in range(0, batch, sub)])
+        fake_pred = torch.empty(batch, 1, dtype=real.dtype)
+        real_pred = torch.empty(batch, 1, dtype=real.dtype)
+        for idx in groups:
+            fake_pred[idx] = d(fake[idx])[0]
+            real_pred[idx] = d(real[idx])[0]
+    fp, rp = fake_pred.clone().requires_grad_(True), real_pred.clone().requires_grad_(True)
+    d_loss = RT.d_logistic_loss(rp, fp) / len(real)
+    d_loss.backward()
+    for idx in groups:
+        d(fake[idx])[0].backward(fp.grad[idx])
+        d(real[idx])[0].backward(rp.grad[idx])
+    yield 'd', d, dict(d_loss=d_loss.detach(), real_pred_d=real_pred, fake_pred_d=fake_pred)
+    del fake
+    # R1 (generator_trainer.py:690-719): the mean over the batch of per-sample penalties
+    r1_total = 0.0
+    for idx in groups:
+        real_r = real[idx].clone().requires_grad_(True)
+        pred, _ = d(real_r)
+        r1 = RT.d_r1_loss(None, pred, real_r) * (len(idx) / batch)
+        (cfg['r1'] / 2 * r1 * cfg['d_reg_every'] + 0 * pred[0]).backward()
+        r1_total = r1_total + r1.detach()
+        del real_r, pred, r1
+    ref_tu.set_grad_none(d, none_d)
+    yield 'r1', d, dict(d_r1_loss=r1_total)
+    # G step (generator_trainer.py:407-436, vanilla)
+    ref_tu.requires_grad(g, True); ref_tu.requires_grad(d, False)
+    fake_pred = torch.empty(batch, 1, dtype=real.dtype)
+    with torch.no_grad():
+        for idx in groups:
+            fake_pred[idx] = d(g([z_g[idx]], noise=pick(noise_g, idx))[0])[0]
+    fp = fake_pred.clone().requires_grad_(True)
+    g_loss = RT.g_nonsaturating_loss(fp)
+    g_loss.backward()
+    for idx in groups:
+        d(g([z_g[idx]], noise=pick(noise_g, idx))[0])[0].backward(fp.grad[idx])
+    yield 'g', g, dict(g_adv_loss=g_loss.detach(), fake_pred_g=fake_pred)
+    # path length (generator_trainer.py:563-599, gan_model.py:803-811): two sweeps -- the per-sample latent gradients first, then the
+    # reference's penalty on all of them as a leaf, then each chunk's second-order graph back-propagated with its slice of the cotangent
+    pb = batch // 2
+    spans = [slice(i, min(i + sub, pb)) for i in range(0, pb, sub)]
+
+    def latent_grad(sl, create_graph):
+        fake, latent = g([z_pl[sl]], noise=[t[sl] for t in noise_pl], return_latents=True)
+        with mock.patch.object(torch, 'randn_like', lambda t: pl_noise[sl]):
+            grad = ref_gm.Generator.g_path_regularize_grad(fake, latent)
+        return (grad, fake) if create_graph else grad.detach()
+
+    grads = torch.cat([latent_grad(sl, False) for sl in spans]).requires_grad_(True)
+    path_loss, mean_path, lengths = RT.g_path_regularize_grad(grads, 0)
+    weight = cfg['path_regularize'] * cfg['g_reg_every']
+    (weight * path_loss).backward()                 # reaches the leaf ``grads`` only
+    for sl in spans:
+        grad, fake = latent_grad(sl, True)
+        autograd.backward([grad, 0 * fake[0, 0, 0, 0]], [grads.grad[sl], None])
+    ref_tu.set_grad_none(g, none_g)
+    yield 'pl', g, dict(g_path_loss=path_loss.detach(), path_lengths=lengths.detach(), g_mean_path_length=mean_path)
+
+
+def _joint_passes(g, d, size, batch, inputs, none_g, none_d, cfg):
+    """The same four passes on the whole batch at once (the body of golden_step_isolated, as a generator): the yardstick of the chunked form."""
+    real, z_d, z_g, z_pl, pl_noise, noise_d, noise_g, noise_pl = inputs
+    ref_tu.requires_grad(g, False); ref_tu.requires_grad(d, True)
+    with torch.no_grad():
+        fake, _ = g([z_d], noise=noise_d)
+    fake_pred, _ = d(fake)
+    real_pred, _ = d(real)
+    d_loss = RT.d_logistic_loss(real_pred, fake_pred) / len(real)
+    d_loss.backward()
+    yield 'd', d, dict(d_loss=d_loss.detach(), real_pred_d=real_pred.detach(), fake_pred_d=fake_pred.detach())
+    real_r = real.clone().requires_grad_(True)
+    real_pred, _ = d(real_r)
+    r1 = RT.d_r1_loss(None, real_pred, real_r)
+    (cfg['r1'] / 2 * r1 * cfg['d_reg_every'] + 0 * real_pred[0]).backward()
+    ref_tu.set_grad_none(d, none_d)
+    yield 'r1', d, dict(d_r1_loss=r1.detach())
+    ref_tu.requires_grad(g, True); ref_tu.requires_grad(d, False)
+    fake, _ = g([z_g], noise=noise_g)
+    fake_pred, _ = d(fake)
+    g_loss = RT.g_nonsaturating_loss(fake_pred)
+    g_loss.backward()
+    yield 'g', g, dict(g_adv_loss=g_loss.detach(), fake_pred_g=fake_pred.detach())
+    fake, latent = g([z_pl], noise=noise_pl, return_latents=True)
+    with mock.patch.object(torch, 'randn_like', lambda t: pl_noise):
+        grad = ref_gm.Generator.g_path_regularize_grad(fake, latent)
+    path_loss, mean_path, lengths = RT.g_path_regularize_grad(grad, 0)
+    (cfg['path_regularize'] * cfg['g_reg_every'] * path_loss + 0 * fake[0, 0, 0, 0]).backward()
+    ref_tu.set_grad_none(g, none_g)
+    yield 'pl', g, dict(g_path_loss=path_loss.detach(), path_lengths=lengths.detach(), g_mean_path_length=mean_path)
+
+
+def _isolated_inputs(size, batch, seed, noise_seeds, dtype=torch.float32):
+    """The draw order tests/step_checks.py::check_isolated repeats."""
+    gen = torch.Generator().manual_seed(seed)
+    real = torch.rand(batch, 3, size, size, generator=gen) * 2 - 1
+    z_d, z_g = torch.randn(batch, 512, generator=gen), torch.randn(batch, 512, generator=gen)
+    z_pl = torch.randn(batch // 2, 512, generator=gen)
+    pl_noise = torch.randn(batch // 2, 3, size, size, generator=gen)
+    maps = [seeded_noise(size, b, s) for b, s in zip((batch, batch, batch // 2), noise_seeds)]
+    cast = lambda t: t.to(dtype)
+    return gen, [cast(t) for t in (real, z_d, z_g, z_pl, pl_noise)] + [[cast(t) for t in m] for m in maps]
+
+
+def _none_grad_sets(g, d, size, gen, dtype=torch.float32):
+    """None-gradient name sets of the reference's dry run (generator_trainer.py:301-327), at batch 1."""
+    fake, latent = g([torch.randn(1, 512, generator=gen).to(dtype)], return_latents=True)
+    RT.g_path_regularize(fake, latent, 0)[0].backward()
+    none_g = sorted(n for n, p in g.named_parameters() if p.grad is None)
+    g.zero_grad()
+    t_in = torch.randn(1, 3, size, size, generator=gen).to(dtype).requires_grad_(True)
+    pred, _ = d(t_in)
+    RT.d_r1_loss(None, pred, t_in).backward()
+    none_d = sorted(n for n, p in d.named_parameters() if p.grad is None)
+    d.zero_grad()
+    return none_g, none_d
+
+
+def golden_step_isolated_chunked(size=512, batch=16, name='step_512_b16', sub=4, check_size=32):
+    """BASELINE config 2 at its own batch (configs/ffhq.json:11,22,23: 512 x 512, batch 16; same key layout as golden_step_isolated, so
+    tests/step_checks.py::check_isolated reads it unchanged).  The joint graph of 16 images does not fit this container, so the passes run
+    as _chunked_passes; that procedure is first held against the joint passes of the same reference modules in FLOAT64 at ``check_size``
+    (every parameter gradient, every statistic: 1e-9), then in float32 (bounded by summation order), and only then used at ``size``."""
+    import gc
+    cfg = dict(r1=1, g_reg_every=4, d_reg_every=16, path_regularize=2)
+    seeds = (21, 22, 23)
+    for dtype, bound in ((torch.float64, 1e-9), (torch.float32, 2e-4)):
+        g, d, _, _ = build_ref(check_size)
+        g, d = g.to(dtype), d.to(dtype)
+        gen, inputs = _isolated_inputs(check_size, batch, 4096, seeds, dtype)
+        none_g, none_d = _none_grad_sets(g, d, check_size, gen, dtype)
+        worst = 0.0
+        for (ph, mod, st), (ph2, mod2, st2) in zip(_joint_passes(g, d, check_size, batch, inputs, none_g, none_d, cfg),
+                                                   _snapshot(_chunked_passes, g, d, check_size, batch, inputs, none_g, none_d, cfg, sub)):
+            assert ph == ph2
+            joint = {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+            assert sorted(joint) == sorted(mod2), (ph, set(joint) ^ set(mod2))
+            total = float(torch.stack([v.double().pow(2).sum() for v in joint.values()]).sum().sqrt())
+            for n, v in joint.items():
+                err = float((v - mod2[n]).double().norm()) / max(float(v.double().norm()), 1e-3 * total)
+                worst = max(worst, err)
+                assert err <= bound, (name, str(dtype), ph, n, err)
+            for k, v in st.items():
+                a, b = torch.as_tensor(v).double().reshape(-1), torch.as_tensor(st2[k]).double().reshape(-1)
+                err = float((a - b).abs().max() / a.abs().max().clamp_min(1e-6))
+                assert err <= bound, (name, str(dtype), ph, k, err)
+            mod.zero_grad()
+        print(name, 'chunked == joint at %d x %d, batch %d, %s: worst per-parameter gradient difference %.2e' % (check_size, check_size, batch, dtype, worst), flush=True)
+        del g, d
+    gen, inputs = _isolated_inputs(size, batch, 4096, seeds)
+    g, d, _, _ = build_ref(size)
+    none_g, none_d = _none_grad_sets(g, d, size, gen)
+    gc.collect()
+    out = {'cfg': np.array([size, batch]), 'input_seed': np.array(4096), 'noise_seeds': np.array(seeds), 'z_d': inputs[1], 'z_g': inputs[2], 'z_pl': inputs[3],
+           'none_g': np.array(none_g), 'none_d': np.array(none_d), 'chunk': np.array(sub)}
+    for phase, mod, stats in _chunked_passes(g, d, size, batch, inputs, none_g, none_d, cfg, sub):
+        stats = {k: torch.as_tensor(v) for k, v in stats.items()}
+        names, norms, elems = sample_grads(mod)
+        out[f'iso/{phase}/names'] = np.array(names)
+        out[f'iso/{phase}/vals'] = torch.stack(norms)
+        out[f'iso/{phase}/elems'] = torch.stack(elems)
+        out.update({f'iso/stat/{k}': v for k, v in stats.items()})
+        print(name, phase, 'done:', {k: (float(v) if v.numel() == 1 else tuple(v.shape)) for k, v in stats.items()}, flush=True)
+        mod.zero_grad(); gc.collect()
+    np.savez_compressed(os.path.join(GOLD, name + '.npz'), **to_np(out))
+    print(name, 'ok')
+
+
+def _snapshot(passes, g, d, *args):
+    """Run a pass generator on DEEP COPIES of the networks and yield (phase, {name: gradient}, stats), zeroing in between, so that the joint and
+    the chunked passes can be walked side by side."""
+    import copy
+    g2, d2 = copy.deepcopy(g), copy.deepcopy(d)
+    for phase, mod, stats in passes(g2, d2, *args):
+        grads = {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
+        yield phase, grads, stats
+        mod.zero_grad()
+
+
 def golden_augment():
     """ADA transforms: sampled matrices under a fixed torch seed (pins the RNG call order) and the image-space
     result + input gradient of the reference's augment() for those matrices (non_leaking.py:394-398)."""
@@ -1028,13 +1228,15 @@ def golden_configs():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    torch.set_num_threads(8)
+    torch.set_num_threads(int(os.environ.get('GOLDEN_THREADS', '8')))
     jobs = {'upfirdn2d': golden_upfirdn2d, 'bias_act': golden_bias_act, 'convs': golden_convs, 'misc': golden_misc,
             'networks': golden_networks, 'noise_modes': golden_noise_modes, 'step': golden_step,
             # the BASELINE resolutions: ~15 min and ~40 GiB on 8 cores (1024x1024 at batch 4 does not fit this container's 64 GiB)
             'step_512': lambda: golden_step(512, 4, 'step_512'), 'step_1024': lambda: golden_step(1024, 2, 'step_1024'),
             # the bench workload itself (1024 x 1024, 4 images), one backward pass at a time: ~25 min, < 60 GiB
             'step_1024_b4': golden_step_isolated,
+            # BASELINE config 2 at its own batch (512 x 512, 16 images), chunked by minibatch-stddev group: ~40 min, < 30 GiB
+            'step_512_b16': golden_step_isolated_chunked,
             'augment': golden_augment, 'fid': golden_fid, 'controller': golden_controller, 'configs': golden_configs, 'controller_afhq': golden_controller_afhq, 'losses': golden_losses, 'inception': golden_inception}
     for name in (sys.argv[1:] or list(jobs)):
         jobs[name]()

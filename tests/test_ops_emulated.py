@@ -43,6 +43,33 @@ def test_network(size, emu_backend):
     oc.check_network(size, 'cpu')
 
 
+@pytest.mark.parametrize('precision', ['high', 'medium'])
+def test_generator_twice_under_non_default_matmul_precision(precision, emu_backend):
+    """the fused style path's latent gather must stay exact, and must not touch process state, under a non-default
+    set_float32_matmul_precision -- the second forward used to die inside torch's legacy / new API check.  (Image parity is not asserted
+    here: on the CPU 'medium' also lowers the emulated backend's own ATen products.)"""
+    from gan_control_amd.models import gan_model as gm
+    before = torch.get_float32_matmul_precision()
+    torch.set_float32_matmul_precision(precision)
+    try:
+        g, _ = oc.build_models(32, 'cpu')
+        z = torch.randn(2, 512, generator=torch.Generator().manual_seed(3))
+        for _ in range(2):
+            img, lat = g([z], return_latents=True)
+            assert torch.isfinite(img).all()
+            assert torch.get_float32_matmul_precision() == precision
+        plan = gm._STYLE_PLANS[g]
+        lat = lat.detach().clone().requires_grad_(True)
+        rows = gm._gather_latents(plan, lat)
+        want = lat.transpose(0, 1)[torch.tensor(plan.latent_index)].reshape(len(plan.latent_index), -1)
+        assert torch.equal(rows, want)
+        rows.backward(torch.ones_like(rows))
+        counts = torch.bincount(torch.tensor(plan.latent_index), minlength=lat.shape[1]).float()
+        assert torch.equal(lat.grad, counts[None, :, None].expand_as(lat))
+    finally:
+        torch.set_float32_matmul_precision(before)
+
+
 def test_no_cpu_fallback():
     """Without the emulation the product refuses CPU tensors instead of silently falling back."""
     from gan_control_amd.models.op import upfirdn2d, fused_leaky_relu

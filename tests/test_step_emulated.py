@@ -110,3 +110,87 @@ def test_direct_forward_equals_function_apply(emu_backend):
         for (n, p), (_, q) in zip(getattr(a, net).named_parameters(), getattr(b, net).named_parameters()):
             assert torch.equal(p, q), (net, n)
     assert float(a.mean_path_length) == float(b.mean_path_length)
+
+
+def test_direct_forward_records_no_graph(emu_backend):
+    """the direct route runs the forward with grad mode OFF, as Function.apply does -- an ATen op inside a forward that touches a
+    tensor requiring a gradient which is NOT an argument must not hand back an output with a graph attached."""
+    import torch
+    from gan_control_amd.models.op import _backend
+
+    hidden = torch.ones(3, requires_grad=True)
+
+    class Leaky(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            assert not torch.is_grad_enabled()
+            return x * hidden
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+
+    x = torch.ones(3)
+    assert _backend._DIRECT
+    y = _backend.call(Leaky, x)
+    assert not y.requires_grad and y.grad_fn is None
+    assert torch.is_grad_enabled()
+    with torch.no_grad():
+        y = _backend.call(Leaky, x)
+        assert not torch.is_grad_enabled()
+    assert not y.requires_grad
+    y = _backend.call(Leaky, x.clone().requires_grad_(True))
+    assert y.requires_grad and y.grad_fn is not None
+
+
+def test_named_params_cache_notices_a_replaced_parameter():
+    """ADVICE r4: trainers/utils.py::named_params -- a parameter swapped in the MIDDLE of the list is found by the periodic complete
+    re-listing, load_state_dict(assign=True) by its hook, and an entry does not keep its network alive."""
+    import gc
+    import weakref
+    import torch
+    from torch import nn
+    from gan_control_amd.trainers import utils as tu
+
+    net = nn.Sequential(nn.Linear(2, 2), nn.Linear(2, 2), nn.Linear(2, 2))
+    first = tu.named_params(net)
+    assert tu.named_params(net) is first
+    net[1].weight = nn.Parameter(torch.zeros(2, 2))                 # neither the first nor the last parameter
+    for _ in range(tu._FULL_CHECK_EVERY):
+        lst = tu.named_params(net)
+    assert lst is not first and dict(lst)['1.weight'] is net[1].weight
+    keep = tu.named_params(net)
+    net.load_state_dict({k: v.clone() for k, v in net.state_dict().items()}, assign=True)
+    assert tu.named_params(net) is not keep and dict(tu.named_params(net))['1.bias'] is net[1].bias
+    net[2].bias = nn.Parameter(torch.ones(2))                       # the last one: the O(1) probe
+    assert dict(tu.named_params(net))['2.bias'] is net[2].bias
+    ref = weakref.ref(net)
+    del net, first, lst, keep
+    gc.collect()
+    assert ref() is None
+
+
+def test_noise_mode_zeros_leaves_unused_strengths_without_adam_state(emu_backend):
+    """with g_noise_mode 'zeros' the reference never gives ``*.noise.weight`` of the affected layers a gradient (the fixture's
+    None set of a plain backward through the reference generator), so its Adam holds no state for them; the trainer's zero-fill of missing
+    gradients must leave them alone."""
+    import torch
+    import op_checks as oc
+    from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
+    cfg = default_config(32, 4)
+    cfg['model_config']['g_noise_mode'] = 'zeros'
+    tr = GeneratorTrainer(cfg, device='cpu', seed=0, fused_adam=False)
+    gold = oc.load_golden('noise_modes')
+    assert sorted(tr.unused_g) == [str(n) for n in gold['zeros/none_grad']]
+    real = tr.synthetic_batch()
+    tr.train_iteration(0, real)                  # D step, R1, G step, path length
+    named = dict(tr.generator.named_parameters())
+    for n, p in named.items():
+        if n in tr.unused_g:
+            assert p.grad is None and p not in tr.g_optim.state, n
+            assert float(p.detach().abs().max()) == 0.0
+        else:
+            assert p in tr.g_optim.state, n
+    # the default mode keeps the zero-not-None behaviour for every parameter
+    tr = GeneratorTrainer(default_config(32, 4), device='cpu', seed=0, fused_adam=False)
+    assert tr.unused_g == set()
