@@ -76,4 +76,10 @@ extern "C" int gc_conv2d_variant_name(const gc_conv_desc* d, int mode, char* nam
 }
 
 extern "C" int gc_abi_version(void) { return GC_ABI_VERSION; }
+extern "C" int gc_struct_sizes(size_t* sizes, int n) {
+    const size_t all[GC_STRUCT_COUNT] = {sizeof(gc_conv_desc), sizeof(gc_conv_epilogue), sizeof(gc_wlayout_group),
+                                         sizeof(gc_wpack_group), sizeof(gc_glin_group), sizeof(gc_wsq_group)};
+    for (int i = 0; sizes && i < n && i < GC_STRUCT_COUNT; ++i) sizes[i] = all[i];
+    return GC_STRUCT_COUNT;
+}
 extern "C" const char* gc_last_error(void) { return gc::err_buf(); }

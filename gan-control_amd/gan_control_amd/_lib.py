@@ -12,7 +12,7 @@ import torch  # noqa: F401  (must be imported first: it loads the HIP runtime th
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _DEFAULT = os.path.normpath(os.path.join(_HERE, '..', 'csrc', 'libgancontrol_hip.so'))
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _c_float_p = ctypes.c_void_p
 _i32, _i64, _f32, _vp, _sz = ctypes.c_int32, ctypes.c_int64, ctypes.c_float, ctypes.c_void_p, ctypes.c_size_t
@@ -49,10 +49,14 @@ class WsqGroup(ctypes.Structure):
     _fields_ = [('w', _vp), ('g', _vp), ('out', _vp), ('rows', _i32), ('taps', _i32)]
 
 
+# the mirrors above in the header's declaration order (gc_struct_sizes)
+STRUCTS = (ConvDesc, ConvEpilogue, WLayoutGroup, WPackGroup, GlinGroup, WsqGroup)
+
 # name -> (restype, argtypes); kept in one table so tests can check every exported symbol
 SIGNATURES = {
     'gc_abi_version': (_i32, []),
     'gc_last_error': (ctypes.c_char_p, []),
+    'gc_struct_sizes': (_i32, [ctypes.POINTER(_sz), _i32]),
     'gc_upfirdn2d_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 14 + [_vp]),
     'gc_upfirdn2d_act_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 11 + [_vp, _vp, _vp, _f32, _f32, _vp]),
     'gc_bias_act_f32': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _f32, _f32, _vp]),
@@ -148,6 +152,13 @@ def load():
         fn.restype, fn.argtypes = res, args
     if lib.gc_abi_version() != ABI_VERSION:
         raise RuntimeError(f'gan_control_amd: ABI version {lib.gc_abi_version()} != {ABI_VERSION}; rebuild the library')
+    # a library built from an older header with the same version number would mis-read every descriptor: compare struct sizes too
+    theirs = (_sz * len(STRUCTS))()
+    count = lib.gc_struct_sizes(theirs, len(STRUCTS))
+    ours = [ctypes.sizeof(c) for c in STRUCTS]
+    if count != len(STRUCTS) or list(theirs) != ours:
+        raise RuntimeError(f'gan_control_amd: {path} was built from another header: struct sizes {list(theirs)[:count]} (library) != {ours} '
+                           f'(binding: {[c.__name__ for c in STRUCTS]}); rebuild the library')
     _lib = lib
     return lib
 

@@ -25,7 +25,10 @@
 extern "C" {
 #endif
 
-#define GC_ABI_VERSION 1
+/* Bumped whenever a struct below changes layout or an entry point changes its signature (2: gc_conv_desc.in_pitch / out_pitch and
+ * gc_conv_epilogue.residual, added during ABI 1 without a bump, + gc_struct_sizes).  A binding must check BOTH gc_abi_version() and
+ * gc_struct_sizes() against its own mirrors before the first call: a stale library otherwise mis-reads every descriptor. */
+#define GC_ABI_VERSION 2
 
 #define GC_OK 0
 #define GC_ERR_BAD_ARG (-1)      /* null pointer, non-positive extent, inconsistent geometry */
@@ -37,6 +40,10 @@ typedef void* gc_stream_t; /* hipStream_t */
 
 int gc_abi_version(void);
 const char* gc_last_error(void);
+/* sizeof() of the library's own view of every struct of this header, in declaration order: gc_conv_desc, gc_conv_epilogue, gc_wlayout_group,
+ * gc_wpack_group, gc_glin_group, gc_wsq_group.  Writes min(n, count) entries and returns count. */
+#define GC_STRUCT_COUNT 6
+int gc_struct_sizes(size_t* sizes, int n);
 
 /* ------------------------------------------------------------------------------------------
  * K1  upfirdn2d: zero-stuff by (up) -> pad / crop -> 2-D FIR -> decimate by (down).

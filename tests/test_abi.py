@@ -52,3 +52,38 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setenv('GANCONTROL_HIP_LIB', '/nonexistent/libgancontrol_hip.so')
     with pytest.raises(RuntimeError, match='no CPU or PyTorch fallback'):
         _lib.load()
+
+
+def test_struct_mirrors_match_the_header_and_the_library(tmp_path):
+    """gc_conv_desc / gc_conv_epilogue grew fields under an unchanged GC_ABI_VERSION.  Three views of every struct must
+    agree: the header compiled by the host C compiler, the ctypes mirrors, and the built library's gc_struct_sizes()."""
+    import subprocess
+    from gan_control_amd import _lib
+    names = ['gc_conv_desc', 'gc_conv_epilogue', 'gc_wlayout_group', 'gc_wpack_group', 'gc_glin_group', 'gc_wsq_group']
+    src = tmp_path / 'sizes.c'
+    src.write_text('#include <stdio.h>\n#include "gancontrol_hip.h"\nint main(void) { printf("%d %d", GC_ABI_VERSION, GC_STRUCT_COUNT);'
+                   + ''.join(' printf(" %%zu", sizeof(%s));' % n for n in names) + ' return 0; }\n')
+    exe = tmp_path / 'sizes'
+    subprocess.run(['gcc', '-I', os.path.join(REPO, 'include'), str(src), '-o', str(exe)], check=True)
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    mirrors = [ctypes.sizeof(c) for c in _lib.STRUCTS]
+    assert out[0] == _lib.ABI_VERSION and out[1] == len(names) == len(_lib.STRUCTS)
+    assert out[2:] == mirrors
+    lib = _lib.load()
+    got = (ctypes.c_size_t * len(names))()
+    assert lib.gc_struct_sizes(got, len(names)) == len(names)
+    assert list(got) == mirrors
+
+
+def test_stale_library_is_rejected(monkeypatch):
+    """A library whose structs differ from the binding's mirrors (built from another header under the same version number) must not load."""
+    from gan_control_amd import _lib
+    _lib.load()
+
+    class OldConvDesc(ctypes.Structure):           # gc_conv_desc before in_pitch / out_pitch
+        _fields_ = _lib.ConvDesc._fields_[:-2]
+
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'STRUCTS', (OldConvDesc,) + tuple(_lib.STRUCTS[1:]))
+    with pytest.raises(RuntimeError, match='built from another header'):
+        _lib.load()
