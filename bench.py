@@ -68,7 +68,19 @@ def parse(argv=None):
     ap.add_argument('--cpu-baseline-size', type=int, default=None, help='resolution of the CPU sample (default: --size)')
     ap.add_argument('--no-host-issue', action='store_true', help='skip the untimed host-issue-time pass ("host_issue_ms_per_step")')
     ap.add_argument('--no-families', action='store_true', help='skip the untimed profiler pass behind "families" / "step_roofline"')
+    # Multi-GPU knobs: they only set the environment of the rank processes this command launches (self_launch), so the first session on an
+    # 8-GPU node is a sweep of flags, not an edit.  Under the driver's own torch.distributed.run command set the variables directly.
+    ap.add_argument('--rccl-algo', default=None, help='NCCL_ALGO for the ranks (Ring | Tree | ...; RCCL default when unset)')
+    ap.add_argument('--rccl-proto', default=None, help='NCCL_PROTO for the ranks (Simple | LL | LL128)')
+    ap.add_argument('--bucket-mb', type=float, default=None, help='gradient bucket size in MiB (GANCONTROL_BUCKET_MB, default 32)')
+    ap.add_argument('--last-bucket-mb', type=float, default=None, help='size of the bucket of the LAST gradients of a backward (GANCONTROL_LAST_BUCKET_MB, default = bucket size)')
+    ap.add_argument('--force-ddp', action='store_true',
+                    help='with --gpus 1: run the one rank through torch.distributed.run with the RCCL gradient reducer on (GANCONTROL_FORCE_DDP=1): '
+                         'the single-GPU cost of the data-parallel path (flat-buffer copies, hooks, one-rank collectives) against the plain run')
     return ap.parse_args(argv)
+
+
+RANK_ENV_FLAGS = (('rccl_algo', 'NCCL_ALGO'), ('rccl_proto', 'NCCL_PROTO'), ('bucket_mb', 'GANCONTROL_BUCKET_MB'), ('last_bucket_mb', 'GANCONTROL_LAST_BUCKET_MB'))
 
 
 def self_launch(args, argv, entry):
@@ -76,6 +88,13 @@ def self_launch(args, argv, entry):
 
     Runs before any GPU call or torch.cuda query of this process (re-exec'ing a process that has initialised the GPU takes
     the machine down on this pool; a child process is safe)."""
+    if not _TEST_CPU['enabled']:
+        # torch.cuda.device_count() does not initialise the GPU on this image (is_available() would): safe before the child starts
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print('bench.py: --gpus %d asked for, %d GPU(s) visible on this machine: not starting the %d-rank job (the ranks beyond the visible '
+                  'devices would fail at set_device and leave the others waiting at the rendezvous)' % (args.gpus, have, args.gpus), file=sys.stderr)
+            return 2
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
@@ -84,6 +103,11 @@ def self_launch(args, argv, entry):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')       # dmabuf IPC: RCCL across processes needs it on this host driver
     env.setdefault('NCCL_DEBUG', 'VERSION')                 # RCCL prints its version line once: evidence of which library ran
+    for flag, var in RANK_ENV_FLAGS:
+        if getattr(args, flag) is not None:
+            env[var] = str(getattr(args, flag))
+    if args.force_ddp:
+        env['GANCONTROL_FORCE_DDP'] = '1'
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in proc.stdout.splitlines():
@@ -267,16 +291,14 @@ def cpu_baseline(size):
            'sample': f'one call of each phase (D step, R1, G step, path length) at {size}x{size}, batch 1, fp32, oracle/step.py OracleStep on '
                      f'{cores} of {host_cores} host threads (the fastest of the thread sweep in this line), {sum(phases.values()):.1f} s; images/sec = 1 / (t_D + t_G + t_R1/16 + t_PL/4), '
                      f'the cadence of the GPU step (the lazy regularisers are {100 * (per_iter / plain - 1):.0f} % of the CPU iteration)'}
-    # The GPU step works on 4 images: the D step (the larger half of a plain iteration) once more at batch 4, where the host's cores have four
-    # samples to spread over; the G step is scaled by the same batch-4 / batch-1 ratio rather than run (it would add ~40 s to a leg that already
-    # takes two minutes) -- skipped altogether when the batch-1 sample was slow, so that the default bench stays within a few minutes.
+    # The GPU step works on 4 images: the plain iteration (D step + G step) once more at batch 4, where the host's cores have four samples to
+    # spread over -- skipped altogether when the batch-1 sample was slow, so that the default bench stays within a few minutes.
     if plain <= 45.0:
-        four = run_phases(4, ('d_step',))
-        ratio = four['d_step'] / phases['d_step']
-        t4 = four['d_step'] + phases['g_step'] * ratio
-        out['batch4'] = {'value_without_regularisers': 4.0 / t4, 'phase_seconds': {'d_step': round(four['d_step'], 2), 'g_step_estimated': round(phases['g_step'] * ratio, 2)},
-                         'note': 'D step at batch 4 on the same threads (measured); G step = its batch-1 time x the D step\'s batch-4 / batch-1 ratio (%.2f); '
-                                 'with the batch-1 share of the lazy regularisers: %.4f images/sec' % (ratio, 4.0 / (t4 * per_iter / plain))}
+        four = run_phases(4, ('d_step', 'g_step'))
+        t4 = four['d_step'] + four['g_step']
+        out['batch4'] = {'value_without_regularisers': 4.0 / t4, 'phase_seconds': {k: round(v, 2) for k, v in four.items()},
+                         'note': 'D step and G step at batch 4 on the same threads, both measured; with the batch-1 share of the lazy regularisers: '
+                                 '%.4f images/sec' % (4.0 / (t4 * per_iter / plain))}
         out['value_batch4'] = 4.0 / (t4 * per_iter / plain)
     return out
 
@@ -294,7 +316,7 @@ def _sync():
 def main(argv=None, entry=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
-    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    if 'WORLD_SIZE' not in os.environ and (args.gpus > 1 or args.force_ddp):
         # nothing above this line has touched the GPU (importing torch does not)
         raise SystemExit(self_launch(args, argv, entry or os.path.abspath(__file__)))
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -306,6 +328,8 @@ def main(argv=None, entry=None):
     if not cpu_test:
         if not torch.cuda.is_available():
             raise SystemExit('bench.py needs an MI355X: the hot path has no CPU fallback')
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit('bench.py: rank %d wants cuda:%d but %d GPU(s) are visible' % (rank, local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
     if world > 1:
         # N ranks share the host: do not let each spawn one intra-op thread per core (an explicit OMP_NUM_THREADS below 4 is respected)
@@ -496,6 +520,9 @@ def main(argv=None, entry=None):
             out['host_issue_ms_per_step'] = round(host_issue['ms_per_step'], 3)
             out['host_issue'] = host_issue
         if rccl is not None:
+            rccl['knobs'] = {var: os.environ.get(var) for _, var in RANK_ENV_FLAGS}
+            rccl['buckets'] = {'generator': len(trainer.g_reducer.buckets), 'discriminator': len(trainer.d_reducer.buckets),
+                               'bucket_bytes': trainer.g_reducer.bucket_bytes, 'last_bucket_bytes': trainer.g_reducer.last_bucket_bytes}
             out['rccl'] = rccl
         if comm is not None:
             out['comm'] = comm
@@ -524,6 +551,12 @@ def main(argv=None, entry=None):
                 for traffic_file in sorted((f for f in os.listdir(os.path.join(REPO, 'profiles')) if f.startswith('pmc_r') and f.endswith('_traffic.json')), reverse=True):
                     pmc = json.load(open(os.path.join(REPO, 'profiles', traffic_file)))
                     if pmc.get('kernel') == name:
+                        # the counters were collected on SOME build of the kernel: only one made from the sources this library was made
+                        # from may be quoted (the file carries the hash of the kernel's sources, tools/pmc_mix.py --parse)
+                        if pmc.get('source_hash') != _lib.source_hash():
+                            out['roofline']['traffic_source'] = ('dropped: profiles/%s was collected on other kernel sources (%s, now %s); re-run tools/pmc_mix.py'
+                                                                 % (traffic_file, pmc.get('source_hash'), _lib.source_hash()))
+                            break
                         out['roofline']['traffic'] = pmc['traffic_bytes_per_launch']
                         out['roofline']['traffic_unit'] = 'bytes/launch'
                         out['roofline']['traffic_source'] = pmc['source'] + ' (profiles/%s)' % traffic_file

@@ -125,6 +125,21 @@ SIGNATURES = {
 _lib = None
 
 
+def source_hash(files=('conv_bf16x3.hip', 'conv_common.h', 'common.h')):
+    """sha256 (first 16 hex digits) over the sources of the split-bf16 convolution kernels, next to the library: what a counter file
+    collected on one build is stamped with, so that it is never quoted for another (bench.py roofline.traffic, tools/pmc_mix.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    root = os.path.dirname(_DEFAULT)
+    for name in files:
+        try:
+            with open(os.path.join(root, name), 'rb') as f:
+                h.update(name.encode() + b'\0' + f.read())
+        except OSError:
+            return None
+    return h.hexdigest()[:16]
+
+
 def library_path():
     return os.environ.get('GANCONTROL_HIP_LIB', _DEFAULT)
 

@@ -98,10 +98,20 @@ class GradientReducer:
     are skipped.  After ``finish()`` the ``.grad`` tensors are views into the bucket buffers.
     """
 
-    def __init__(self, module, bucket_bytes=32 << 20, group=None, order_by_arrival=True):
+    def __init__(self, module, bucket_bytes=None, group=None, order_by_arrival=True, last_bucket_bytes=None):
+        """bucket_bytes: default 32 MiB (GANCONTROL_BUCKET_MB).  last_bucket_bytes (GANCONTROL_LAST_BUCKET_MB, default = bucket_bytes): size of the
+        bucket holding the gradients that arrive LAST -- the one collective backward cannot hide; a smaller one shortens the exposed tail at the
+        price of one more launch.  Both are the first knobs of the 8-GPU session (bench.py --bucket-mb / --last-bucket-mb)."""
         self.group = group
         self.enabled = self._armed = False
-        self.bucket_bytes = bucket_bytes
+        env_mb = lambda name: (float(os.environ[name]) if os.environ.get(name) else None)
+        if bucket_bytes is None:
+            bucket_bytes = int((env_mb('GANCONTROL_BUCKET_MB') or 32) * (1 << 20))
+        if last_bucket_bytes is None:
+            mb = env_mb('GANCONTROL_LAST_BUCKET_MB')
+            last_bucket_bytes = int(mb * (1 << 20)) if mb else bucket_bytes
+        self.bucket_bytes = max(1, bucket_bytes)
+        self.last_bucket_bytes = max(1, min(last_bucket_bytes, self.bucket_bytes))
         self._params = [p for p in module.parameters()]
         # reverse registration order approximates the order in which backward produces gradients; replaced by the OBSERVED order of
         # the first reduced pass (_reorder)
@@ -117,15 +127,28 @@ class GradientReducer:
         self.measure = False      # bench.py: tally payload bytes and the exposed (not overlapped) wait of every finish()
         self.bytes_reduced, self._stalls = 0, []
 
-    def _layout(self, ordered):
-        self.buckets, cur, size = [], [], 0
-        for p in ordered:
-            cur.append(p)
-            size += p.numel() * p.element_size()
-            if size >= self.bucket_bytes:
-                self.buckets.append(_Bucket(cur)); cur, size = [], 0
-        if cur:
-            self.buckets.append(_Bucket(cur))
+    def _layout(self, ordered, live=None):
+        """Buckets over ``ordered``; the first ``live`` parameters (default: all) are the ones that produce gradients, and the last of THOSE form
+        the small tail bucket when last_bucket_bytes < bucket_bytes."""
+        live = len(ordered) if live is None else live
+        nbytes = lambda p: p.numel() * p.element_size()
+        tail_at = live
+        if self.last_bucket_bytes < self.bucket_bytes and live > 1:
+            size = 0
+            while tail_at > 1 and size + nbytes(ordered[tail_at - 1]) <= self.last_bucket_bytes:
+                tail_at -= 1
+                size += nbytes(ordered[tail_at])
+            tail_at = min(tail_at, live - 1)             # at least one parameter
+        self.buckets = []
+        for part in (ordered[:tail_at], ordered[tail_at:live], ordered[live:]):
+            cur, size = [], 0
+            for p in part:
+                cur.append(p)
+                size += nbytes(p)
+                if size >= self.bucket_bytes:
+                    self.buckets.append(_Bucket(cur)); cur, size = [], 0
+            if cur:
+                self.buckets.append(_Bucket(cur))
         self._bucket_of = {p: b for b in self.buckets for p in b.params}
 
     def _reorder(self):
@@ -137,14 +160,15 @@ class GradientReducer:
         for p in self._arrival:
             if p not in seen:
                 seen.add(p); order.append(index[p])
+        live = len(order)
         order += [index[p] for p in reversed(self._params) if p not in seen]
         if dist.get_world_size(self.group) > 1:
             dev = self._params[0].device if dist.get_backend(self.group) == 'nccl' else 'cpu'
-            t = torch.tensor(order, dtype=torch.int64, device=dev)
+            t = torch.tensor(order + [live], dtype=torch.int64, device=dev)
             dist.broadcast(t, dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
-            order = t.tolist()
+            *order, live = t.tolist()
         # gradients an accumulation pass has already moved into an old bucket buffer keep their values: .grad owns its storage view
-        self._layout([self._params[i] for i in order])
+        self._layout([self._params[i] for i in order], live)
         self.arrival_order = order
 
     def remove(self):

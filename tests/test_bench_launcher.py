@@ -69,3 +69,49 @@ def test_bench_refuses_to_run_without_a_gpu_or_the_test_switch():
     out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--steps', '1', '--warmup', '0', '--no-cpu-baseline'],
                          env=_env(), capture_output=True, text=True, timeout=300)
     assert out.returncode != 0 and 'no CPU fallback' in (out.stderr + out.stdout)
+
+
+def test_more_ranks_than_gpus_is_refused_quickly():
+    """`bench.py --gpus 2` on a machine with fewer GPUs exits non-zero with a readable message instead of starting ranks
+    that die at set_device while the others wait at the rendezvous (here: no GPU at all; the -m gpu twin runs on the one-GPU box)."""
+    import time
+    import torch
+    want = torch.cuda.device_count() + 1
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', str(max(2, want)), '--steps', '1', '--warmup', '0', '--no-cpu-baseline'],
+                         env=_env(), capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and time.time() - t0 < 60
+    assert 'GPU(s) visible' in out.stderr and not [ln for ln in out.stdout.splitlines() if ln.startswith('{')]
+
+
+def test_rank_environment_knobs_and_forced_single_rank_ddp():
+    """--bucket-mb / --last-bucket-mb / --rccl-algo reach the ranks as environment (and show in the line); --force-ddp runs ONE rank through
+    the launcher with the gradient reducer on: the line then carries `comm` like an N > 1 line."""
+    out = subprocess.run([sys.executable, ENTRY, '--gpus', '2', '--bucket-mb', '0.25', '--last-bucket-mb', '0.01', '--rccl-algo', 'Ring'] + ARGS,
+                         env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert line['rccl']['knobs'] == {'NCCL_ALGO': 'Ring', 'NCCL_PROTO': None, 'GANCONTROL_BUCKET_MB': '0.25', 'GANCONTROL_LAST_BUCKET_MB': '0.01'}
+    assert line['rccl']['buckets']['bucket_bytes'] == 262144 and line['rccl']['buckets']['last_bucket_bytes'] == 10485
+    assert line['rccl']['buckets']['generator'] > 8
+    out = subprocess.run([sys.executable, ENTRY, '--force-ddp'] + ARGS, env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.splitlines() if ln.startswith('{')][0])
+    assert line['n_gpus'] == 1 and line['rccl']['ranks'] == 1 and line['comm']['bytes_per_step'] > 0
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_gpus_2_on_a_one_gpu_box_exits_non_zero_within_a_minute():
+    """The -m gpu twin of test_more_ranks_than_gpus_is_refused_quickly: on the one-GPU box `bench.py --gpus 2` must not hang."""
+    import time
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip('this box has the GPUs the command asks for')
+    t0 = time.time()
+    out = subprocess.run([sys.executable, os.path.join(REPO, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--no-cpu-baseline'],
+                         env=_env(), capture_output=True, text=True, timeout=60)
+    assert out.returncode != 0 and time.time() - t0 < 60
+    assert '1 GPU(s) visible' in out.stderr

@@ -241,6 +241,52 @@ def test_buckets_follow_the_observed_arrival_order():
         assert torch.allclose(got['grads'][n], p.grad, atol=1e-6), n
 
 
+def _tail_worker(rank, world, port, out):
+    _setup(rank, world, port)
+    from gan_control_amd.trainers.ddp import GradientReducer
+    torch.manual_seed(0)
+    net = _Interleaved()
+    big = 2 * 48 * 48 * 4
+    os.environ['GANCONTROL_BUCKET_MB'] = str(big / (1 << 20))
+    os.environ['GANCONTROL_LAST_BUCKET_MB'] = str(9500 / (1 << 20))         # body.0 (48 x 48 weights + 48 biases = 9408 bytes), the layer backward reaches last, alone
+    try:
+        red = GradientReducer(net)
+    finally:
+        del os.environ['GANCONTROL_BUCKET_MB'], os.environ['GANCONTROL_LAST_BUCKET_MB']
+    assert red.bucket_bytes == big and red.last_bucket_bytes == 9500
+    x = torch.randn(8, 48, generator=torch.Generator().manual_seed(3))[rank::world]
+    for it in range(3):
+        net.zero_grad(set_to_none=True)
+        red.begin(sync=True, phase='p'); net(x).square().mean().backward(); red.finish()
+    rep = dict(red.report['p'])
+    sizes = [sum(p.numel() * 4 for p in b.params) for b in red.buckets]
+    if rank == 0:
+        torch.save({'report': rep, 'sizes': sizes, 'grads': {n: p.grad.clone() for n, p in net.named_parameters()},
+                    'last': [n for n, p in net.named_parameters() if any(p is q for q in red.buckets[-1].params)]}, out)
+    dist.destroy_process_group()
+
+
+def test_small_last_bucket():
+    """GANCONTROL_LAST_BUCKET_MB (bench.py --last-bucket-mb): the gradients that arrive last get a bucket of their own, so the one collective
+    backward cannot hide is short; every bucket still launches from a hook and the reduced gradients are the full-batch ones."""
+    port = 25500 + os.getpid() % 2000
+    with tempfile.TemporaryDirectory() as tmp:
+        out = os.path.join(tmp, 'o.pt')
+        mp.spawn(_tail_worker, args=(2, port, out), nprocs=2, join=True)
+        got = torch.load(out)
+    assert got['sizes'][-1] == 9408 < min(got['sizes'][:-1]), got['sizes']
+    assert sorted(got['last']) == ['body.0.bias', 'body.0.weight'], got['last']
+    rep = got['report']
+    assert rep['finish'] == 0 and rep['late'] == 0 and rep['hook'] == len(got['sizes'])
+    assert rep['launched_at'][-1] == rep['gradients']
+    torch.manual_seed(0)
+    net = _Interleaved()
+    x = torch.randn(8, 48, generator=torch.Generator().manual_seed(3))
+    net(x).square().mean().backward()
+    for n, p in net.named_parameters():
+        assert torch.allclose(got['grads'][n], p.grad, atol=1e-6), n
+
+
 def _inputs(size=SIZE, global_b=GLOBAL_B):
     import op_checks as oc
     gen = torch.Generator().manual_seed(77)

@@ -51,7 +51,11 @@ def parse(fdir, wdir, out):
                      'algorithmic_bytes': algo, 'traffic_over_algorithmic': (read_b + write_b) / algo})
         tot += launches * (read_b + write_b); n += launches
         print(f'B{b} {c:4d}ch @{res:4d}: read {read_b / 2**20:8.1f} MiB  write {write_b / 2**20:8.1f} MiB  algorithmic {algo / 2**20:8.1f} MiB  x{(read_b + write_b) / algo:5.2f}')
-    json.dump({'kernel': KERNEL_LABEL, 'traffic_bytes_per_launch': tot / n,
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gan-control_amd'))
+    from gan_control_amd import _lib
+    algo_w = sum(r['launches_per_16_iterations'] * r['algorithmic_bytes'] for r in rows) / n
+    # source_hash: the kernel sources the measured library was built from -- bench.py quotes this file only for a library built from the same
+    json.dump({'kernel': KERNEL_LABEL, 'traffic_bytes_per_launch': tot / n, 'algorithmic_bytes_per_launch': algo_w, 'source_hash': _lib.source_hash(),
                'source': 'rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over tools/pmc_mix.py; FETCH_SIZE doubled (16-byte-per-lane loads); '
                          'fabric-side bytes (Infinity-Cache hits included), launch-weighted over the shape mix of the FFHQ-1024 step', 'shapes': rows}, open(out, 'w'), indent=1)
     print('launch-weighted traffic per launch: %.1f MiB' % (tot / n / 2**20))
