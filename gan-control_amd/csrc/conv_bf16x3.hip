@@ -56,7 +56,7 @@
 #define GC_WS_WIDE_CB32 4      // column blocks of the wide tiles of the 32-output-channel variant (4: 4 rows x 128 px)
 #endif
 #ifndef GC_CT_ABL
-#define GC_CT_ABL 0           // dev ablations of convt_fused_bf16x3_kernel (wrong results): 1 no stores, 2 no MFMAs, 4 no global loads
+#define GC_CT_ABL 0           // dev ablations of convt_fused_bf16x3_kernel (wrong results): 1 no stores, 2 no MFMAs, 4 no global loads, 8 no conversion (a pre-split input)
 #endif
 #ifndef GC_CT_DMA
 #define GC_CT_DMA 0           // 1: convt_fused_bf16x3_kernel copies the pre-split weight slab of a chunk HBM -> LDS by LDS-DMA instead of through registers.
@@ -86,6 +86,11 @@
 #endif
 #ifndef GC_WS_STRIDED
 #define GC_WS_STRIDED 1     // a workgroup's tiles are `groups` apart instead of consecutive (DRAM locality of the resident workgroups)
+#endif
+#ifndef GC_S2_ABL
+#define GC_S2_ABL 0         // dev ablations of conv_bf16x3_kernel at stride 2 (wrong results): 1 the loaded registers are written to LDS as they are -- no scale, no hi / lo
+                            // split, no masks: what a PRE-SPLIT input (the producer emitting channel-last bf16 pairs, same bytes) would leave of the staging;
+                            // 2 no patch loads and no patch commit at all (weights, fragment reads, MFMAs, stores only)
 #endif
 #ifndef GC_WS_ABL
 #define GC_WS_ABL 0         // dev ablations of conv_bf16x3_ws_kernel (wrong results): 1 no patch staging, 2 no weight DMA, 4 fragments read once, 8 no stores
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int k = min(k0 + kgl * 8 + q, p.K - 1);          // wave-uniform -> scalar offset
-                preg[j][q] = buf_load_u128(rx, boff, (unsigned)k * chan * 4u);
+                if (!(DOWN == 2 && GC_S2_ABL == 2)) preg[j][q] = buf_load_u128(rx, boff, (unsigned)k * chan * 4u);
             }
         }
     };
@@ -414,7 +419,18 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
                 }
             }
         };
-        if (ragged_rows) convert(std::true_type{}); else convert(std::false_type{});
+        if (DOWN == 2 && GC_S2_ABL == 1) {
+            // the 8 x 16 bytes of a task are 4 hi + 4 lo units' worth: stored without touching them
+#pragma unroll
+            for (int j = 0; j < C::NT; ++j) {
+                const typename C::Task tk = C::task_of(tb + 128 * j, lead);
+                const int rbase = kgl * PLANE + tk.row * C::RP;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (i < tk.used) { const int u = rbase + C::ucol(tk.col + i); p_h[u] = preg[j][i]; p_l[u] = preg[j][4 + i]; }
+            }
+        } else if (DOWN == 2 && GC_S2_ABL == 2) {
+        } else if (ragged_rows) convert(std::true_type{}); else convert(std::false_type{});
     };
     auto mfma_phase = [&]() {
         const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
@@ -560,6 +576,15 @@ __device__ __forceinline__ float scaled_plus(float a, float s, float r) {
 #pragma clang fp contract(off)
     const float v = a * s;
     return v + r;
+}
+// a + b / a * s, never contracted with a neighbouring operation
+__device__ __forceinline__ float plain_sum(float a, float b) {
+#pragma clang fp contract(off)
+    return a + b;
+}
+__device__ __forceinline__ float plain_mul(float a, float s) {
+#pragma clang fp contract(off)
+    return a * s;
 }
 
 // EPK: 0 = the full fused epilogue; 1 = out_scale and / or residual only (the input-gradient launches: G's modulated layers, D's ResBlock
@@ -749,57 +774,57 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
             voff[j] = inside ? (unsigned)(qy * p.out_w + qx) * 4u + (unsigned)(4 * hi) * oplane : OOB;
             nz[j] = (p.noise && inside) ? p.noise[((size_t)b * p.out_h + qy) * p.out_w + qx] : 0.f;
         }
-        if (EPK > 0) {
-            // (a template parameter: as a run-time branch the store sequences of the two paths were merged into one control-flow tangle that stored
-            // zeros.)  Values differ from the full epilogue's only in the sign of an exact zero (it adds +0 for the absent bias).
-            if (EPK == 1 && p.residual) {
+        // Two phases, no control flow inside either.  (Round 5: the first version evaluated the epilogue AT each store and chose between the
+        // residual / plain forms per element; the compiler turned that into one basic block per element -- two ds_read_b32 of out_scale / bias,
+        // each waited for on the spot, ~12 vector instructions, the store, a branch: 128 exposed LDS round trips per lane and tile on the
+        // MULTIPLYING waves, all eight of them at the same moment, next to 108 MFMAs per chunk.  tools/kernel_regs.py / the disassembly show it.)
+        // Phase 1: every accumulator becomes its final value in place.  The 16 out_scale / bias values of a 32-channel block that this lane's
+        // registers belong to are four runs of four consecutive channels: four 16-byte LDS reads each, issued together.
+        if (EPK < 2) {
+#pragma unroll
+            for (int i = 0; i < WOC; ++i) {
+                float so16[16], bi16[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 s4 = *reinterpret_cast<const float4*>(&s_so[i * 32 + 8 * q + 4 * hi]);
+                    so16[4 * q] = s4.x; so16[4 * q + 1] = s4.y; so16[4 * q + 2] = s4.z; so16[4 * q + 3] = s4.w;
+                    if (EPK == 0) {
+                        const float4 b4 = *reinterpret_cast<const float4*>(&s_bias[i * 32 + 8 * q + 4 * hi]);
+                        bi16[4 * q] = b4.x; bi16[4 * q + 1] = b4.y; bi16[4 * q + 2] = b4.z; bi16[4 * q + 3] = b4.w;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < WPX; ++j)
 #pragma unroll
-                    for (int i = 0; i < WOC; ++i)
-#pragma unroll
-                        for (int r = 0; r < 16; ++r)
-                            acc[i][j][r] = scaled_plus(acc[i][j][r], s_so[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi],
-                                                       buf_load_f32(rres, voff[j], (unsigned)(nb + i * 32 + (r & 3) + 8 * (r >> 2)) * oplane));
-            }
-#pragma unroll
-            for (int j = 0; j < WPX; ++j)
-#pragma unroll
-                for (int i = 0; i < WOC; ++i)
-#pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int ocs = nb + i * 32 + (r & 3) + 8 * (r >> 2);
-                        float v = acc[i][j][r];
-                        if (EPK == 1 && !p.residual) v *= s_so[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi];
-                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff[j], (int)((unsigned)ocs * oplane), GC_CONV_ST_AUX);
-                        acc[i][j][r] = 0.f;
+                        // EPK 1 (out_scale and / or residual only): the product is rounded on its own, as conv_epilogue rounds it; values differ from
+                        // the full epilogue's only in the sign of an exact zero (it adds +0 for the absent bias)
+                        if (EPK == 0) acc[i][j][r] = conv_epilogue(ec, acc[i][j][r], so16[r], bi16[r], nz[j]);
+                        else          acc[i][j][r] = plain_mul(acc[i][j][r], so16[r]);
                     }
-            return;
+            }
         }
-        if (p.residual) {
+        if (EPK < 2 && p.residual) {     // wave-uniform: one branch around the whole block; every load is issued before the first store
 #pragma unroll
             for (int j = 0; j < WPX; ++j)
 #pragma unroll
                 for (int i = 0; i < WOC; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        acc[i][j][r] = conv_epilogue(ec, acc[i][j][r], s_so[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi], s_bias[i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi], nz[j])
-                                       + buf_load_f32(rres, voff[j], (unsigned)(nb + i * 32 + (r & 3) + 8 * (r >> 2)) * oplane);
+                        acc[i][j][r] = plain_sum(acc[i][j][r], buf_load_f32(rres, voff[j], (unsigned)(nb + i * 32 + (r & 3) + 8 * (r >> 2)) * oplane));
         }
+        // Phase 2: nothing but stores
 #pragma unroll
-        for (int j = 0; j < WPX; ++j) {
+        for (int j = 0; j < WPX; ++j)
 #pragma unroll
-            for (int i = 0; i < WOC; ++i) {
+            for (int i = 0; i < WOC; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int ocl = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                     const int ocs = nb + i * 32 + (r & 3) + 8 * (r >> 2);
-                    const float v = p.residual ? acc[i][j][r] : conv_epilogue(ec, acc[i][j][r], s_so[ocl], s_bias[ocl], nz[j]);
+                    const float v = acc[i][j][r];
                     if (!(GC_WS_ABL & 8) || v == 12345.678f) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(int, v), ry, (int)voff[j], (int)((unsigned)ocs * oplane), GC_CONV_ST_AUX);
                     acc[i][j][r] = 0.f;
                 }
-            }
-        }
     };
     int tile_c = tile_begin, k0_c = 0;
     if (!GC_WS_DMA_STAGER) { weights(0, 0); wait_staged_loads(); }
@@ -1634,6 +1659,11 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
         const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
         const int inrow = p.in_w - (ix0 + t_col);                    // pixels of this group that are still inside the image row
         const int ubase = kgl_p * PLANE + t_row * PWD + t_col;
+        if (GC_CT_ABL & 8) {        // ablation: what a pre-split input would leave of the staging -- the loaded registers go to LDS as they are
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (i < t_used) { p_h[ubase + i] = preg[i]; p_l[ubase + i] = preg[4 + i]; }
+        } else {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float v[8];
@@ -1648,6 +1678,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
                 p_h[ubase + i] = h;
                 GC_LO(p_l[ubase + i] = l;)
             }
+        }
         }
         if (WDMA) wait_staged_loads();           // the LDS-DMA rows of this wave have landed (untracked by the compiler: counted by hand)
     };

@@ -830,8 +830,7 @@ def golden_step_isolated_chunked(size=512, batch=16, name='step_512_b16', sub=4,
     import gc
     cfg = dict(r1=1, g_reg_every=4, d_reg_every=16, path_regularize=2)
     seeds = (21, 22, 23)
-    for dtype, bound in ((torch.float64, 1e-9), (torch.float32, 1e-3)):     # float32: summation order only (a noise strength's gradient is ONE
-        # scalar summed over batch x channels x pixels of random-sign terms: 2e-4 measured; everything else ~1e-6)
+    for dtype, bound in ((torch.float64, 1e-9), (torch.float32, 2e-4)):     # float32: summation order only
         g, d, _, _ = build_ref(check_size)
         g, d = g.to(dtype), d.to(dtype)
         gen, inputs = _isolated_inputs(check_size, batch, 4096, seeds, dtype)
@@ -843,10 +842,18 @@ def golden_step_isolated_chunked(size=512, batch=16, name='step_512_b16', sub=4,
             joint = {n: p.grad.clone() for n, p in mod.named_parameters() if p.grad is not None}
             assert sorted(joint) == sorted(mod2), (ph, set(joint) ^ set(mod2))
             total = float(torch.stack([v.double().pow(2).sum() for v in joint.values()]).sum().sqrt())
+            scal = [(float(v), float(mod2[n])) for n, v in joint.items() if v.numel() == 1]
             for n, v in joint.items():
+                if v.numel() == 1 and dtype == torch.float32:
+                    continue        # a noise strength: ONE scalar = a random-sign sum over batch x channels x pixels; compared together below
                 err = float((v - mod2[n]).double().norm()) / max(float(v.double().norm()), 1e-3 * total)
                 worst = max(worst, err)
                 assert err <= bound, (name, str(dtype), ph, n, err)
+            if scal and dtype == torch.float32:
+                a, b = torch.tensor(scal, dtype=torch.float64).unbind(1)
+                err = float((a - b).norm() / a.norm().clamp_min(1e-3 * total))
+                print(name, ph, 'noise strengths as one vector, float32 chunked vs joint: %.2e' % err, flush=True)
+                assert err <= 20 * bound, (name, ph, 'scalar parameters', err)
             for k, v in st.items():
                 a, b = torch.as_tensor(v).double().reshape(-1), torch.as_tensor(st2[k]).double().reshape(-1)
                 err = float((a - b).abs().max() / a.abs().max().clamp_min(1e-6))

@@ -17,7 +17,7 @@ from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default
 names = sys.argv[1:] or ['step_1024_b4']
 out = {}
 for name in names:
-    for mode in ('f32', 'bf16x3'):
+    for mode in os.environ.get('PROBE_MODES', 'f32,bf16x3').split(','):
         _backend.get().conv_mode = mode
         m = step_checks._Measure()
         step_checks.check_isolated('cuda', name=name, measure=m, trainer=lambda size, batch: GeneratorTrainer(default_config(size, batch), device='cuda', seed=0))
