@@ -194,8 +194,40 @@ __global__ __launch_bounds__(256) void pack_weights_grouped_kernel(PackGroupArgs
 // v_sub_f32 by asm: left to itself the compiler pairs neighbouring channels into v_pk_mul_f32 / v_pk_add_f32, and packed fp32 does not
 // run under another wave's MFMA (profiles/pmc_r01.md, co-issue table) -- in the wave-specialised kernel the staging wave shares its SIMD
 // with two multiplying waves, so every packed instruction is time taken from the matrix pipe.
+// Two fp32 values -> one dword of two bf16 (a in the low half), round to nearest even: ONE v_cvt_pk_bf16_f32.  Written `(__bf16)f` element by
+// element the compiler spends one conversion per VALUE on the hi parts (it needs each hi back as a float for the lo part) and v_perm to pair
+// them up: 5.2 vector instructions per value in the staging loops (round 5, opcode histogram of the commit phase); from the PAIR the two hi
+// parts come back as floats by one shift and one mask -- 3 per value unscaled, 4 scaled, the same bits.
+#ifndef GC_PAIR_SPLIT
+#define GC_PAIR_SPLIT 1
+#endif
+__device__ __forceinline__ unsigned cvt_pk_bf16(float a, float b) {
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 template <bool SCALED>
 __device__ __forceinline__ void split8s(const float (&v)[8], const float (&sc)[8], uint4* h, uint4* l) {
+#if GC_PAIR_SPLIT && GC_PLAIN_SPLIT
+    unsigned hh[4], ll[4];
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {
+        float f0 = v[q], f1 = v[q + 1];
+        if (SCALED) { asm("v_mul_f32 %0, %1, %2" : "=v"(f0) : "v"(v[q]), "v"(sc[q])); asm("v_mul_f32 %0, %1, %2" : "=v"(f1) : "v"(v[q + 1]), "v"(sc[q + 1])); }
+        const unsigned pk = cvt_pk_bf16(f0, f1);
+        const float t0 = __uint_as_float(pk << 16), t1 = __uint_as_float(pk & 0xffff0000u);
+        float d0, d1;
+        // the low part of a scaled value is taken from the EXACT product (one fused multiply-subtract), so the rounding of v * sc to fp32
+        // is captured as well -- what the compiler's own contraction of `v * sc - hi` does
+        if (SCALED) { asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(d0) : "v"(v[q]), "v"(sc[q]), "v"(t0)); asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(d1) : "v"(v[q + 1]), "v"(sc[q + 1]), "v"(t1)); }
+        else        { asm("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(f0), "v"(t0)); asm("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(f1), "v"(t1)); }
+        hh[q / 2] = pk;
+        ll[q / 2] = cvt_pk_bf16(d0, d1);
+    }
+    *h = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+    *l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+#else
     bf16x8 hh, ll;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -210,8 +242,6 @@ __device__ __forceinline__ void split8s(const float (&v)[8], const float (&sc)[8
         const float tf = (float)t;
         float dlo;
 #if GC_PLAIN_SPLIT
-        // the low part of a scaled value is taken from the EXACT product (one fused multiply-subtract), so the rounding of v * sc to fp32
-        // is captured as well -- what the compiler's own contraction of `v * sc - hi` does
         if (SCALED) asm("v_fma_f32 %0, %1, %2, -%3" : "=v"(dlo) : "v"(v[q]), "v"(sc[q]), "v"(tf));
         else        asm("v_sub_f32 %0, %1, %2" : "=v"(dlo) : "v"(f), "v"(tf));
 #else
@@ -221,6 +251,7 @@ __device__ __forceinline__ void split8s(const float (&v)[8], const float (&sc)[8
     }
     *h = *reinterpret_cast<uint4*>(&hh);
     *l = *reinterpret_cast<uint4*>(&ll);
+#endif
 }
 
 template <int WG_OC, int WG_PX, int WOC, int WPX, int UP, int DOWN, int KS, int CB = 1>
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
         // four a group lies entirely inside the image or entirely outside (and was then fetched as zeros): the per-pixel row-end mask --
         // 32 selects per chunk -- is only needed for the odd widths (the 1025-wide planes of the stride-2 convolutions).
         const bool ragged_rows = ((p.in_w & 3) != 0 || a.in_pitch != p.in_w) && ix0 + lead + 32 * C::SEG_M + 4 > p.in_w;      // ... and there only in the tiles that reach the row end
-        auto convert = [&](auto masked) {
+        auto convert = [&](auto masked, auto scaled) {
 #pragma unroll
             for (int j = 0; j < C::NT; ++j) {
                 const typename C::Task tk = C::task_of(tb + 128 * j, lead);
@@ -410,7 +441,7 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
                         v[q] = (!decltype(masked)::value || i < inrow) ? __uint_as_float(raw) : 0.f;
                     }
                     uint4 h, l;
-                    split8s<true>(v, sc, &h, &l);        // plain (un-packed) multiplies and subtractions: see split8s
+                    split8s<decltype(scaled)::value>(v, sc, &h, &l);        // plain (un-packed) multiplies and subtractions: see split8s
                     if (i < tk.used) {
                         const int u = rbase + C::ucol(tk.col + i);
                         p_h[u] = h;
@@ -430,7 +461,11 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
                     if (i < tk.used) { const int u = rbase + C::ucol(tk.col + i); p_h[u] = preg[j][i]; p_l[u] = preg[j][4 + i]; }
             }
         } else if (DOWN == 2 && GC_S2_ABL == 2) {
-        } else if (ragged_rows) convert(std::true_type{}); else convert(std::false_type{});
+        } else if (p.si) {      // without modulation (every layer of D) the multiply by one is not issued
+            if (ragged_rows) convert(std::true_type{}, std::true_type{}); else convert(std::false_type{}, std::true_type{});
+        } else {
+            if (ragged_rows) convert(std::true_type{}, std::false_type{}); else convert(std::false_type{}, std::false_type{});
+        }
     };
     auto mfma_phase = [&]() {
         const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
@@ -571,12 +606,6 @@ __device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, const
                  : "=&s"(keep) : "v"(voff), "s"(base), "s"(dst) : "memory");
 }
 
-// a * s + r with the product rounded on its own, as conv_epilogue rounds it (no contraction into one fma)
-__device__ __forceinline__ float scaled_plus(float a, float s, float r) {
-#pragma clang fp contract(off)
-    const float v = a * s;
-    return v + r;
-}
 // a + b / a * s, never contracted with a neighbouring operation
 __device__ __forceinline__ float plain_sum(float a, float b) {
 #pragma clang fp contract(off)
@@ -955,6 +984,22 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4* 
     *l = make_uint4(__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7]));
     return;
 #endif
+#if GC_PAIR_SPLIT
+    unsigned hh[4], ll[4];
+#pragma unroll
+    for (int q = 0; q < 8; q += 2) {       // pairs: see cvt_pk_bf16 (the same bits as the element-by-element form below)
+        const float f0 = SCALED ? v[q] * scale : v[q], f1 = SCALED ? v[q + 1] * scale : v[q + 1];
+        const unsigned pk = cvt_pk_bf16(f0, f1);
+        const float t0 = __uint_as_float(pk << 16), t1 = __uint_as_float(pk & 0xffff0000u);
+        float d0, d1;
+        asm("v_sub_f32 %0, %1, %2" : "=v"(d0) : "v"(f0), "v"(t0));      // plain, not packed: v_pk_add_f32 stalls the matrix pipe (profiles/pmc_r01.md); +3..4 % at >= 64 channels
+        asm("v_sub_f32 %0, %1, %2" : "=v"(d1) : "v"(f1), "v"(t1));
+        hh[q / 2] = pk;
+        ll[q / 2] = cvt_pk_bf16(d0, d1);
+    }
+    *h = make_uint4(hh[0], hh[1], hh[2], hh[3]);
+    *l = make_uint4(ll[0], ll[1], ll[2], ll[3]);
+#else
     bf16x8 hh, ll;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -968,6 +1013,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], float scale, uint4* 
     }
     *h = *reinterpret_cast<uint4*>(&hh);
     *l = *reinterpret_cast<uint4*>(&ll);
+#endif
 }
 
 template <int WK, int WN, int WP, int TR, int KS>
@@ -1083,9 +1129,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD1(WK * WN == 1, ry, off, 16));
         }
     };
-    auto unit8 = [&](auto scaled_t, const float4 (&r)[2], int col0, int width, float scale, uint4* h, uint4* l) {
+    // `edge_t`: the column masks exist only in the variant that border tiles take.  (Round 5: written as a per-lane `if (unit straddles a border)`
+    // the compiler predicated the masks for EVERY lane and tile -- two compares, a scalar and, a select per value: 448 of the 1 021 vector
+    // instructions of the conversion phase; the tile-uniform switch in commit() makes it a scalar branch that 30 of 32 tile columns skip.)
+    auto unit8 = [&](auto scaled_t, auto edge_t, const float4 (&r)[2], int col0, int width, float scale, uint4* h, uint4* l) {
         float v[8] = {r[0].x, r[0].y, r[0].z, r[0].w, r[1].x, r[1].y, r[1].z, r[1].w};
-        if (col0 < 0 || col0 + 8 > width) {      // only lanes whose unit straddles an image border pay for the masks
+        if (decltype(edge_t)::value) {
 #pragma unroll
             for (int q = 0; q < 8; ++q) v[q] = (col0 + q >= 0 && col0 + q < width) ? v[q] : 0.f;
         }
@@ -1104,14 +1153,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
             b_tab = b;
         }
         wait_staged_loads();
-        auto items = [&](auto scaled_t) {          // without modulation (every layer of D) the multiply by one is not issued: it is packed fp32, which stalls the matrix pipe
+        auto items = [&](auto scaled_t, auto edge_t) {          // without modulation (every layer of D) the multiply by one is not issued: it is packed fp32, which stalls the matrix pipe
             constexpr bool SC = decltype(scaled_t)::value;
 #pragma unroll
             for (int j = 0; j < C::NPX; ++j) {
                 const unsigned d = (unsigned)opaque((int)xdesc[j]);       // opaque: nothing derived from the descriptor may be hoisted out of the tile loop (registers)
                 const float sc = SC ? s_scale[(d >> 24) & 63u] : 1.f;
                 uint4 h, l;
-                unit8(scaled_t, xreg[j], ox0 - p.pad_x + 8 * (int)((d >> 16) & 15u), p.in_w, sc, &h, &l);      // rows / channels outside the image were loaded as zeros
+                unit8(scaled_t, edge_t, xreg[j], ox0 - p.pad_x + 8 * (int)((d >> 16) & 15u), p.in_w, sc, &h, &l);      // rows / channels outside the image were loaded as zeros
                 if (256 * (j + 1) <= C::NXU || tid + 256 * j < C::NXU) { xh[d & 0xffffu] = h; GC_LO(xl[d & 0xffffu] = l;) }
             }
 #pragma unroll
@@ -1119,11 +1168,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
                 const unsigned d = (unsigned)opaque((int)ydesc[j]);
                 const float sc = SC ? s_scale[KT + ((d >> 24) & 63u)] : 1.f;
                 uint4 h, l;
-                unit8(scaled_t, yreg[j], ox0 + 8 * (int)((d >> 16) & 15u), p.out_w, sc, &h, &l);
+                unit8(scaled_t, edge_t, yreg[j], ox0 + 8 * (int)((d >> 16) & 15u), p.out_w, sc, &h, &l);
                 if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; GC_LO(yl[d & 0xffffu] = l;) }
             }
         };
-        if (scaled) items(std::true_type{}); else items(std::false_type{});
+        // tile-uniform: does any staged unit of this tile reach over the left / right image border?
+        const bool edge = ox0 - p.pad_x < 0 || ox0 - p.pad_x + 8 * XU > p.in_w || ox0 + 8 * YU > p.out_w;
+        if (scaled) { if (edge) items(std::true_type{}, std::true_type{}); else items(std::true_type{}, std::false_type{}); }
+        else        { if (edge) items(std::false_type{}, std::true_type{}); else items(std::false_type{}, std::false_type{}); }
         // the one unit per sample that was fetched from offset 0 instead of -pad (see prefetch): channel 0, image row 0, left halo
         if (k0 == 0 && ox0 == 0 && p.pad_x > 0 && oy0 < PH && oy0 - p.pad_y <= 0) {          // uniform and rare
             __syncthreads();
@@ -1348,8 +1400,8 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             b_tab = b;
         }
         wait_staged_loads();
-        auto items = [&](auto scaled_t) {
-            constexpr bool SC = decltype(scaled_t)::value;
+        auto items = [&](auto scaled_t, auto edge_t) {          // edge_t: the right-border masks, compiled only into the variant the last tile column takes (see wgrad_bf16x3_kernel)
+            constexpr bool SC = decltype(scaled_t)::value, EDGE = decltype(edge_t)::value;
 #pragma unroll
             for (int j = 0; j < C::NPX; ++j) {
                 const unsigned d = xd(j);
@@ -1362,7 +1414,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
                 const int room = p.in_w - col0;             // columns of this item inside the image (pad = 0: only the right border cuts)
                 float ev[8], od[8];
 #pragma unroll
-                for (int q = 0; q < 8; ++q) { ev[q] = 2 * q < room ? v[2 * q] : 0.f; od[q] = 2 * q + 1 < room ? v[2 * q + 1] : 0.f; }
+                for (int q = 0; q < 8; ++q) { ev[q] = (!EDGE || 2 * q < room) ? v[2 * q] : 0.f; od[q] = (!EDGE || 2 * q + 1 < room) ? v[2 * q + 1] : 0.f; }
                 uint4 eh, el, oh, ol;
                 split8<SC>(ev, sc, &eh, &el);
                 if (256 * (j + 1) <= C::NXI || tid + 256 * j < C::NXI) {
@@ -1382,13 +1434,15 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
                 float v[8] = {yreg[j][0].x, yreg[j][0].y, yreg[j][0].z, yreg[j][0].w, yreg[j][1].x, yreg[j][1].y, yreg[j][1].z, yreg[j][1].w};
                 const int room = p.out_w - col0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v[q] = q < room ? v[q] : 0.f;
+                for (int q = 0; q < 8; ++q) v[q] = (!EDGE || q < room) ? v[q] : 0.f;
                 uint4 h, l;
                 split8<SC>(v, sc, &h, &l);
                 if (256 * (j + 1) <= C::NYU || tid + 256 * j < C::NYU) { yh[d & 0xffffu] = h; GC_LO(yl[d & 0xffffu] = l;) }
             }
         };
-        if (scaled) items(std::true_type{}); else items(std::false_type{});
+        const bool edge = 2 * ox0 + 16 * NI > p.in_w || ox0 + 8 * YU > p.out_w;      // tile-uniform (pad = 0: only the right border cuts)
+        if (scaled) { if (edge) items(std::true_type{}, std::true_type{}); else items(std::true_type{}, std::false_type{}); }
+        else        { if (edge) items(std::false_type{}, std::true_type{}); else items(std::false_type{}, std::false_type{}); }
     };
 
     if (t_begin < t_end) {
@@ -1541,7 +1595,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     uint4* wl_l = wl_h + C::WUNITS;
     uint4* p_h = wl_l + C::WUNITS;              // [kg][PH][PWD]
     uint4* p_l = p_h + C::PUNITS;
-    __shared__ float s_so[OCT], s_bias[OCT];    // out_scale / bias of this workgroup's channels (see conv_epilogue)
+    __shared__ __attribute__((aligned(16))) float s_so[OCT], s_bias[OCT];    // out_scale / bias of this workgroup's channels (see conv_epilogue)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
@@ -1673,7 +1727,8 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
                 v[q] = i < inrow ? __uint_as_float(raw) : 0.f;
             }
             uint4 h, l;
-            split8s<true>(v, sc, &h, &l);        // plain (un-packed) multiplies and subtractions: see split8s
+            if (p.si) split8s<true>(v, sc, &h, &l);        // plain (un-packed) multiplies and subtractions: see split8s
+            else      split8s<false>(v, sc, &h, &l);       // D's input-gradient launches: no per-sample scale, no multiply by one
             if (i < t_used) {
                 p_h[ubase + i] = h;
                 GC_LO(p_l[ubase + i] = l;)
@@ -1749,6 +1804,16 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
             nz[j][ph >> 1][ph & 1] = (EPI == 2 && p.noise) ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
         }
     }
+    // out_scale / bias of this lane's 16 channels (four runs of four consecutive ones), fetched ONCE before the store loops: read at each
+    // store they cost one exposed LDS round trip per output pair (round 5, found in the disassembly: 124 of 128 stores behind an lgkmcnt wait)
+    float so16[16], bi16[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float4 s4 = EPI > 0 ? *reinterpret_cast<const float4*>(&s_so[wave_oc * 32 + 8 * q + 4 * hi]) : make_float4(1.f, 1.f, 1.f, 1.f);
+        const float4 b4 = EPI == 2 ? *reinterpret_cast<const float4*>(&s_bias[wave_oc * 32 + 8 * q + 4 * hi]) : make_float4(0.f, 0.f, 0.f, 0.f);
+        so16[4 * q] = s4.x; so16[4 * q + 1] = s4.y; so16[4 * q + 2] = s4.z; so16[4 * q + 3] = s4.w;
+        bi16[4 * q] = b4.x; bi16[4 * q + 1] = b4.y; bi16[4 * q + 2] = b4.z; bi16[4 * q + 3] = b4.w;
+    }
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         const int qy = qy0 + (wave_px * WPX + j) * RPB + l31 / TPW, qx = qx0 + l31 % TPW;
@@ -1772,8 +1837,8 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
                 const int ocl = wave_oc * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
                 if (n0 + ocl < p.N) {
                     float v0 = acc[py * 2][j][r], v1 = acc[py * 2 + 1][j][r];
-                    if (EPI == 1) { v0 *= s_so[ocl]; v1 *= s_so[ocl]; }
-                    if (EPI == 2) { v0 = conv_epilogue(ec, v0, s_so[ocl], s_bias[ocl], nz[j][py][0]); v1 = conv_epilogue(ec, v1, s_so[ocl], s_bias[ocl], nz[j][py][1]); }
+                    if (EPI == 1) { v0 *= so16[r]; v1 *= so16[r]; }
+                    if (EPI == 2) { v0 = conv_epilogue(ec, v0, so16[r], bi16[r], nz[j][py][0]); v1 = conv_epilogue(ec, v1, so16[r], bi16[r], nz[j][py][1]); }
                     if (EPI == 2 && p.residual) { v0 += res[0][r]; v1 += res[1][r]; }
                     float* yp = yb + ((size_t)(n0 + ocl) * p.out_h + oy) * opitch + ox;
                     if ((GC_CT_ABL & 1) && v0 != 12345.678f) continue;
