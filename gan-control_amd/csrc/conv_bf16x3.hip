@@ -809,7 +809,9 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
         // MULTIPLYING waves, all eight of them at the same moment, next to 108 MFMAs per chunk.  tools/kernel_regs.py / the disassembly show it.)
         // Phase 1: every accumulator becomes its final value in place.  The 16 out_scale / bias values of a 32-channel block that this lane's
         // registers belong to are four runs of four consecutive channels: four 16-byte LDS reads each, issued together.
-        if (EPK < 2) {
+        // (with a residual its loads belong to the same block as the arithmetic: issued from a separate block after phase 1 their latency was
+        // exposed once per tile -- 512 -> 512 @64^2 with scale + residual 199 -> 217 us in the first version of this change)
+        auto phase1 = [&](auto with_res) {
 #pragma unroll
             for (int i = 0; i < WOC; ++i) {
                 float so16[16], bi16[16];
@@ -828,20 +830,13 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
                     for (int r = 0; r < 16; ++r) {
                         // EPK 1 (out_scale and / or residual only): the product is rounded on its own, as conv_epilogue rounds it; values differ from
                         // the full epilogue's only in the sign of an exact zero (it adds +0 for the absent bias)
-                        if (EPK == 0) acc[i][j][r] = conv_epilogue(ec, acc[i][j][r], so16[r], bi16[r], nz[j]);
-                        else          acc[i][j][r] = plain_mul(acc[i][j][r], so16[r]);
+                        float v = EPK == 0 ? conv_epilogue(ec, acc[i][j][r], so16[r], bi16[r], nz[j]) : plain_mul(acc[i][j][r], so16[r]);
+                        if (decltype(with_res)::value) v = plain_sum(v, buf_load_f32(rres, voff[j], (unsigned)(nb + i * 32 + (r & 3) + 8 * (r >> 2)) * oplane));
+                        acc[i][j][r] = v;
                     }
             }
-        }
-        if (EPK < 2 && p.residual) {     // wave-uniform: one branch around the whole block; every load is issued before the first store
-#pragma unroll
-            for (int j = 0; j < WPX; ++j)
-#pragma unroll
-                for (int i = 0; i < WOC; ++i)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r)
-                        acc[i][j][r] = plain_sum(acc[i][j][r], buf_load_f32(rres, voff[j], (unsigned)(nb + i * 32 + (r & 3) + 8 * (r >> 2)) * oplane));
-        }
+        };
+        if (EPK < 2) { if (p.residual) phase1(std::true_type{}); else phase1(std::false_type{}); }      // wave-uniform: one branch around the whole block
         // Phase 2: nothing but stores
 #pragma unroll
         for (int j = 0; j < WPX; ++j)

@@ -21,24 +21,25 @@ def test_training_moves_samples_towards_the_data_in_both_arithmetics():
         space = ts.FeatureSpace(dev)
         train_set = ts.procedural_images(2048, 32, seed=7, device=dev)
         held_out = ts.procedural_images(1000, 32, seed=8, device=dev)
-        real_stats = space.stats(held_out)
-        floor = space.distance(train_set[:1000], real_stats)
+        real = {'inception': space.stats(held_out), 'pixel': ts.pixel_stats(held_out)}
+        floor = ts.pixel_distance(train_set[:1000], real['pixel'])
         runs = {}
         for mode in ('f32', 'bf16x3'):
-            runs[mode] = ts.run_hip(space, real_stats, train_set, 32, 16, SHORT_ITERS, 0, mode, 1000)
+            runs[mode] = ts.run_hip(space, real, train_set, 32, 16, SHORT_ITERS, 0, mode, 1000)
             print(mode, runs[mode])
     finally:
         hip.conv_mode = prev
         torch.cuda.empty_cache()
     for mode, r in runs.items():
-        d0, d1 = r['distance']['0'], r['distance'][str(SHORT_ITERS)]
+        d0, d1 = r['distance'][KEY]['0'], r['distance'][KEY][str(SHORT_ITERS)]
         assert r['finite'], mode
         assert d1 < d0 / FALL_AT_SHORT_ITERS, (mode, d0, d1, floor)
         # the game is alive: the discriminator's logistic loss neither collapses to 0 nor blows up (2 ln 2 = 1.39 at equilibrium)
         assert all(0.1 < w < 2.5 for w in r['d_logistic_windows'][1:]), (mode, r['d_logistic_windows'])
-    a, b = (runs[m]['distance'][str(SHORT_ITERS)] for m in ('f32', 'bf16x3'))
+    a, b = (runs[m]['distance'][KEY][str(SHORT_ITERS)] for m in ('f32', 'bf16x3'))
     assert abs(a - b) <= MODE_GAP * max(a, b), (a, b)        # same data order, seeds and initial weights: the arithmetics end in the same region
 
 
+KEY = 'raw/pixel'
 FALL_AT_SHORT_ITERS = 1.5      # set from profiles/train_sanity_r05.json (see module docstring)
 MODE_GAP = 0.6

