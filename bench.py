@@ -562,8 +562,8 @@ def main(argv=None, entry=None):
                         out['roofline']['traffic_source'] = pmc['source'] + ' (profiles/%s)' % traffic_file
                         break
                 if name.startswith('conv_bf16x3_ws_kernel'):
-                    out['roofline']['rocprof_names'] = ('rocprofv3 lists this kernel once per epilogue variant -- %s, <KS, WOC, CB, 0 | 1 | 2> (full / scale-or-residual / none): '
-                                                        'compare avg_launch_us with their launch-weighted average' % name.split('|')[0].replace('>', ', EPK>'))
+                    out['roofline']['rocprof_names'] = ('rocprofv3 lists this kernel once per epilogue variant -- %s, <KS, WOC, CB, 0 | 1 | 2, residual> (full / scale-or-residual / none): '
+                                                        'compare avg_launch_us with their launch-weighted average' % name.split('|')[0].replace('>', ', EPK, RES>'))
                 if split:
                     out['roofline']['note'] = ('achieved = ALGORITHMIC flops/s; the split-bf16 kernel issues 3 bf16 MFMAs per product, '
                                                'so the matrix pipes do 3x this (frac of bf16 peak spent = %.3f) and frac <= 1/3 by construction; '

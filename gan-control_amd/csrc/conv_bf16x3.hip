@@ -92,6 +92,9 @@
                             // split, no masks: what a PRE-SPLIT input (the producer emitting channel-last bf16 pairs, same bytes) would leave of the staging;
                             // 2 no patch loads and no patch commit at all (weights, fragment reads, MFMAs, stores only)
 #endif
+#ifndef GC_FRAG_PIPE
+#define GC_FRAG_PIPE 1      // conv_bf16x3_kernel (up = 1): fragment reads of the next tap issued before the MFMAs of the current one (0: the compiler's order)
+#endif
 #ifndef GC_WS_ABL
 #define GC_WS_ABL 0         // dev ablations of conv_bf16x3_ws_kernel (wrong results): 1 no patch staging, 2 no weight DMA, 4 fragments read once, 8 no stores
 #endif
@@ -468,6 +471,43 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
         }
     };
     auto mfma_phase = [&]() {
+#if GC_FRAG_PIPE
+        if constexpr (UP == 1) {
+            // Fragment double buffer, as in the wave-specialised kernel: the LDS reads of tap t + 1 are issued BEFORE the MFMAs of tap t (the
+            // scheduling barriers pin that order).  Left alone the compiler issues a tap's reads and waits for them on the spot -- the
+            // disassembly of the stride-2 variant showed `ds_read x4, s_waitcnt lgkmcnt, v_mfma` with one or two MFMAs between two waits.
+            bf16x8 fa[2][2 * WOC], fb[2][2 * WPX];
+            auto load_tap = [&](int t, int set) {
+                const int jy = t / KS, jx = t % KS;
+                const int wbase = t * KG * OCT + aoff;
+                const int pbase = jy * C::RP + C::ucol(l31 * DOWN + jx);
+#pragma unroll
+                for (int i = 0; i < WOC; ++i) {
+                    const uint4 uh = wl_h[wbase + i * 32];
+                    fa[set][i] = *reinterpret_cast<const bf16x8*>(&uh);
+                    GC_LO(const uint4 ul = wl_l[wbase + i * 32]; fa[set][WOC + i] = *reinterpret_cast<const bf16x8*>(&ul);)
+                }
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) {
+                    const uint4 uh = p_h[pbase + boff[j]];
+                    fb[set][j] = *reinterpret_cast<const bf16x8*>(&uh);
+                    GC_LO(const uint4 ul = p_l[pbase + boff[j]]; fb[set][WPX + j] = *reinterpret_cast<const bf16x8*>(&ul);)
+                }
+            };
+            load_tap(0, 0);
+#pragma unroll
+            for (int t = 0; t < KS * KS; ++t) {
+                if (t + 1 < KS * KS) load_tap(t + 1, (t + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < WOC; ++i)
+#pragma unroll
+                    for (int j = 0; j < WPX; ++j) { GC_MFMA3(acc[i][j], fa[t & 1][i], fa[t & 1][WOC + i], fb[t & 1][j], fb[t & 1][WPX + j]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            return;
+        }
+#endif
         const int nty = UP == 1 ? KS : ay.n, ntx = UP == 1 ? KS : ax.n;
         for (int jy = 0; jy < nty; ++jy) {
             for (int jx = 0; jx < ntx; ++jx) {
@@ -619,7 +659,10 @@ __device__ __forceinline__ float plain_mul(float a, float s) {
 // EPK: 0 = the full fused epilogue; 1 = out_scale and / or residual only (the input-gradient launches: G's modulated layers, D's ResBlock
 // convolutions); 2 = nothing to apply.  Compile-time: the epilogue runs on the MULTIPLYING waves (6 vector instructions + 2 LDS reads per output
 // element in its full form, 384 per lane and tile, both waves of a SIMD at the same moment) next to only 108 MFMAs per tile at 32 input channels.
-template <int KS, int WOC, int CB, int EPK = 0>
+// RES: the launch adds a residual (gc_conv_epilogue.residual).  Compile-time as well: the residual form keeps 64 loads in flight next to the
+// accumulators, and as a run-time branch of the SAME kernel its register pressure spilled values that live across the whole kernel (34 VGPRs,
+// a -9 .. -20 % on the 64-channel layers WITHOUT a residual, same-box A/B profiles/kernel_ab_r05_b.log).
+template <int KS, int WOC, int CB, int EPK = 0, bool RES = false>
 __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     using C = BCfg<1, 8, WOC, 2, 1, 1, KS, CB>;      // CB = 1: 16 rows x 32 px tiles; CB = 2: 8 rows x 64 px (longer contiguous runs per row: the HBM-bound layers)
     constexpr int OCT = 32 * WOC, TPH = C::TPH, PLANE = C::PLANE, WPX = 2, NTAP = KS * KS;
@@ -836,7 +879,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
                     }
             }
         };
-        if (EPK < 2) { if (p.residual) phase1(std::true_type{}); else phase1(std::false_type{}); }      // wave-uniform: one branch around the whole block
+        if (EPK < 2) phase1(std::integral_constant<bool, RES>{});
         // Phase 2: nothing but stores
 #pragma unroll
         for (int j = 0; j < WPX; ++j)
@@ -1742,6 +1785,59 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
         const bool more = k0 + KCB < p.K;
         prefetch(more ? k0 + KCB : k0);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
         __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
+#if GC_FRAG_PIPE
+        if (!(GC_CT_ABL & 2)) {
+            // The nine (phase, tap) steps of a chunk as one software pipeline: the weight fragment of step s + 1 -- and the patch fragments of the
+            // next neighbour group when the group changes -- are read BEFORE the MFMAs of step s (scheduling barriers pin the order); the compiler's
+            // own order waited `lgkmcnt(0)` a dozen times per chunk with one to five MFMAs in between.
+            // step s -> neighbour group g = (dyi, dxi): s = 0: (0,0); 1, 2: (0,1); 3, 4: (1,0); 5..8: (1,1)
+            bf16x8 fbh[WDMA ? 2 : 1][WPX], fbl[WDMA ? 2 : 1][WPX], fah[2], fal[2];
+            auto grp = [](int s_) { return s_ == 0 ? 0 : (s_ < 3 ? 1 : (s_ < 5 ? 2 : 3)); };
+            auto load_b = [&](int g, int set) {
+                const int dyi = g >> 1, dxi = g & 1;
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) {
+                    const uint4 uh = p_h[boff[j] + dyi * PWD + dxi];
+                    fbh[set][j] = *reinterpret_cast<const bf16x8*>(&uh);
+                    GC_LO(const uint4 ul = p_l[boff[j] + dyi * PWD + dxi]; fbl[set][j] = *reinterpret_cast<const bf16x8*>(&ul);)
+                }
+            };
+            auto step_of = [&](int s_, int& py, int& px, int& ty, int& tx) {
+                const int g = grp(s_), dyi = g >> 1, dxi = g & 1;
+                const int iy = g == 2 ? s_ - 3 : (g == 3 ? (s_ - 5) >> 1 : 0), ix = g == 1 ? s_ - 1 : (g == 3 ? (s_ - 5) & 1 : 0);
+                py = (dyi == 1 && iy == 1) ? 1 : 0; ty = dyi == 0 ? 0 : (iy == 0 ? 2 : 1);
+                px = (dxi == 1 && ix == 1) ? 1 : 0; tx = dxi == 0 ? 0 : (ix == 0 ? 2 : 1);
+            };
+            auto load_a = [&](int s_, int set) {
+                int py, px, ty, tx;
+                step_of(s_, py, px, ty, tx);
+                const int wbase = (ty * 3 + tx) * KG * OCT + aoff;
+                const uint4 uh = wl_h[wbase];
+                fah[set] = *reinterpret_cast<const bf16x8*>(&uh);
+                GC_LO(const uint4 ul = wl_l[wbase]; fal[set] = *reinterpret_cast<const bf16x8*>(&ul);)
+            };
+            // (two sets of patch fragments only where the registers allow it: with the weight slab staged through registers -- WDMA = false,
+            // 40 more live registers -- the second set spilled INSIDE the chunk loop, a scratch reload in front of every prefetch pair)
+            constexpr int BSETS = WDMA ? 2 : 1;
+            load_b(0, 0);
+            load_a(0, 0);
+#pragma unroll
+            for (int s_ = 0; s_ < 9; ++s_) {
+                if (BSETS == 1 && s_ > 0 && grp(s_) != grp(s_ - 1)) load_b(grp(s_), 0);
+                if (s_ + 1 < 9) {
+                    load_a(s_ + 1, (s_ + 1) & 1);
+                    if (BSETS == 2 && grp(s_ + 1) != grp(s_)) load_b(grp(s_ + 1), grp(s_ + 1) & 1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                int py, px, ty, tx;
+                step_of(s_, py, px, ty, tx);
+                const int bs = BSETS == 2 ? grp(s_) & 1 : 0;
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) { GC_MFMA3(acc[py * 2 + px][j], fah[s_ & 1], fal[s_ & 1], fbh[bs][j], fbl[bs][j]); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
+#endif
 #pragma unroll
         for (int dyi = 0; dyi < 2; ++dyi) {
 #pragma unroll
@@ -2320,9 +2416,12 @@ int launch_ws(Bf16Args a, hipStream_t s) {
     if (gc::probing()) return gc::probe_name("conv_bf16x3_ws_kernel<%d,%d,%d>|up1,down1,k%d", KS, WOC, CB, KS);
     const bool plain = GC_WS_BARE && !a.c.bias && !a.c.noise && !a.c.act;
     const int epk = !plain ? 0 : ((a.c.so || a.c.residual) ? 1 : 2);
-    if (epk == 2)      hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 2>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
-    else if (epk == 1) hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 1>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
-    else               hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 0>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    const bool res = a.c.residual != nullptr;
+    if (epk == 2)             hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 2, false>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    else if (epk == 1 && res) hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 1, true>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    else if (epk == 1)        hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 1, false>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    else if (res)             hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 0, true>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
+    else                      hipLaunchKernelGGL((conv_bf16x3_ws_kernel<KS, WOC, CB, 0, false>), dim3((unsigned)gx, ocb), dim3(768), 0, s, a);
     return gc::check_launch("gc_conv2d_bf16x3_f32(ws)");
 }
 

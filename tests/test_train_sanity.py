@@ -40,6 +40,8 @@ def test_training_moves_samples_towards_the_data_in_both_arithmetics():
     assert abs(a - b) <= MODE_GAP * max(a, b), (a, b)        # same data order, seeds and initial weights: the arithmetics end in the same region
 
 
-KEY = 'raw/pixel'
-FALL_AT_SHORT_ITERS = 1.5      # set from profiles/train_sanity_r05.json (see module docstring)
-MODE_GAP = 0.6
+# profiles/train_sanity_r05.json, EMA generator, pixel-space distance: 16.5-23.6 at initialisation, 5.2-9.5 after 500 iterations in all six runs
+# (2.5-4.3 x), f32 and bf16x3 within 7 % of each other at equal seed
+KEY = 'ema/pixel'
+FALL_AT_SHORT_ITERS = 1.8
+MODE_GAP = 0.25

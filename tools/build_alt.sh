@@ -5,7 +5,7 @@
 set -e
 R=$(cd "$(dirname "$0")/.." && pwd)/gan-control_amd/csrc
 name=$1; extra=$2; src=${3:-$R/conv_bf16x3.hip}
-make -C $R -j4 > /dev/null; mkdir -p $R/alt
+mkdir -p $R/alt
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R -I$R/../../include -Wall -Wno-unused-result $extra -c -x hip $src -o $R/build/alt_$name.o 2> /dev/null
 objs=$(ls $R/build/{capi,upfirdn2d,bias_act,conv,weight_layout,pointwise,warp,inception,small_gemm,style,conv_bf16}.o)
 hipcc --offload-arch=gfx950 -shared -fPIC -o $R/alt/libalt_$name.so $R/build/alt_$name.o $objs
