@@ -1312,6 +1312,230 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
+// Wave-specialised weight gradient (round 5; 3 x 3, stride 1, K and N multiples of 64): the role split and the two-deep staging of the
+// stride-1 forward kernel applied to dW.  wgrad_bf16x3_kernel alternates stage -> barrier -> multiply -> barrier with one LDS stage; two
+// co-resident workgroups overlap by luck (1.45 x of one).  Here ONE workgroup of 16 waves owns a CU:
+//  * 12 MULTIPLYING waves = 3 tap rows x (2 x 2) blocks of 32 k x 32 n: wave (ty, wk, wn) holds the three accumulators of taps (ty, 0..2)
+//    -- 48 registers instead of 144 -- and issues nothing but LDS fragment reads, the funnel shifts of the tap columns and MFMAs;
+//  * 4 STAGING waves load, split and write what the NEXT item needs while the loads of the item after next are in flight.
+// The pixel space is walked in STRIPS: a strip is 32 columns x RB consecutive output rows of one sample, an ITEM is one output row of a strip.
+// Item r needs X rows r - 1, r, r + 1 (tap row ty reads row r - 1 + ty) and dY row r: the X rows live in a ring of 6 row slots, so an item
+// inside a strip stages ONE new X row and one dY row (the first item of a strip: three X rows) -- every input row is converted once per strip
+// instead of (TR + 2) / TR times per tile, and the staging waves are idle most of an item.  One barrier per item.
+// Sums are accumulated in a fixed order (strips of a split in order, rows in order, half-rows in order): bit-identical run to run; the order
+// differs from wgrad_bf16x3_kernel's, so the two agree to rounding, not bit for bit.
+#ifndef GC_WG_WS
+#define GC_WG_WS 1
+#endif
+struct WgWsCfg {
+    static constexpr int XR = 6, YR = 2, XU = 5, YU = 4;
+    static constexpr int CSX = (XR * XU) | 1, CSY = (YR * YU) | 1;          // odd unit strides between channels: conflict-free b128 reads
+    static constexpr int XUNITS = 64 * CSX, YUNITS = 64 * CSY;
+    static constexpr int SMEM_UNITS = 2 * (XUNITS + YUNITS);
+    static constexpr int ROW_X = 64 * XU, ROW_Y = 64 * YU;                   // units of one staged X / dY row
+};
+
+__global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb, int bands) {
+    using C = WgWsCfg;
+    constexpr int XR = C::XR, YR = C::YR, XU = C::XU, YU = C::YU, CSX = C::CSX, CSY = C::CSY;
+    constexpr int NXJ = (3 * C::ROW_X + 255) / 256;          // X units per staging lane and item (three rows at the top of a strip): 4, the last partly idle
+    static_assert(C::ROW_Y == 256, "one dY unit per staging lane and item");
+    __shared__ uint4 smem[C::SMEM_UNITS];
+    uint4* xh = smem;
+    uint4* xl = xh + C::XUNITS;
+    uint4* yh = xl + C::XUNITS;
+    uint4* yl = yh + C::YUNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64, split = blockIdx.z;
+
+    // the strips of this split: `sstep` apart (neighbouring splits work on neighbouring column strips of one row band: contiguous rows in DRAM)
+    const int strips_per_sample = p.tiles_x * bands;
+    const int sb = p.spb ? split / p.spb : 0;        // per-sample mode (gc_conv2d_wgrad_samples_*): the splits of one sample walk that sample's strips only
+    const int sstep = p.spb ? p.spb : (int)gridDim.z;
+    const int s_begin = p.spb ? sb * strips_per_sample + (split - sb * p.spb) : split;
+    const int s_end = p.spb ? (sb + 1) * strips_per_sample : strips_per_sample * p.B;
+    const int nstrips = s_begin < s_end ? (s_end - s_begin + sstep - 1) / sstep : 0;
+    const int items = nstrips * rb;
+    const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
+
+    if (wave >= 12) {
+        // ---------------- staging waves ----------------
+        const int st = tid - 768;
+        constexpr unsigned OUTSIDE = 0x80000000u;
+        const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
+        // Which units a lane stages is fixed: X unit u = st + 256 j (j < NXJ) = (row q of the up-to-three new rows, channel, unit column), and ONE dY
+        // unit (channel, unit column).  Everything per unit is recomputed from the lane index where it is used (a few integer instructions): nothing
+        // but the loaded data lives in registers between an item's loads and its conversion.
+        const int ych = st >> 2, yu = st & 3;
+        // an item's position: strip (sample b, first column ox0, first row oy0) and row r of the strip; advanced one item at a time
+        struct Cur { int sidx, b, oy0, ox0, r, ord; };
+        auto place = [&](Cur& c) {
+            c.b = c.sidx / strips_per_sample;
+            const int rem = c.sidx - c.b * strips_per_sample;
+            c.oy0 = (rem / p.tiles_x) * rb;
+            c.ox0 = (rem % p.tiles_x) * 32;
+        };
+        auto advance = [&](Cur& c) {
+            if (++c.r == rb) { c.r = 0; c.sidx += sstep; ++c.ord; place(c); }
+        };
+        auto loads = [&](float4 (&xv)[NXJ][2], float (&xs)[NXJ], float4 (&yv)[2], float& ys, const Cur& c, bool live_item) {
+            const int b = min(c.b, p.B - 1);
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
+            const int oy = c.oy0 + c.r;
+            const int nx = c.r == 0 ? 3 : 1;                     // new X rows of this item: all three at the top of a strip, else the bottom one
+#pragma unroll
+            for (int j = 0; j < NXJ; ++j) {
+                const int u = opaque(st) + 256 * j;
+                const int q = u / C::ROW_X, rem = u - q * C::ROW_X, ch = rem / XU, xu = rem - ch * XU;
+                const int iy = oy - p.pad_y + (nx == 3 ? q : 2);
+                const int lin = ((k0 + ch) * xchan + iy * p.in_w + c.ox0 - p.pad_x) * 4 + xu * 32;
+                // (the unit at channel 0, row 0, column -pad of a sample would start at a negative offset, which the range check rejects as a whole:
+                // it is loaded from offset 0 and shifted by one pixel in convert())
+                const bool ok = live_item && q < nx && (unsigned)iy < (unsigned)p.in_h;
+                const unsigned off = ok ? (unsigned)max(lin, 0) : OUTSIDE;
+                xv[j][0] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 0));
+                xv[j][1] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 16));
+                xs[j] = p.si ? p.si[(size_t)b * p.K + k0 + min(ch, 63)] : 1.f;
+            }
+            const unsigned yoff = live_item ? (unsigned)(((n0 + ych) * ychan + oy * p.out_w + c.ox0) * 4 + yu * 32) : OUTSIDE;
+            yv[0] = __builtin_bit_cast(float4, buf_load_u128(ry, yoff, 0));
+            yv[1] = __builtin_bit_cast(float4, buf_load_u128(ry, yoff, 16));
+            ys = p.so ? p.so[(size_t)b * p.N + n0 + ych] : 1.f;
+        };
+        auto convert = [&](const float4 (&xv)[NXJ][2], const float (&xs)[NXJ], const float4 (&yv)[2], float ys, const Cur& c, int yslot) {
+            const int oy = c.oy0 + c.r;
+            const int nx = c.r == 0 ? 3 : 1;
+            const int xseq = c.ord * (rb + 2) + c.r;                     // sequence number of this item's X row of tap row 0; rows ty = 1, 2 follow
+            const bool scaled = p.si != nullptr || p.so != nullptr;
+            const bool edge = c.ox0 - p.pad_x < 0 || c.ox0 - p.pad_x + 8 * XU > p.in_w || c.ox0 + 8 * YU > p.out_w;      // strip-uniform
+            auto body = [&](auto scaled_t, auto edge_t) {
+                constexpr bool SC = decltype(scaled_t)::value, EDGE = decltype(edge_t)::value;
+#pragma unroll
+                for (int j = 0; j < NXJ; ++j) {
+                    const int u = opaque(st) + 256 * j;
+                    const int q = u / C::ROW_X, rem = u - q * C::ROW_X, ch = rem / XU, xu = rem - ch * XU;
+                    float v[8] = {xv[j][0].x, xv[j][0].y, xv[j][0].z, xv[j][0].w, xv[j][1].x, xv[j][1].y, xv[j][1].z, xv[j][1].w};
+                    if (EDGE) {
+                        const int col0 = c.ox0 - p.pad_x + 8 * xu;
+                        if (col0 < 0 && k0 + ch == 0 && oy - p.pad_y + (nx == 3 ? q : 2) == 0) {
+                            // the unit fetched from offset 0 instead of -pad (see loads): what was loaded is columns 0..7, wanted is -1..6
+#pragma unroll
+                            for (int e = 7; e > 0; --e) v[e] = v[e - 1];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (col0 + e >= 0 && col0 + e < p.in_w) ? v[e] : 0.f;
+                    }
+                    uint4 h, l;
+                    split8<SC>(v, xs[j], &h, &l);
+                    if (q < nx) {
+                        const int slot = (xseq + (nx == 3 ? q : 2)) % XR;
+                        const int o = ch * CSX + slot * XU + xu;
+                        xh[o] = h; GC_LO(xl[o] = l;)
+                    }
+                }
+                {
+                    float v[8] = {yv[0].x, yv[0].y, yv[0].z, yv[0].w, yv[1].x, yv[1].y, yv[1].z, yv[1].w};
+                    if (EDGE) {
+                        const int col0 = c.ox0 + 8 * yu;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = col0 + e < p.out_w ? v[e] : 0.f;
+                    }
+                    uint4 h, l;
+                    split8<SC>(v, ys, &h, &l);
+                    const int o = ych * CSY + yslot * YU + yu;
+                    yh[o] = h; GC_LO(yl[o] = l;)
+                }
+            };
+            if (scaled) { if (edge) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+            else        { if (edge) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+        };
+        // interval t: the multiplying waves work on item t; item t + 1 is converted here (its loads were issued one interval ago), item t + 2 is fetched
+        float4 xva[NXJ][2], xvb[NXJ][2], yva[2], yvb[2];
+        float xsa[NXJ], xsb[NXJ], ysa, ysb;
+        Cur cl{s_begin, 0, 0, 0, 0, 0};                 // cursor of the loads
+        place(cl);
+        Cur cc = cl;                                    // cursor of the conversions
+        loads(xva, xsa, yva, ysa, cl, 0 < items); advance(cl);
+        loads(xvb, xsb, yvb, ysb, cl, 1 < items); advance(cl);
+        if (items > 0) convert(xva, xsa, yva, ysa, cc, 0);
+        advance(cc);
+        __syncthreads();
+        for (int t = 0; t < items; t += 2) {
+            loads(xva, xsa, yva, ysa, cl, t + 2 < items); advance(cl);
+            if (t + 1 < items) convert(xvb, xsb, yvb, ysb, cc, 1);
+            advance(cc);
+            __syncthreads();
+            if (t + 1 >= items) break;
+            loads(xvb, xsb, yvb, ysb, cl, t + 3 < items); advance(cl);
+            if (t + 2 < items) convert(xva, xsa, yva, ysa, cc, 0);
+            advance(cc);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------- multiplying waves ----------------
+    const int ty = wave >> 2, wk = (wave >> 1) & 1, wn = wave & 1;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int xa = (wk * 32 + l31) * CSX + hi, yb_ = (wn * 32 + l31) * CSY + hi;
+    int r = 0, xslot = ty % XR, yslot = 0;           // row of the strip, ring slot of this wave's X row (tap row ty), slot of the dY row
+    __syncthreads();                 // item 0 is staged
+    for (int it = 0; it < items; ++it) {
+        __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
+        // both half-rows' fragments are read before the first MFMA (twelve ds_read_b128, 18 MFMAs)
+        uint4 fbh0, fbh1, fbl0, fbl1, a0h0, a0h1, a1h0, a1h1, a0l0, a0l1, a1l0, a1l1;
+        {
+            const int yo = yb_ + yslot * YU, o = xa + xslot * XU;
+            fbh0 = yh[yo]; fbh1 = yh[yo + 2];
+            a0h0 = xh[o]; a1h0 = xh[o + 1]; a0h1 = xh[o + 2]; a1h1 = xh[o + 3];
+            GC_LO(fbl0 = yl[yo]; fbl1 = yl[yo + 2]; a0l0 = xl[o]; a1l0 = xl[o + 1]; a0l1 = xl[o + 2]; a1l1 = xl[o + 3];)
+        }
+        auto half = [&](const uint4& fbh, const uint4& fbl, const uint4& a0h, const uint4& a1h, const uint4& a0l, const uint4& a1l) {
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&fbh);
+#ifndef GC_SINGLE
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&fbl);
+#endif
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const uint4 uh = shift_px(a0h, a1h, tx);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh);
+#ifndef GC_SINGLE
+                const uint4 ul = shift_px(a0l, a1l, tx);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&ul);
+#endif
+                GC_MFMA3(acc[tx], ah, al, bh, bl);
+            }
+        };
+        half(fbh0, fbl0, a0h0, a1h0, a0l0, a1l0);
+        half(fbh1, fbl1, a0h1, a1h1, a0l1, a1l1);
+        __builtin_amdgcn_s_setprio(0);
+        // next item: one ring slot on inside a strip, three at a strip boundary (the new strip brings three new rows)
+        if (++r == rb) { r = 0; xslot += 3; } else { xslot += 1; }
+        if (xslot >= XR) xslot -= XR;
+        yslot ^= 1;
+        __syncthreads();             // the slots of this item may be rewritten from the next interval on; the next item is staged
+    }
+    float* out = p.ws + (size_t)split * 9 * p.K * p.N;
+    const int n = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int k = k0 + wk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+            out[((size_t)(ty * 3 + tx) * p.K + k) * p.N + n] = acc[tx][rr];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
 // Stride-2 variant (down = 2, pad = 0): dW[tap][k][n] = sum_px X[k][2 px + tap] * dY[n][px] -- the weight gradient
 // of D's 3x3 / 1x1 stride-2 convolutions and (operands swapped) of G's transposed convolutions.  Each input row is
 // staged DE-INTERLEAVED: units of 8 even columns and units of 8 odd columns, so tap tx = 0 reads an even unit,
@@ -2690,6 +2914,25 @@ int wgrad_launch(const gc_conv_desc* d, const float* x, const float* dy, const f
              d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, pl.tiles_x, pl.tiles_y, pl.tiles_per_split, d->in_pitch ? d->in_pitch : d->in_w,
              dw_samples ? pl.splits / d->batch : 0};
     dim3 grid(gc::ceil_div(d->in_ch, pl.kt), gc::ceil_div(d->out_ch, pl.ct), pl.splits);
+#if GC_WG_WS
+    // the wave-specialised kernel: 3 x 3 "same" convolutions with whole 64-channel blocks on both sides; strips of rb rows, at least two per split
+    if (d->down == 1 && d->kh == 3 && !pl.small && d->in_ch % 64 == 0 && d->out_ch % 64 == 0 && d->pad_x == 1 && d->pad_y == 1 && d->out_w >= 32 &&
+        d->out_h == d->in_h && d->out_w == d->in_w) {
+        const int per = dw_samples ? pl.splits / d->batch : pl.splits;                     // splits that share one pool of strips
+        const long long pool = (long long)pl.tiles_x * (dw_samples ? 1 : d->batch);          // ... strips per row band in that pool
+        int rb = 0;
+        for (int cand = 16; cand >= 2; cand >>= 1)
+            if (d->out_h % cand == 0 && pool * (d->out_h / cand) >= 2LL * per) { rb = cand; break; }
+        if (rb) {
+            if (gc::probing()) return gc::probe_name("wgrad_bf16x3_ws_kernel|rb%d", rb);
+            hipLaunchKernelGGL(wgrad_bf16x3_ws_kernel, grid, dim3(1024), 0, s, a, rb, d->out_h / rb);
+            int rc = gc::check_launch(who);
+            if (rc || direct) return rc;
+            if (dw_samples) return launch_wgrad_reduce_samples(static_cast<const float*>(workspace), dw, dw_samples, count, d->batch, pl.splits / d->batch, s);
+            return launch_wgrad_reduce(static_cast<const float*>(workspace), dw, count, pl.splits, s);
+        }
+    }
+#endif
     if (d->down == 2) {
         if (pl.kt == 32) {
             if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 3, 1>), grid, dim3(256), 0, s, a);
