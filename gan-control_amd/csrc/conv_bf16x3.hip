@@ -1325,7 +1325,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
 // Sums are accumulated in a fixed order (strips of a split in order, rows in order, half-rows in order): bit-identical run to run; the order
 // differs from wgrad_bf16x3_kernel's, so the two agree to rounding, not bit for bit.
 #ifndef GC_WG_WS
-#define GC_WG_WS 1
+#define GC_WG_WS 0          // MEASURED AT PARITY with wgrad_bf16x3_kernel, not enabled (round 5, tools/kbench.py, same box, profiles/kernel_ab_r05_{d,e}.log): B = 4
+                            // 277-298 vs 281-299 TF/s, B = 8 315-323 vs 317-333.  Correct (all weight-gradient tests, race screen) and bit-reproducible.  The
+                            // staging waves bound it: the first version (every lane converted four X slots per item, three of them dead inside a strip) ran at
+                            // 216-220 TF/s, lean staging 261-278, staging waves at priority 3 277-298; an item (18 MFMAs per wave between two 16-wave barriers,
+                            // its fragment reads issued by all twelve multiplying waves at the same moment) is too short.  Two-row items would halve the
+                            // barrier / read-burst share but need 56 registers per staging set at a strip start (two sets do not fit 128).
+#endif
+#ifndef GC_WGWS_STAGER_PRIO
+#define GC_WGWS_STAGER_PRIO 3      // the staging waves bound this kernel (kbench, B = 4: 261-278 TF/s at priority 0, 277-298 at 3): they issue first
 #endif
 struct WgWsCfg {
     static constexpr int XR = 6, YR = 2, XU = 5, YU = 4;
@@ -1339,6 +1347,7 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
     using C = WgWsCfg;
     constexpr int XR = C::XR, YR = C::YR, XU = C::XU, YU = C::YU, CSX = C::CSX, CSY = C::CSY;
     constexpr int NXJ = (3 * C::ROW_X + 255) / 256;          // X units per staging lane and item (three rows at the top of a strip): 4, the last partly idle
+    constexpr int NXJ1 = (C::ROW_X + 255) / 256;              // ... inside a strip (one row): 2
     static_assert(C::ROW_Y == 256, "one dY unit per staging lane and item");
     __shared__ uint4 smem[C::SMEM_UNITS];
     uint4* xh = smem;
@@ -1363,6 +1372,7 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
 
     if (wave >= 12) {
         // ---------------- staging waves ----------------
+        if (GC_WGWS_STAGER_PRIO) __builtin_amdgcn_s_setprio(GC_WGWS_STAGER_PRIO);
         const int st = tid - 768;
         constexpr unsigned OUTSIDE = 0x80000000u;
         const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
@@ -1370,6 +1380,16 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
         // unit (channel, unit column).  Everything per unit is recomputed from the lane index where it is used (a few integer instructions): nothing
         // but the loaded data lives in registers between an item's loads and its conversion.
         const int ych = st >> 2, yu = st & 3;
+        // (keeping each slot's channel / unit column / offsets in registers instead of recomputing them from the lane index -- two integer divisions
+        // per unit -- was tried: 128 registers, 4-10 spilled, a scratch reload in front of the staging waves' LDS writes)
+        auto statics = [&](int u, int& meta, int& lo, int& go) {
+            const int q = u / C::ROW_X, rem = u - q * C::ROW_X, ch = rem / XU, xu = rem - ch * XU;
+            meta = q | xu << 4 | ch << 8;
+            lo = ch * CSX + xu;
+            go = ((k0 + ch) * xchan) * 4 + xu * 32;
+        };
+#define GC_WGWS_SLOT(j, meta, lo, go) int meta, lo, go; statics(opaque(st) + 256 * (j), meta, lo, go)
+        const int ygo = ((n0 + ych) * ychan) * 4 + yu * 32, ylo = ych * CSY + yu;
         // an item's position: strip (sample b, first column ox0, first row oy0) and row r of the strip; advanced one item at a time
         struct Cur { int sidx, b, oy0, ox0, r, ord; };
         auto place = [&](Cur& c) {
@@ -1387,21 +1407,23 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
             const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
             const int oy = c.oy0 + c.r;
             const int nx = c.r == 0 ? 3 : 1;                     // new X rows of this item: all three at the top of a strip, else the bottom one
+            const int nj = nx == 3 ? NXJ : NXJ1;                 // unit slots in use (item-uniform): inside a strip one row = 320 units = 1.25 per lane
 #pragma unroll
             for (int j = 0; j < NXJ; ++j) {
-                const int u = opaque(st) + 256 * j;
-                const int q = u / C::ROW_X, rem = u - q * C::ROW_X, ch = rem / XU, xu = rem - ch * XU;
+                if (j >= nj) { xv[j][0] = xv[j][1] = make_float4(0.f, 0.f, 0.f, 0.f); xs[j] = 1.f; continue; }
+                GC_WGWS_SLOT(j, meta, lo_, go);
+                const int q = meta & 15;
                 const int iy = oy - p.pad_y + (nx == 3 ? q : 2);
-                const int lin = ((k0 + ch) * xchan + iy * p.in_w + c.ox0 - p.pad_x) * 4 + xu * 32;
+                const int lin = go + (iy * p.in_w + c.ox0 - p.pad_x) * 4;
                 // (the unit at channel 0, row 0, column -pad of a sample would start at a negative offset, which the range check rejects as a whole:
                 // it is loaded from offset 0 and shifted by one pixel in convert())
                 const bool ok = live_item && q < nx && (unsigned)iy < (unsigned)p.in_h;
                 const unsigned off = ok ? (unsigned)max(lin, 0) : OUTSIDE;
                 xv[j][0] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 0));
                 xv[j][1] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 16));
-                xs[j] = p.si ? p.si[(size_t)b * p.K + k0 + min(ch, 63)] : 1.f;
+                xs[j] = p.si ? p.si[(size_t)b * p.K + k0 + min(meta >> 8, 63)] : 1.f;
             }
-            const unsigned yoff = live_item ? (unsigned)(((n0 + ych) * ychan + oy * p.out_w + c.ox0) * 4 + yu * 32) : OUTSIDE;
+            const unsigned yoff = live_item ? (unsigned)(ygo + (oy * p.out_w + c.ox0) * 4) : OUTSIDE;
             yv[0] = __builtin_bit_cast(float4, buf_load_u128(ry, yoff, 0));
             yv[1] = __builtin_bit_cast(float4, buf_load_u128(ry, yoff, 16));
             ys = p.so ? p.so[(size_t)b * p.N + n0 + ych] : 1.f;
@@ -1412,16 +1434,18 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
             const int xseq = c.ord * (rb + 2) + c.r;                     // sequence number of this item's X row of tap row 0; rows ty = 1, 2 follow
             const bool scaled = p.si != nullptr || p.so != nullptr;
             const bool edge = c.ox0 - p.pad_x < 0 || c.ox0 - p.pad_x + 8 * XU > p.in_w || c.ox0 + 8 * YU > p.out_w;      // strip-uniform
+            const int nj = nx == 3 ? NXJ : NXJ1;
             auto body = [&](auto scaled_t, auto edge_t) {
                 constexpr bool SC = decltype(scaled_t)::value, EDGE = decltype(edge_t)::value;
 #pragma unroll
                 for (int j = 0; j < NXJ; ++j) {
-                    const int u = opaque(st) + 256 * j;
-                    const int q = u / C::ROW_X, rem = u - q * C::ROW_X, ch = rem / XU, xu = rem - ch * XU;
+                    if (j >= nj) continue;                   // item-uniform: a scalar branch
+                    GC_WGWS_SLOT(j, meta, lo_, go);
+                    const int q = meta & 15;
                     float v[8] = {xv[j][0].x, xv[j][0].y, xv[j][0].z, xv[j][0].w, xv[j][1].x, xv[j][1].y, xv[j][1].z, xv[j][1].w};
                     if (EDGE) {
-                        const int col0 = c.ox0 - p.pad_x + 8 * xu;
-                        if (col0 < 0 && k0 + ch == 0 && oy - p.pad_y + (nx == 3 ? q : 2) == 0) {
+                        const int col0 = c.ox0 - p.pad_x + 8 * ((meta >> 4) & 15);
+                        if (col0 < 0 && k0 + (meta >> 8) == 0 && oy - p.pad_y + (nx == 3 ? q : 2) == 0) {
                             // the unit fetched from offset 0 instead of -pad (see loads): what was loaded is columns 0..7, wanted is -1..6
 #pragma unroll
                             for (int e = 7; e > 0; --e) v[e] = v[e - 1];
@@ -1433,7 +1457,7 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
                     split8<SC>(v, xs[j], &h, &l);
                     if (q < nx) {
                         const int slot = (xseq + (nx == 3 ? q : 2)) % XR;
-                        const int o = ch * CSX + slot * XU + xu;
+                        const int o = lo_ + slot * XU;
                         xh[o] = h; GC_LO(xl[o] = l;)
                     }
                 }
@@ -1446,7 +1470,7 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
                     }
                     uint4 h, l;
                     split8<SC>(v, ys, &h, &l);
-                    const int o = ych * CSY + yslot * YU + yu;
+                    const int o = ylo + yslot * YU;
                     yh[o] = h; GC_LO(yl[o] = l;)
                 }
             };
@@ -1494,9 +1518,12 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
         uint4 fbh0, fbh1, fbl0, fbl1, a0h0, a0h1, a1h0, a1h1, a0l0, a0l1, a1l0, a1l1;
         {
             const int yo = yb_ + yslot * YU, o = xa + xslot * XU;
-            fbh0 = yh[yo]; fbh1 = yh[yo + 2];
-            a0h0 = xh[o]; a1h0 = xh[o + 1]; a0h1 = xh[o + 2]; a1h1 = xh[o + 3];
-            GC_LO(fbl0 = yl[yo]; fbl1 = yl[yo + 2]; a0l0 = xl[o]; a1l0 = xl[o + 1]; a0l1 = xl[o + 2]; a1l1 = xl[o + 3];)
+            fbh0 = yh[yo]; a0h0 = xh[o]; a1h0 = xh[o + 1];
+            GC_LO(fbl0 = yl[yo]; a0l0 = xl[o]; a1l0 = xl[o + 1];)
+            __builtin_amdgcn_sched_barrier(0);
+            fbh1 = yh[yo + 2]; a0h1 = xh[o + 2]; a1h1 = xh[o + 3];
+            GC_LO(fbl1 = yl[yo + 2]; a0l1 = xl[o + 2]; a1l1 = xl[o + 3];)
+            __builtin_amdgcn_sched_barrier(0);
         }
         auto half = [&](const uint4& fbh, const uint4& fbl, const uint4& a0h, const uint4& a1h, const uint4& a0l, const uint4& a1l) {
             const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&fbh);
