@@ -95,6 +95,9 @@
 #ifndef GC_FRAG_PIPE
 #define GC_FRAG_PIPE 1      // conv_bf16x3_kernel (up = 1): fragment reads of the next tap issued before the MFMAs of the current one (0: the compiler's order)
 #endif
+#ifndef GC_WS_EARLY_DMA
+#define GC_WS_EARLY_DMA 1   // conv_bf16x3_ws_kernel: weight slabs requested before a finished tile's stores, counted vmcnt, raw barrier (see the multiplying waves' loop)
+#endif
 #ifndef GC_WS_ABL
 #define GC_WS_ABL 0         // dev ablations of conv_bf16x3_ws_kernel (wrong results): 1 no patch staging, 2 no weight DMA, 4 fragments read once, 8 no stores
 #endif
@@ -896,8 +899,18 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     int tile_c = tile_begin, k0_c = 0;
     if (!GC_WS_DMA_STAGER) { weights(0, 0); wait_staged_loads(); }
     __syncthreads();                 // stage 0 is staged
+    // GC_WS_EARLY_DMA (round 5): the weight slab of item it + 2 is requested right AFTER the barrier that ends item it -- its stage is free from
+    // that moment -- and BEFORE the stores of a finished tile, instead of at the top of item it + 1 after them.  vmcnt counts loads and stores in
+    // issue order, so with the request after the stores the `vmcnt(0)` in front of the next barrier also waited for the whole tile's stores to
+    // reach memory -- once per tile, with only one or two items per tile at 32 / 64 input channels to hide it behind.  With the request older than
+    // the stores the wait is counted: `vmcnt(S)`, S = the stores a lane issues per tile (at most 63), lets them stay in flight across the barrier.
+    // The barrier is then the raw instruction (the `__syncthreads()` fence would drain the stores again).
+    constexpr bool EARLY = GC_WS_EARLY_DMA && !GC_WS_DMA_STAGER && !(GC_WS_ABL & 2);
+    constexpr int NSTORES = WOC * WPX * 16 > 63 ? 63 : WOC * WPX * 16;
+    bool stored = false;             // the previous item ended a tile: its stores were issued after the newest weight request
+    if (EARLY) weights(KCB < p.K ? KCB : 0, 1);                       // item 1
     for (int it = 0; it < items; ++it) {
-        if (!(GC_WS_ABL & 2) && !GC_WS_DMA_STAGER) weights(k0_c + KCB < p.K ? k0_c + KCB : 0, (it + 1) & 1);          // after the last item: a valid slab into a stage nobody reads
+        if (!EARLY && !(GC_WS_ABL & 2) && !GC_WS_DMA_STAGER) weights(k0_c + KCB < p.K ? k0_c + KCB : 0, (it + 1) & 1);          // after the last item: a valid slab into a stage nobody reads
         const uint4* const wl_h = smem + (it & 1) * STAGE;
         const uint4* const wl_l = wl_h + C::WUNITS;
         const uint4* const p_h = wl_l + C::WUNITS;
@@ -956,10 +969,22 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
+        if (EARLY) {
+            // the rows of item it + 1 were requested one item ago, before any store still in flight
+            if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTORES) : "memory");
+            else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS reads have returned
+            __builtin_amdgcn_s_barrier();
+            // item it + 2 goes into the stage item it has just left: (it + 2) chunks on from the start, modulo the chunks of a tile
+            const int k2 = k0_c + 2 * KCB;
+            weights(k2 < p.K ? k2 : (k2 - p.K < p.K ? k2 - p.K : 0), it & 1);
+            stored = false;
+        } else {
         if (!GC_WS_DMA_STAGER) wait_staged_loads();         // the LDS-DMA rows of this wave have landed (they were issued a whole MFMA phase ago)
         __syncthreads();             // this stage may be rewritten from the next item on; the other one is staged
+        }
         k0_c += KCB;
-        if (k0_c >= p.K) { finish_tile(tile_c); k0_c = 0; tile_c += tstep; }
+        if (k0_c >= p.K) { finish_tile(tile_c); k0_c = 0; tile_c += tstep; stored = true; }
     }
 }
 
