@@ -1356,6 +1356,15 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
                             // 216-220 TF/s, lean staging 261-278, staging waves at priority 3 277-298; an item (18 MFMAs per wave between two 16-wave barriers,
                             // its fragment reads issued by all twelve multiplying waves at the same moment) is too short.  Two-row items would halve the
                             // barrier / read-burst share but need 56 registers per staging set at a strip start (two sets do not fit 128).
+                            // Ablations (GC_WGWS_ABL, profiles/kernel_ab_r05_h.log, B = 4, 128 -> 128 @256^2): complete 264 us; the multiplying waves ALONE
+                            // (staging waves keep only the barriers) 145 us = 534 TF/s; the staging waves alone (no MFMAs, no fragment reads) 60 us; staging
+                            // + fragment reads without MFMAs 233 us.  The two sides do not overlap -- together they cost more than their sum -- which is the
+                            // thing to understand (PMC: SQ wait / issue counters per role) before this kernel is worth enabling: its matrix side is the
+                            // fastest in the library.
+#endif
+#ifndef GC_WGWS_ABL
+#define GC_WGWS_ABL 0       // dev ablations of wgrad_bf16x3_ws_kernel (wrong results): 1 the staging waves only keep the barriers, 2 the multiplying waves issue no MFMAs,
+                            // 4 ... and no fragment reads either
 #endif
 #ifndef GC_WGWS_STAGER_PRIO
 #define GC_WGWS_STAGER_PRIO 3      // the staging waves bound this kernel (kbench, B = 4: 261-278 TF/s at priority 0, 277-298 at 3): they issue first
@@ -1508,6 +1517,11 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
         Cur cl{s_begin, 0, 0, 0, 0, 0};                 // cursor of the loads
         place(cl);
         Cur cc = cl;                                    // cursor of the conversions
+        if (GC_WGWS_ABL & 1) {
+            __syncthreads();
+            for (int t = 0; t < items; ++t) __syncthreads();
+            return;
+        }
         loads(xva, xsa, yva, ysa, cl, 0 < items); advance(cl);
         loads(xvb, xsb, yvb, ysb, cl, 1 < items); advance(cl);
         if (items > 0) convert(xva, xsa, yva, ysa, cc, 0);
@@ -1541,7 +1555,7 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
         __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
         // both half-rows' fragments are read before the first MFMA (twelve ds_read_b128, 18 MFMAs)
         uint4 fbh0, fbh1, fbl0, fbl1, a0h0, a0h1, a1h0, a1h1, a0l0, a0l1, a1l0, a1l1;
-        {
+        if (!(GC_WGWS_ABL & 4)) {
             const int yo = yb_ + yslot * YU, o = xa + xslot * XU;
             fbh0 = yh[yo]; a0h0 = xh[o]; a1h0 = xh[o + 1];
             GC_LO(fbl0 = yl[yo]; a0l0 = xl[o]; a1l0 = xl[o + 1];)
@@ -1566,8 +1580,12 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
                 GC_MFMA3(acc[tx], ah, al, bh, bl);
             }
         };
+        if (!(GC_WGWS_ABL & 2)) {
         half(fbh0, fbl0, a0h0, a1h0, a0l0, a1l0);
         half(fbh1, fbl1, a0h1, a1h1, a0l1, a1l1);
+        } else if (!(GC_WGWS_ABL & 4)) {
+            acc[0][0] += __builtin_bit_cast(float, fbh0.x ^ fbh1.x ^ a0h0.x ^ a1h0.x ^ a0h1.x ^ a1h1.x GC_LO(^ fbl0.x ^ fbl1.x ^ a0l0.x ^ a1l0.x ^ a0l1.x ^ a1l1.x));
+        }
         __builtin_amdgcn_s_setprio(0);
         // next item: one ring slot on inside a strip, three at a strip boundary (the new strip brings three new rows)
         if (++r == rb) { r = 0; xslot += 3; } else { xslot += 1; }
