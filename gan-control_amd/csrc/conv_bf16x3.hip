@@ -1360,7 +1360,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
                             // (staging waves keep only the barriers) 145 us = 534 TF/s; the staging waves alone (no MFMAs, no fragment reads) 60 us; staging
                             // + fragment reads without MFMAs 233 us.  The two sides do not overlap -- together they cost more than their sum -- which is the
                             // thing to understand (PMC: SQ wait / issue counters per role) before this kernel is worth enabling: its matrix side is the
-                            // fastest in the library.
+                            // fastest in the library.  It is NOT the staging waves' instruction count: a version with the three always-used slots static per
+                            // lane (six registers, no integer divisions) and the strip-start rows fetched on the spot ran no faster at >= 128 channels and
+                            // 16 % slower at 64 (the on-the-spot fetch stalls once per strip): profiles/kernel_ab_r05_i.log.
 #endif
 #ifndef GC_WGWS_ABL
 #define GC_WGWS_ABL 0       // dev ablations of wgrad_bf16x3_ws_kernel (wrong results): 1 the staging waves only keep the barriers, 2 the multiplying waves issue no MFMAs,
