@@ -1350,7 +1350,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_bf16x3_kernel(WgArgs p) {
 // Sums are accumulated in a fixed order (strips of a split in order, rows in order, half-rows in order): bit-identical run to run; the order
 // differs from wgrad_bf16x3_kernel's, so the two agree to rounding, not bit for bit.
 #ifndef GC_WG_WS
-#define GC_WG_WS 0          // MEASURED AT PARITY with wgrad_bf16x3_kernel, not enabled (round 5, tools/kbench.py, same box, profiles/kernel_ab_r05_{d,e}.log): B = 4
+#define GC_WG_WS 2          // 2: wgrad_bf16x3_ws2_kernel (two-row items, stream staging: +5..8 % over the one-role kernel, below); 0: one-role kernel only;
+                            // 1: the first, one-row form -- MEASURED AT PARITY with wgrad_bf16x3_kernel, not enabled (round 5, tools/kbench.py, same box, profiles/kernel_ab_r05_{d,e}.log): B = 4
                             // 277-298 vs 281-299 TF/s, B = 8 315-323 vs 317-333.  Correct (all weight-gradient tests, race screen) and bit-reproducible.  The
                             // staging waves bound it: the first version (every lane converted four X slots per item, three of them dead inside a strip) ran at
                             // 216-220 TF/s, lean staging 261-278, staging waves at priority 3 277-298; an item (18 MFMAs per wave between two 16-wave barriers,
@@ -1594,6 +1595,261 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws_kernel(WgArgs p, int rb,
         if (xslot >= XR) xslot -= XR;
         yslot ^= 1;
         __syncthreads();             // the slots of this item may be rewritten from the next interval on; the next item is staged
+    }
+    float* out = p.ws + (size_t)split * 9 * p.K * p.N;
+    const int n = n0 + wn * 32 + l31;
+#pragma unroll
+    for (int tx = 0; tx < 3; ++tx) {
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int k = k0 + wk * 32 + (rr & 3) + 8 * (rr >> 2) + 4 * hi;
+            out[((size_t)(ty * 3 + tx) * p.K + k) * p.N + n] = acc[tx][rr];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Second form of the wave-specialised weight gradient (GC_WG_WS = 2): TWO output rows per item and the input rows staged as a stream.
+// The one-row form's ablations (profiles/kernel_ab_r05_{h,j}.log) say its matrix side alone runs at ~530 TF/s and that the staging waves' path --
+// load latency, conversion, LDS write -- is what an item waits for: an item was 18 MFMAs per wave, ~0.7 us, and its loads were requested two
+// items = ~1.5 us ahead.  Here an item is 36 MFMAs per wave (half the barriers), the loads of an item are requested two items = ~3 us ahead, and
+// every staging step is exactly five unit slots per lane:
+//   * X rows 2i + 2, 2i + 3 of the strip (the two new rows of item i: 640 units = 2.5 slots), dY rows 2i, 2i + 1 (512 units = 2 slots);
+//   * the idle half of the third X slot carries 128 units of the NEXT strip's first two input rows (its top halo: 640 units over the steps of
+//     items 2..6), so a strip boundary costs no extra step: those two rows live in two dedicated row slots (6, 7), the other rows of all strips
+//     form one running sequence through a ring of six.
+// Strips are 16 rows (out_h a multiple of 16).  Same partial-sum layout and reduce pass as the other weight-gradient kernels.
+struct WgWs2Cfg {
+    static constexpr int XRING = 6, XR = 8, YR = 4, XU = 5, YU = 4, RB = 16;
+    static constexpr int CSX = (XR * XU) | 1, CSY = (YR * YU) | 1;
+    static constexpr int XUNITS = 64 * CSX, YUNITS = 64 * CSY;
+    static constexpr int SMEM_UNITS = 2 * (XUNITS + YUNITS);
+    static constexpr int ROW_X = 64 * XU, ROW_Y = 64 * YU;
+};
+
+__global__ __launch_bounds__(1024) void wgrad_bf16x3_ws2_kernel(WgArgs p, int bands) {
+    using C = WgWs2Cfg;
+    constexpr int XRING = C::XRING, YR = C::YR, XU = C::XU, YU = C::YU, CSX = C::CSX, CSY = C::CSY, RB = C::RB, IPS = RB / 2;
+    __shared__ uint4 smem[C::SMEM_UNITS];
+    uint4* xh = smem;
+    uint4* xl = xh + C::XUNITS;
+    uint4* yh = xl + C::XUNITS;
+    uint4* yl = yh + C::YUNITS;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int k0 = blockIdx.x * 64, n0 = blockIdx.y * 64, split = blockIdx.z;
+
+    const int strips_per_sample = p.tiles_x * bands;
+    const int sb = p.spb ? split / p.spb : 0;
+    const int sstep = p.spb ? p.spb : (int)gridDim.z;
+    const int s_begin = p.spb ? sb * strips_per_sample + (split - sb * p.spb) : split;
+    const int s_end = p.spb ? (sb + 1) * strips_per_sample : strips_per_sample * p.B;
+    const int nstrips = s_begin < s_end ? (s_end - s_begin + sstep - 1) / sstep : 0;
+    const int items = nstrips * IPS;
+    const int xchan = p.in_h * p.in_w, ychan = p.out_h * p.out_w;
+
+    // row slot of input row xr (0 .. RB + 1) of the strip with ordinal `ord`: the two top rows in the dedicated slots, the rest in the running ring
+    auto xslot_of = [&](int ord, int xr) { return xr < 2 ? XRING + xr : (ord * RB + xr - 2) % XRING; };
+
+    if (wave >= 12) {
+        // ---------------- staging waves ----------------
+        if (GC_WGWS_STAGER_PRIO) __builtin_amdgcn_s_setprio(GC_WGWS_STAGER_PRIO);
+        const int st = tid - 768;
+        constexpr unsigned OUTSIDE = 0x80000000u;
+        const unsigned xbytes = (unsigned)p.K * xchan * 4u, ybytes = (unsigned)p.N * ychan * 4u;
+        struct Strip { int sidx, b, oy0, ox0, ord; };
+        auto place = [&](Strip& c) {
+            c.b = c.sidx / strips_per_sample;
+            const int rem = c.sidx - c.b * strips_per_sample;
+            c.oy0 = (rem / p.tiles_x) * RB;
+            c.ox0 = (rem % p.tiles_x) * 32;
+        };
+        // One X unit of (strip c, input row xr): u in [0, 320) = (channel, unit column)
+        auto x_load = [&](float4 (&v)[2], float& sc, const Strip& c, int xr, int u, bool live) {
+            const int ch = min(u / XU, 63), xu = u - (u / XU) * XU;
+            const int b = min(c.b, p.B - 1);
+            const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.x + (size_t)b * p.K * xchan, xbytes);
+            const int iy = c.oy0 + xr - p.pad_y;
+            // (the unit at channel 0, row 0, column -pad of a sample would start at a negative offset, which the range check rejects as a whole:
+            // it is loaded from offset 0 and shifted by one pixel when it is converted)
+            const int lin = ((k0 + ch) * xchan + iy * p.in_w + c.ox0 - p.pad_x) * 4 + xu * 32;
+            const unsigned off = (live && (unsigned)iy < (unsigned)p.in_h && c.b < p.B) ? (unsigned)max(lin, 0) : OUTSIDE;
+            v[0] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 0));
+            v[1] = __builtin_bit_cast(float4, buf_load_u128(rx, off, 16));
+            sc = p.si ? p.si[(size_t)b * p.K + k0 + ch] : 1.f;
+        };
+        auto x_store = [&](auto scaled_t, auto edge_t, const float4 (&r2)[2], float sc, const Strip& c, int xr, int u, bool live) {
+            const int ch = min(u / XU, 63), xu = u - (u / XU) * XU;
+            float v[8] = {r2[0].x, r2[0].y, r2[0].z, r2[0].w, r2[1].x, r2[1].y, r2[1].z, r2[1].w};
+            if (decltype(edge_t)::value) {
+                const int col0 = c.ox0 - p.pad_x + 8 * xu;
+                if (col0 < 0 && k0 + ch == 0 && c.oy0 + xr - p.pad_y == 0) {
+#pragma unroll
+                    for (int e = 7; e > 0; --e) v[e] = v[e - 1];
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (col0 + e >= 0 && col0 + e < p.in_w) ? v[e] : 0.f;
+            }
+            uint4 h, l;
+            split8<decltype(scaled_t)::value>(v, sc, &h, &l);
+            if (live) { const int o = ch * CSX + xslot_of(c.ord, xr) * XU + xu; xh[o] = h; GC_LO(xl[o] = l;) }
+        };
+        auto y_load = [&](float4 (&v)[2], float& sc, const Strip& c, int r, bool live) {
+            const int ych = st >> 2, yu = st & 3;
+            const int b = min(c.b, p.B - 1);
+            const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.dy + (size_t)b * p.N * ychan, ybytes);
+            const unsigned off = (live && c.b < p.B) ? (unsigned)(((n0 + ych) * ychan + (c.oy0 + r) * p.out_w + c.ox0) * 4 + yu * 32) : OUTSIDE;
+            v[0] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 0));
+            v[1] = __builtin_bit_cast(float4, buf_load_u128(ry, off, 16));
+            sc = p.so ? p.so[(size_t)b * p.N + n0 + ych] : 1.f;
+        };
+        auto y_store = [&](auto scaled_t, auto edge_t, const float4 (&r2)[2], float sc, const Strip& c, int r) {
+            const int ych = st >> 2, yu = st & 3;
+            float v[8] = {r2[0].x, r2[0].y, r2[0].z, r2[0].w, r2[1].x, r2[1].y, r2[1].z, r2[1].w};
+            if (decltype(edge_t)::value) {
+                const int col0 = c.ox0 + 8 * yu;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = col0 + e < p.out_w ? v[e] : 0.f;
+            }
+            uint4 h, l;
+            split8<decltype(scaled_t)::value>(v, sc, &h, &l);
+            const int o = ych * CSY + ((c.ord * RB + r) % YR) * YU + yu;
+            yh[o] = h; GC_LO(yl[o] = l;)
+        };
+        // A step = what item i of strip c needs that is not staged yet + (steps 2..6) a fifth of the next strip's top rows.
+        // Slots: 0, 1 = X units st, st + 256 of the 640 (rows 2i + 2, 2i + 3); 2 = X unit st + 512 for st < 128, else unit (i - 2) * 128 + st - 128 of
+        // the next strip's rows 0, 1; 3, 4 = dY rows 2i, 2i + 1.
+        struct Step { Strip c, n; int i; bool live; };       // strip, the strip after it, item
+        auto step_loads = [&](float4 (&v)[5][2], float (&sc)[5], const Step& s) {
+            const int u0 = opaque(st), u1 = opaque(st) + 256, u2 = opaque(st) + 512;
+            x_load(v[0], sc[0], s.c, 2 * s.i + 2, u0, s.live);                       // u0 < 320: row 2i + 2
+            x_load(v[1], sc[1], s.c, 2 * s.i + 2 + (u1 >= C::ROW_X ? 1 : 0), u1 >= C::ROW_X ? u1 - C::ROW_X : u1, s.live);
+            if (st < 128) {
+                x_load(v[2], sc[2], s.c, 2 * s.i + 3, u2 - C::ROW_X, s.live);
+            } else {
+                const int hu = (s.i - 2) * 128 + st - 128;                           // unit of the next strip's top rows, [0, 640)
+                x_load(v[2], sc[2], s.n, hu >= C::ROW_X ? 1 : 0, hu >= C::ROW_X ? hu - C::ROW_X : hu, s.live && s.i >= 2 && s.i <= 6);
+            }
+            y_load(v[3], sc[3], s.c, 2 * s.i, s.live);
+            y_load(v[4], sc[4], s.c, 2 * s.i + 1, s.live);
+        };
+        auto step_stores = [&](const float4 (&v)[5][2], const float (&sc)[5], const Step& s) {
+            if (!s.live) return;
+            const bool scaled = p.si != nullptr || p.so != nullptr;
+            auto is_edge = [&](const Strip& c) { return c.ox0 - p.pad_x < 0 || c.ox0 - p.pad_x + 8 * XU > p.in_w || c.ox0 + 8 * YU > p.out_w; };
+            const bool edge = is_edge(s.c) || is_edge(s.n);
+            auto body = [&](auto scaled_t, auto edge_t) {
+                const int u0 = opaque(st), u1 = opaque(st) + 256, u2 = opaque(st) + 512;
+                x_store(scaled_t, edge_t, v[0], sc[0], s.c, 2 * s.i + 2, u0, true);
+                x_store(scaled_t, edge_t, v[1], sc[1], s.c, 2 * s.i + 2 + (u1 >= C::ROW_X ? 1 : 0), u1 >= C::ROW_X ? u1 - C::ROW_X : u1, true);
+                if (st < 128) {
+                    x_store(scaled_t, edge_t, v[2], sc[2], s.c, 2 * s.i + 3, u2 - C::ROW_X, true);
+                } else {
+                    const int hu = (s.i - 2) * 128 + st - 128;
+                    x_store(scaled_t, edge_t, v[2], sc[2], s.n, hu >= C::ROW_X ? 1 : 0, hu >= C::ROW_X ? hu - C::ROW_X : hu, s.i >= 2 && s.i <= 6 && s.n.b < p.B);
+                }
+                y_store(scaled_t, edge_t, v[3], sc[3], s.c, 2 * s.i);
+                y_store(scaled_t, edge_t, v[4], sc[4], s.c, 2 * s.i + 1);
+            };
+            if (scaled) { if (edge) body(std::true_type{}, std::true_type{}); else body(std::true_type{}, std::false_type{}); }
+            else        { if (edge) body(std::false_type{}, std::true_type{}); else body(std::false_type{}, std::false_type{}); }
+        };
+        auto next_step = [&](Step& s, int t) {           // the step after s, which is item t overall
+            if (++s.i == IPS) {
+                s.i = 0;
+                s.c = s.n;
+                s.n.sidx += sstep; ++s.n.ord; place(s.n);
+                if (s.n.sidx >= s_end) s.n.b = p.B;      // no strip after the last one: its loads read as zeros, nothing of it is stored
+            }
+            s.live = t < items;
+        };
+        Step sl;                                        // cursor of the loads
+        sl.c = Strip{s_begin, 0, 0, 0, 0}; place(sl.c);
+        sl.n = Strip{s_begin + sstep, 0, 0, 0, 1}; place(sl.n);
+        if (sl.n.sidx >= s_end) sl.n.b = p.B;
+        sl.i = 0; sl.live = items > 0;
+        Step sc_ = sl;                                  // cursor of the conversions
+        float4 va[5][2], vb[5][2];
+        float sa[5], sb5[5];
+        // prologue: the first strip's top rows (nobody staged them ahead): three slots, on the spot
+        if (items > 0) {
+            const bool scaled = p.si != nullptr || p.so != nullptr;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int u = opaque(st) + 256 * j;
+                x_load(va[j], sa[j], sl.c, u >= C::ROW_X ? 1 : 0, u >= C::ROW_X ? u - C::ROW_X : u, u < 2 * C::ROW_X);
+            }
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int u = opaque(st) + 256 * j;
+                if (scaled) x_store(std::true_type{}, std::true_type{}, va[j], sa[j], sl.c, u >= C::ROW_X ? 1 : 0, u >= C::ROW_X ? u - C::ROW_X : u, u < 2 * C::ROW_X);
+                else        x_store(std::false_type{}, std::true_type{}, va[j], sa[j], sl.c, u >= C::ROW_X ? 1 : 0, u >= C::ROW_X ? u - C::ROW_X : u, u < 2 * C::ROW_X);
+            }
+        }
+        // interval t: the multiplying waves work on item t; item t + 1 is converted here (its loads were issued one interval ago), item t + 2 is fetched
+        step_loads(va, sa, sl); next_step(sl, 1);
+        step_loads(vb, sb5, sl); next_step(sl, 2);
+        step_stores(va, sa, sc_); next_step(sc_, 1);
+        __syncthreads();
+        for (int t = 0; t < items; t += 2) {
+            step_loads(va, sa, sl); next_step(sl, t + 3);
+            step_stores(vb, sb5, sc_); next_step(sc_, t + 2);
+            __syncthreads();
+            if (t + 1 >= items) break;
+            step_loads(vb, sb5, sl); next_step(sl, t + 4);
+            step_stores(va, sa, sc_); next_step(sc_, t + 3);
+            __syncthreads();
+        }
+        return;
+    }
+
+    // ---------------- multiplying waves ----------------
+    const int ty = wave >> 2, wk = (wave >> 1) & 1, wn = wave & 1;
+    f32x16 acc[3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+    const int xa = (wk * 32 + l31) * CSX + hi, yb_ = (wn * 32 + l31) * CSY + hi;
+    int i = 0, ord = 0;
+    __syncthreads();                 // item 0 is staged
+    for (int it = 0; it < items; ++it) {
+        __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
+        // four quarter-steps (row, half-row): the fragments of the next one are read before the MFMAs of the current one
+        uint4 fbh[2], fbl[2], a0h[2], a1h[2], a0l[2], a1l[2];
+        auto read_q = [&](int q, int set) {
+            const int row = q >> 1, half = q & 1;
+            const int yo = yb_ + ((ord * RB + 2 * i + row) % YR) * YU + 2 * half;
+            const int o = xa + xslot_of(ord, 2 * i + row + ty) * XU + 2 * half;
+            fbh[set] = yh[yo]; a0h[set] = xh[o]; a1h[set] = xh[o + 1];
+            GC_LO(fbl[set] = yl[yo]; a0l[set] = xl[o]; a1l[set] = xl[o + 1];)
+        };
+        read_q(0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (q + 1 < 4) read_q(q + 1, (q + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 bh = *reinterpret_cast<const bf16x8*>(&fbh[q & 1]);
+#ifndef GC_SINGLE
+            const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&fbl[q & 1]);
+#endif
+#pragma unroll
+            for (int tx = 0; tx < 3; ++tx) {
+                const uint4 uh = shift_px(a0h[q & 1], a1h[q & 1], tx);
+                const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&uh);
+#ifndef GC_SINGLE
+                const uint4 ul = shift_px(a0l[q & 1], a1l[q & 1], tx);
+                const bf16x8 al = *reinterpret_cast<const bf16x8*>(&ul);
+#endif
+                GC_MFMA3(acc[tx], ah, al, bh, bl);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (++i == IPS) { i = 0; ++ord; }
+        __syncthreads();             // the rows of this item may be rewritten from the next interval on; the next item is staged
     }
     float* out = p.ws + (size_t)split * 9 * p.K * p.N;
     const int n = n0 + wn * 32 + l31;
@@ -2995,9 +3251,11 @@ int wgrad_launch(const gc_conv_desc* d, const float* x, const float* dy, const f
         int rb = 0;
         for (int cand = 16; cand >= 2; cand >>= 1)
             if (d->out_h % cand == 0 && pool * (d->out_h / cand) >= 2LL * per) { rb = cand; break; }
+        if (GC_WG_WS == 2) rb = (d->out_h % 16 == 0 && pool * (d->out_h / 16) >= 2LL * per) ? 16 : 0;
         if (rb) {
             if (gc::probing()) return gc::probe_name("wgrad_bf16x3_ws_kernel|rb%d", rb);
-            hipLaunchKernelGGL(wgrad_bf16x3_ws_kernel, grid, dim3(1024), 0, s, a, rb, d->out_h / rb);
+            if (GC_WG_WS == 2) hipLaunchKernelGGL(wgrad_bf16x3_ws2_kernel, grid, dim3(1024), 0, s, a, d->out_h / rb);
+            else hipLaunchKernelGGL(wgrad_bf16x3_ws_kernel, grid, dim3(1024), 0, s, a, rb, d->out_h / rb);
             int rc = gc::check_launch(who);
             if (rc || direct) return rc;
             if (dw_samples) return launch_wgrad_reduce_samples(static_cast<const float*>(workspace), dw, dw_samples, count, d->batch, pl.splits / d->batch, s);
