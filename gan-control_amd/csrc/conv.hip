@@ -717,19 +717,24 @@ WgradPlan plan_wgrad(const gc_conv_desc* d) {
 // waves take (32 pixels x 32 output channels) work items; each workgroup writes raw partial sums of its channels to part[slice], and
 // splitk_finish_kernel adds the slices in fixed order and applies out_scale + the fused epilogue.
 // conv_mfma_kernel with its split over K took 27 .. 65 us on these shapes (92 without a workspace); this one 10 .. 30 us.
-struct SmallArgs { ConvArgs c; float* part; long long per_slice; int pixels; };
+struct SmallArgs { ConvArgs c; float* part; long long per_slice; int bgroup; };     // bgroup: samples per workgroup (blockIdx.z walks the groups)
 constexpr int SMALL_THREADS = 512;       // eight waves: two per SIMD hide the staging latency
 constexpr int SMALL_KC = 16;             // input channels per chunk
 
-template <int KS, int WOC, int NCH, int DOWN>
+// UP = 2 (round 5: the 4^2 -> 9^2 transposed convolutions -- G's first up-sampling layer, the input gradient of D's 9 -> 4 convolution -- ran on
+// conv_mfma_kernel at 65 / 113 us for B = 4 / 8): the staged plane is the ZERO-STUFFED input with its halo, (out + KS - 1)^2 positions, and the
+// product loop is the stride-1 one; three quarters of its MFMAs multiply zeros, which costs nothing where the launch is bound by latency.
+template <int KS, int WOC, int NCH, int DOWN, int UP = 1>
 __global__ __launch_bounds__(SMALL_THREADS) void conv_f32_small_kernel(SmallArgs a) {
     constexpr int NTAP = KS * KS, OCT = 32 * WOC, NW = SMALL_THREADS / 64, KC = SMALL_KC;
     constexpr int WFLOATS = NCH * NTAP * KC * OCT;               // [chunk][tap][k][oc]
+    static_assert(UP == 1 || DOWN == 1, "up and down are exclusive");
     extern __shared__ float small_smem[];
     const ConvArgs& p = a.c;
     const int halo = p.pad_y;                                    // = pad_x: KS / 2 at stride 1, 0 at stride 2
-    const int ph = p.in_h + 2 * halo, pw = p.in_w + 2 * halo, plane = ph * pw;      // zero-haloed plane of one sample
-    const int per_k = p.B * plane + 1;                           // + one zero for the lanes past the last pixel
+    const int ph = UP == 2 ? p.out_h + KS - 1 : p.in_h + 2 * halo, pw = UP == 2 ? p.out_w + KS - 1 : p.in_w + 2 * halo, plane = ph * pw;      // zero-haloed (UP = 2: zero-stuffed) plane of one sample
+    const int b0 = blockIdx.z * a.bgroup, nb = min(a.bgroup, p.B - b0);       // this workgroup's samples
+    const int per_k = nb * plane + 1;                            // + one zero for the lanes past the last pixel
     float* wl = small_smem;
     float* pl = wl + WFLOATS;                                    // [chunk * 16 + k][sample][ph][pw] (+ zero)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
@@ -749,14 +754,16 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_f32_small_kernel(SmallArgs
     }
     // patch: every sample's plane with a zero halo, times in_scale.  One item = one position of the haloed planes x 8 channels (one
     // decode of the position, eight loads in flight, eight conflict-free LDS stores: consecutive lanes hold consecutive positions)
-    const int chan = p.in_h * p.in_w, npos = p.B * plane, nitems = npos * (NCH * KC / 8);
+    const int chan = p.in_h * p.in_w, npos = nb * plane, nitems = npos * (NCH * KC / 8);
     for (int it = tid; it < nitems; it += SMALL_THREADS) {
         const int kg = it / npos, pos = it - kg * npos;
         const int b = pos / plane, q0 = pos - b * plane, yy = q0 / pw - halo, xx = q0 % pw - halo;
-        const bool inside = yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w;
+        const bool inside = UP == 2 ? (yy >= 0 && xx >= 0 && ((yy | xx) & 1) == 0 && (yy >> 1) < p.in_h && (xx >> 1) < p.in_w)
+                                    : (yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w);
         const int kb = k0 + kg * 8;
-        const float* src = p.x + (inside ? (size_t)b * p.K * chan + yy * p.in_w + xx : (size_t)0);
-        const float* ssrc = p.si + (size_t)b * p.K;
+        const int at = UP == 2 ? (yy >> 1) * p.in_w + (xx >> 1) : yy * p.in_w + xx;
+        const float* src = p.x + (inside ? (size_t)(b0 + b) * p.K * chan + at : (size_t)0);
+        const float* ssrc = p.si + (size_t)(b0 + b) * p.K;
         float v[8], sc[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
@@ -775,17 +782,17 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_f32_small_kernel(SmallArgs
     }
     __syncthreads();
     // one work item = 32 pixels x 32 output channels; the waves take them round-robin
-    const int items = (a.pixels + 31) / 32 * WOC;
-    float* out = a.part + (size_t)blockIdx.x * a.per_slice;
-    const int oplane = p.out_h * p.out_w;
+    const int oplane = p.out_h * p.out_w, pixels = nb * oplane;
+    const int items = (pixels + 31) / 32 * WOC;
+    float* out = a.part + (size_t)blockIdx.x * a.per_slice + (size_t)b0 * p.N * oplane;
     for (int item = wave; item < items; item += NW) {
         const int cb = item / WOC, i = item % WOC;
         const int pix = cb * 32 + l31;
-        const bool live = pix < a.pixels;
+        const bool live = pix < pixels;
         const int b = live ? pix / oplane : 0, o = live ? pix - b * oplane : 0;
         const int oy = o / p.out_w, ox = o - oy * p.out_w;
         // this lane's pixel under tap (0, 0); the lanes past the last pixel read the zero at the end of their channel's row
-        const int base = hi * per_k + (live ? b * plane + oy * DOWN * pw + ox * DOWN : p.B * plane);
+        const int base = hi * per_k + (live ? b * plane + oy * DOWN * pw + ox * DOWN : nb * plane);
         const int wbase = hi * OCT + i * 32 + l31;
         f32x16 acc;
 #pragma unroll
@@ -811,35 +818,55 @@ __global__ __launch_bounds__(SMALL_THREADS) void conv_f32_small_kernel(SmallArgs
     }
 }
 
-// LDS of the small-plane kernel with `nch` channel chunks per workgroup: the weight slab + the zero-haloed planes of every sample
-inline size_t small_lds_bytes(const gc_conv_desc* d, int nch) {
-    const size_t plane = (size_t)(d->in_h + 2 * d->pad_y) * (d->in_w + 2 * d->pad_x);
-    return ((size_t)d->kh * d->kw * SMALL_KC * 64 + (size_t)nch * SMALL_KC * ((size_t)d->batch * plane + 1)) * sizeof(float);
+// LDS of the small-plane kernel with `nch` channel chunks per workgroup and `bg` samples: the weight slab + the zero-haloed planes of those samples
+inline size_t small_plane(const gc_conv_desc* d) {
+    if (d->up == 2) return (size_t)(d->out_h + d->kh - 1) * (d->out_w + d->kw - 1);
+    return (size_t)(d->in_h + 2 * d->pad_y) * (d->in_w + 2 * d->pad_x);
+}
+inline size_t small_lds_bytes(const gc_conv_desc* d, int nch, int bg) {
+    return ((size_t)d->kh * d->kw * SMALL_KC * 64 + (size_t)nch * SMALL_KC * ((size_t)bg * small_plane(d) + 1)) * sizeof(float);
 }
 // what one workgroup may use: the device's per-block limit (160 KiB on gfx950; a part with less sends these shapes to conv_mfma_kernel's split over K)
 inline size_t small_lds_max() { return std::min<size_t>(160 * 1024, gc::device_lds_limit()); }
+constexpr int SMALL_MAX_PIXELS = 512;    // output pixels of one workgroup's samples (16 work items per wave and output-channel block)
 
-// shapes the small-plane kernel takes: 1x1 / 3x3 taps at stride 1 with "same" padding or at stride 2 without padding, >= 64 input and
-// output channels (any count), output planes <= 8 x 8 with at most 512 pixels over all samples, dense rows, and a patch that fits the
-// LDS next to the weight slab (many samples of tiny planes do not: their halo is most of the patch)
+// Samples per workgroup: all of them when their planes fit the LDS and SMALL_MAX_PIXELS, else halved until they do (round 5: D's 17 -> 8
+// convolution at B = 8 needs 148 KB of planes -- it ran on conv_mfma_kernel at 138 us next to 34 us at B = 4).  0: not even one sample fits.
+inline int small_bgroup(const gc_conv_desc* d) {
+    int bg = d->batch;
+    while (bg > 1 && (small_lds_bytes(d, 1, bg) > small_lds_max() || (long long)bg * d->out_h * d->out_w > SMALL_MAX_PIXELS)) bg = (bg + 1) / 2;
+    if (bg < 1 || small_lds_bytes(d, 1, bg) > small_lds_max() || (long long)bg * d->out_h * d->out_w > SMALL_MAX_PIXELS) return 0;
+    return bg;
+}
+
+// shapes the small-plane kernel takes: 1x1 / 3x3 taps at stride 1 with "same" padding or at stride 2 without padding, output planes <= 8 x 8;
+// 3x3 taps with up = 2 onto planes <= 10 x 10 (4^2 -> 9^2); >= 64 input and output channels (any count), dense rows, and a patch that fits the
+// LDS next to the weight slab (many samples of tiny planes are split into sample groups: their halo is most of the patch)
 inline bool small_eligible(const gc_conv_desc* d) {
 #ifdef GC_NO_SMALL
     return false;
 #endif
-    if (d->up != 1 || d->kh != d->kw || (d->kh != 1 && d->kh != 3) || d->pad_y != d->pad_x) return false;
-    if (d->down == 1) { if (d->pad_y != d->kh / 2 || d->out_h != d->in_h || d->out_w != d->in_w) return false; }
-    else if (d->down == 2) { if (d->pad_y != 0 || d->in_h < d->kh || d->in_w < d->kw || d->out_h != (d->in_h - d->kh) / 2 + 1 || d->out_w != (d->in_w - d->kw) / 2 + 1) return false; }
-    else return false;
+    if (d->kh != d->kw || (d->kh != 1 && d->kh != 3) || d->pad_y != d->pad_x || d->batch < 1) return false;
+    if (d->up == 2) {
+#ifdef GC_NO_SMALL_UP
+        return false;
+#endif
+        if (d->down != 1 || d->kh != 3 || d->pad_y < 0 || d->out_w > 10 || d->out_h > 10) return false;
+    } else if (d->up == 1) {
+        if (d->down == 1) { if (d->pad_y != d->kh / 2 || d->out_h != d->in_h || d->out_w != d->in_w) return false; }
+        else if (d->down == 2) { if (d->pad_y != 0 || d->in_h < d->kh || d->in_w < d->kw || d->out_h != (d->in_h - d->kh) / 2 + 1 || d->out_w != (d->in_w - d->kw) / 2 + 1) return false; }
+        else return false;
+        if (d->out_w > 8 || d->out_h > 8) return false;
+    } else return false;
     if ((d->in_pitch != 0 && d->in_pitch != d->in_w) || !dense_output(d)) return false;
     if (d->in_ch < 64 || d->out_ch < 64) return false;
-    if (d->out_w > 8 || d->out_h > 8) return false;
-    const long long pixels = (long long)d->batch * d->out_h * d->out_w;
-    return pixels >= 1 && pixels <= 512 && small_lds_bytes(d, 1) <= small_lds_max();
+    return small_bgroup(d) >= 1;
 }
 
 // channel chunks per workgroup: two (32 channels x 32 output channels) when the partial sums of 16-channel slices would outweigh the weights
 inline int small_chunks(const gc_conv_desc* d) {
-    if (d->in_ch % (2 * SMALL_KC) != 0 || small_lds_bytes(d, 2) > small_lds_max()) return 1;
+    const int bg = small_bgroup(d);
+    if (d->in_ch % (2 * SMALL_KC) != 0 || small_lds_bytes(d, 2, bg) > small_lds_max()) return 1;
 #ifdef GC_SMALL_NCH
     return GC_SMALL_NCH;
 #endif
@@ -848,17 +875,18 @@ inline int small_chunks(const gc_conv_desc* d) {
 }
 inline int small_slices(const gc_conv_desc* d) { return gc::ceil_div(d->in_ch, SMALL_KC * small_chunks(d)); }
 
-template <int KS, int DOWN>
+template <int KS, int DOWN, int UP = 1>
 int launch_small(const gc_conv_desc* d, const SmallArgs& sa, hipStream_t s) {
-    const size_t lds = small_lds_bytes(d, small_chunks(d));
+    const size_t lds = small_lds_bytes(d, small_chunks(d), sa.bgroup);
+    const unsigned groups = (unsigned)gc::ceil_div(d->batch, sa.bgroup);
     if (small_chunks(d) == 2) {
         static bool done[16] = {false};
-        if (int rc = gc::allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 1, 2, DOWN>), small_lds_max(), done, "gc_conv2d_f32(small planes)")) return rc;
-        hipLaunchKernelGGL((conv_f32_small_kernel<KS, 1, 2, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 32)), dim3(SMALL_THREADS), lds, s, sa);
+        if (int rc = gc::allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 1, 2, DOWN, UP>), small_lds_max(), done, "gc_conv2d_f32(small planes)")) return rc;
+        hipLaunchKernelGGL((conv_f32_small_kernel<KS, 1, 2, DOWN, UP>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 32), groups), dim3(SMALL_THREADS), lds, s, sa);
     } else {
         static bool done[16] = {false};
-        if (int rc = gc::allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 2, 1, DOWN>), small_lds_max(), done, "gc_conv2d_f32(small planes)")) return rc;
-        hipLaunchKernelGGL((conv_f32_small_kernel<KS, 2, 1, DOWN>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 64)), dim3(SMALL_THREADS), lds, s, sa);
+        if (int rc = gc::allow_dynamic_lds(reinterpret_cast<const void*>(&conv_f32_small_kernel<KS, 2, 1, DOWN, UP>), small_lds_max(), done, "gc_conv2d_f32(small planes)")) return rc;
+        hipLaunchKernelGGL((conv_f32_small_kernel<KS, 2, 1, DOWN, UP>), dim3(small_slices(d), gc::ceil_div(d->out_ch, 64), groups), dim3(SMALL_THREADS), lds, s, sa);
     }
     return gc::check_launch("gc_conv2d_f32(small planes)");
 }
@@ -902,10 +930,11 @@ int gcconv::conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w,
     hipStream_t s = (hipStream_t)stream;
     const size_t need = conv2d_f32_workspace(d);
     if (small_eligible(d) && (gc::probing() || (workspace && workspace_bytes >= need))) {
-        if (gc::probing()) return gc::probe_name("conv_f32_small_kernel<%d,%d,%d,%d>|up1,down%d,k%d", d->kh, small_chunks(d) == 2 ? 1 : 2, small_chunks(d), d->down, d->down, d->kh);
-        SmallArgs sa{a, static_cast<float*>(workspace), (long long)d->batch * d->out_ch * d->out_h * d->out_w, d->batch * d->out_h * d->out_w};
-        if (d->down == 2) rc = d->kh == 3 ? launch_small<3, 2>(d, sa, s) : launch_small<1, 2>(d, sa, s);
-        else              rc = d->kh == 3 ? launch_small<3, 1>(d, sa, s) : launch_small<1, 1>(d, sa, s);
+        if (gc::probing()) return gc::probe_name("conv_f32_small_kernel<%d,%d,%d,%d>|up%d,down%d,k%d", d->kh, small_chunks(d) == 2 ? 1 : 2, small_chunks(d), d->down, d->up, d->down, d->kh);
+        SmallArgs sa{a, static_cast<float*>(workspace), (long long)d->batch * d->out_ch * d->out_h * d->out_w, small_bgroup(d)};
+        if (d->up == 2)        rc = launch_small<3, 1, 2>(d, sa, s);
+        else if (d->down == 2) rc = d->kh == 3 ? launch_small<3, 2>(d, sa, s) : launch_small<1, 2>(d, sa, s);
+        else                   rc = d->kh == 3 ? launch_small<3, 1>(d, sa, s) : launch_small<1, 1>(d, sa, s);
         if (rc) return rc;
         ConvArgs fin_s = a;
         fin_s.part = sa.part;

@@ -2328,13 +2328,16 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
         if (WDMA) wait_staged_loads();           // the LDS-DMA rows of this wave have landed (untracked by the compiler: counted by hand)
     };
 
-    prefetch(0);
+    // split over the input channels (small planes, see plan_splitk_bf16): slice blockIdx.z covers [kz0, kz1) and stores raw partial sums
+    const int kz0 = a.k_per_split ? (int)blockIdx.z * a.k_per_split : 0;
+    const int kz1 = a.k_per_split ? min(p.K, kz0 + a.k_per_split) : p.K;
+    prefetch(kz0);
     __syncthreads();        // s_si
-    commit(0);
+    commit(kz0);
     __syncthreads();
-    for (int k0 = 0; k0 < p.K; k0 += KCB) {
+    for (int k0 = kz0; k0 < kz1; k0 += KCB) {
         wait_staged_loads();    // no-op in hardware (commit retired them); clears the compiler's pending-load model at the loop header
-        const bool more = k0 + KCB < p.K;
+        const bool more = k0 + KCB < kz1;
         prefetch(more ? k0 + KCB : k0);       // unconditional: a conditional prefetch merges through register copies, which wait for the loads
         __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
 #if GC_FRAG_PIPE
@@ -2435,7 +2438,7 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
     // rows of a 1025-wide plane start anywhere), half the store instructions and whole 128-byte segments per 16 lanes.
     typedef float f2u __attribute__((ext_vector_type(2), aligned(4)));
     const int opitch = a.out_pitch;          // rows of a (2H + 1)-wide output are never 16-byte aligned: a pitch that is a multiple of 32 floats gives every 128-byte store run whole cache lines
-    float* yb = p.y + (size_t)b * p.N * p.out_h * opitch;
+    float* yb = (a.k_per_split ? a.part + (size_t)blockIdx.z * a.per_slice : p.y) + (size_t)b * p.N * p.out_h * opitch;
     const EpilogueConsts ec = epilogue_consts(p);
     float nz[WPX][2][2];         // fetched before the first store: a load between stores waits for every store before it
 #pragma unroll
@@ -2892,7 +2895,7 @@ int launch_t(Bf16Args a, hipStream_t s) {
     const long long gx = (long long)a.c.tiles_x * a.c.tiles_y * a.c.B;
     if (gx > 2147483647LL) return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_bf16x3_f32: grid too large");
     if (gc::probing()) return gc::probe_name("convt_fused_bf16x3_kernel<%d,%d,%d,%d>|up2,down1,k3", WG_OC, WG_PX, WPX, TPW);
-    dim3 grid((unsigned)gx, gc::ceil_div(a.c.N, C::OCT));
+    dim3 grid((unsigned)gx, gc::ceil_div(a.c.N, C::OCT), a.k_per_split ? gc::ceil_div(a.c.K, a.k_per_split) : 1);
     const int epi = (a.c.bias || a.c.noise || a.c.act || a.c.residual) ? 2 : (a.c.so ? 1 : 0);
     // LDS-DMA copies whole rows unmasked: every output-channel block and every 16-channel chunk must be complete
     const bool dma = GC_CT_DMA && a.c.N % C::OCT == 0 && a.c.K % KCB == 0;
@@ -3031,13 +3034,33 @@ bool eligible(const gc_conv_desc* d) {
 // Planes of 9 .. 32 pixels (the 16^2 / 32^2 layers, 512 channels) give the launch only B * tiles * N / 64 = 64 .. 256 workgroups, each
 // walking all 32 channel chunks one after the other with nothing to hide the load latency behind (512 -> 512 @16^2, B = 4: 88 us for
 // 4.8 GFLOP).  Splitting K over blockIdx.z fills the chip and shortens the dependent chain; slices of >= 4 chunks.
+#ifndef GC_CT_SPLITK
+#define GC_CT_SPLITK 1        // transposed 3x3 convolutions on small planes split over the input channels
+#endif
+#ifndef GC_SPLIT_TARGET
+#define GC_SPLIT_TARGET 512   // workgroups a split launch aims for
+#endif
 struct SplitPlan { int slices, k_per_split; };
 SplitPlan plan_splitk_bf16(const gc_conv_desc* d) {
     SplitPlan sp{1, 0};
-    if (d->up != 1 || d->in_ch < 128) return sp;
-    const int rows = d->down == 2 ? 4 : 8;          // tile rows the dispatcher picks (4-row tiles when the launch is small: assume the larger tile here)
-    const long long wgs = (long long)gc::ceil_div(d->out_w, 32) * gc::ceil_div(d->out_h, rows) * d->batch * gc::ceil_div(d->out_ch, 64);
-    const int want = (int)std::min<long long>(512 / std::max<long long>(wgs, 1), d->in_ch / 64);
+    if (d->in_ch < 128) return sp;
+    long long wgs;
+    if (d->up == 2) {
+        // the fused transposed kernel (round 5: 512 -> 512 @8^2 / @16^2 were 64 / 160 workgroups walking all 32 chunks: 90 us each whatever the plane);
+        // dense rows only (the finish pass writes dense rows), > 32 output channels (dispatch_t's 64-channel tiles)
+        if (!GC_CT_SPLITK || d->kh != 3 || d->pad_y != 2 || d->pad_x != 2 || d->out_ch <= 32 || (d->out_pitch != 0 && d->out_pitch != d->out_w)) return sp;
+        const int qw = gc::ceil_div(d->out_w, 2), qh = gc::ceil_div(d->out_h, 2);
+        const bool narrow = GC_CONVT_NARROW && gc::ceil_div(qw, 16) * 16 < gc::ceil_div(qw, 32) * 32;
+        wgs = (long long)gc::ceil_div(qw, narrow ? 16 : 32) * gc::ceil_div(qh, narrow ? 8 : 4) * d->batch * gc::ceil_div(d->out_ch, 64);
+    } else {
+        // tile rows as dispatch() picks them: 4 at stride 2; at stride 1 eight unless that gives < 512 workgroups, then four (round 5: this plan
+        // assumed eight rows throughout and cut the stride-1 layers into twice the slices they needed -- 512 -> 512 @32^2: B = 4 79 -> 71 us with
+        // two slices instead of four, B = 8 133 -> 114 us unsplit; the partial sums are the cost of a slice)
+        int rows = d->down == 2 ? 4 : 8;
+        wgs = (long long)gc::ceil_div(d->out_w, 32) * gc::ceil_div(d->out_h, rows) * d->batch * gc::ceil_div(d->out_ch, 64);
+        if (d->down == 1 && d->out_ch > 32 && wgs < 512) wgs = (long long)gc::ceil_div(d->out_w, 32) * gc::ceil_div(d->out_h, 4) * d->batch * gc::ceil_div(d->out_ch, 64);
+    }
+    const int want = (int)std::min<long long>(GC_SPLIT_TARGET / std::max<long long>(wgs, 1), d->in_ch / 64);
     if (want <= 1) return sp;
     sp.k_per_split = gc::ceil_div(gc::ceil_div(d->in_ch, want), KCB) * KCB;
     sp.slices = gc::ceil_div(d->in_ch, sp.k_per_split);
@@ -3169,9 +3192,9 @@ extern "C" int gc_conv2d_fused_bf16x3_packed_f32(const gc_conv_desc* d, const fl
         a.per_slice = (long long)d->batch * d->out_ch * d->out_h * d->out_w;
     }
     if (d->kh == 3) {
-        if (d->up == 2 && d->pad_y == 2 && d->pad_x == 2) return dispatch_t(a, s);
-        if (d->up == 2) return dispatch<2, 1, 3>(a, s);
-        rc = d->down == 2 ? dispatch<1, 2, 3>(a, s) : dispatch<1, 1, 3>(a, s);
+        if (d->up == 2 && d->pad_y == 2 && d->pad_x == 2) rc = dispatch_t(a, s);
+        else if (d->up == 2) return dispatch<2, 1, 3>(a, s);
+        else rc = d->down == 2 ? dispatch<1, 2, 3>(a, s) : dispatch<1, 1, 3>(a, s);
     } else {
         if (d->up == 2) return dispatch<2, 1, 1>(a, s);
         rc = d->down == 2 ? dispatch<1, 2, 1>(a, s) : dispatch<1, 1, 1>(a, s);

@@ -326,6 +326,11 @@ SMALL_CASES = [(4, 512, 512, 4, 4, 3, 1, 1, 1), (4, 512, 512, 8, 8, 3, 1, 1, 1),
                (4, 512, 512, 17, 17, 3, 1, 2, 0), (4, 512, 512, 9, 9, 3, 1, 2, 0), (2, 64, 64, 7, 11, 3, 1, 2, 0), (3, 128, 64, 9, 9, 1, 1, 2, 0),
                # ragged channel counts: 513 -> 512 (D's last block after the minibatch-stddev channel) and its input gradient 512 -> 513
                (4, 513, 512, 4, 4, 3, 1, 1, 1), (4, 512, 513, 4, 4, 3, 1, 1, 1), (2, 72, 100, 8, 8, 3, 1, 1, 1), (2, 100, 70, 15, 15, 3, 1, 2, 0)]
+# round 5: transposed (up = 2) 3x3 onto planes <= 10 x 10 on a zero-stuffed plane (G's 4^2 -> 9^2 layer, the input gradient of D's 9 -> 4 convolution),
+# odd planes, another padding; and batches whose planes do not fit the LDS at once, in sample groups (D's 17 -> 8 at B = 8; 4 + 3 samples; 9^2 at B = 8)
+SMALL_UP_CASES = [(4, 512, 512, 4, 4, 3, 2, 1, 2), (3, 80, 64, 3, 4, 3, 2, 1, 2), (2, 64, 96, 4, 4, 3, 2, 1, 1), (1, 64, 64, 1, 1, 3, 2, 1, 2)]
+SMALL_GROUP_CASES = [(8, 512, 512, 17, 17, 3, 1, 2, 0), (7, 512, 64, 17, 17, 3, 1, 2, 0), (8, 512, 512, 4, 4, 3, 2, 1, 2), (21, 64, 64, 8, 8, 3, 1, 1, 1)]
+SMALL_CASES = SMALL_CASES + SMALL_UP_CASES + SMALL_GROUP_CASES
 
 @pytest.mark.parametrize('case', CONV_CASES + SMALL_CASES)
 def test_conv2d_kernel(case):
@@ -455,7 +460,10 @@ WS_CASES = [(3, 64, 128, 130, 190, 3, 1, 1, 1), (2, 80, 64, 257, 259, 3, 1, 1, 1
 # tile shapes (64 oc x 16 x 16 | 64 oc x 8 x 32 | 32 oc x 16 x 32 q-pixels), several tiles per workgroup, odd chunk counts, ragged widths
 TWS_CASES = [(4, 64, 128, 64, 64, 3, 2, 1, 2), (3, 48, 128, 100, 127, 3, 2, 1, 2), (3, 64, 32, 200, 130, 3, 2, 1, 2), (4, 32, 96, 70, 100, 3, 2, 1, 2),
              (4, 64, 64, 200, 260, 3, 2, 1, 2)]
-BF16_CASES = BF16_CASES + WS_CASES + TWS_CASES + SMALL_CASES + [(400, 64, 64, 1, 1, 3, 1, 1, 1)]      # ... and past the LDS: back on the general path
+# round 5: transposed 3x3 on small planes split over the input channels (convt_fused_bf16x3_kernel + splitk_finish_kernel): the networks' @8^2 / @16^2
+# layers (8 and 3 slices), a ragged last slice, q-tiles that end inside the plane, the 16- and the 32-column tile
+CT_SPLIT_CASES = [(4, 512, 512, 8, 8, 3, 2, 1, 2), (4, 512, 128, 16, 16, 3, 2, 1, 2), (2, 272, 64, 16, 12, 3, 2, 1, 2), (8, 512, 512, 8, 8, 3, 2, 1, 2), (1, 192, 96, 20, 9, 3, 2, 1, 2)]
+BF16_CASES = BF16_CASES + WS_CASES + TWS_CASES + SMALL_CASES + CT_SPLIT_CASES + [(400, 64, 64, 1, 1, 3, 1, 1, 1)]      # ... and past the LDS: back on the general path
 
 
 @pytest.mark.parametrize('case', BF16_CASES)
@@ -474,6 +482,9 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
     if case in WS_CASES:
         from gan_control_amd.utils.profiling import conv_variant
         assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_bf16x3_ws_kernel'), 'this shape is meant to reach the wave-specialised kernel'
+    if case in CT_SPLIT_CASES:
+        from gan_control_amd import _lib
+        assert _lib.load().gc_conv2d_bf16x3_splitk_bytes(hip._desc(x, N, geom)) > 0, 'this shape is meant to be split over its input channels'
     if case in SMALL_CASES:
         from gan_control_amd.utils.profiling import conv_variant
         assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_f32_small_kernel'), 'this shape is meant to reach the small-plane kernel (exact fp32 in this mode too)'
@@ -503,7 +514,7 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
             assert rel_err(out, ref) < 5e-5, ('wgrad', use_scales)
 
 
-EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3 and c not in WS_CASES + SMALL_CASES][::2] + WS_CASES + SMALL_CASES[1:4]
+EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3 and c not in WS_CASES + SMALL_CASES + CT_SPLIT_CASES][::2] + WS_CASES + SMALL_CASES[1:4] + SMALL_UP_CASES[:2] + SMALL_GROUP_CASES[:3] + CT_SPLIT_CASES[:3]
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x3'])

@@ -40,9 +40,9 @@ def main():
     convs = []
     for ch, res in [(512, 4), (512, 8), (512, 16), (512, 32), (512, 64), (256, 128), (128, 256), (64, 512), (32, 1024)]:
         convs.append(('conv3x3 s1', ch, ch, res, 3, 1, 1, 1))
-    for (ic, oc, res) in [(512, 512, 4), (512, 512, 16), (512, 512, 32), (512, 256, 64), (256, 128, 128), (128, 64, 256), (64, 32, 512)]:
+    for (ic, oc, res) in [(512, 512, 4), (512, 512, 8), (512, 512, 16), (512, 512, 32), (512, 256, 64), (256, 128, 128), (128, 64, 256), (64, 32, 512)]:
         convs.append(('convT3x3 up2', ic, oc, res, 3, 2, 1, 2))
-    for (ic, oc, res) in [(32, 64, 1025), (64, 128, 513), (128, 256, 257), (256, 512, 129), (512, 512, 65), (512, 512, 17)]:
+    for (ic, oc, res) in [(32, 64, 1025), (64, 128, 513), (128, 256, 257), (256, 512, 129), (512, 512, 65), (512, 512, 33), (512, 512, 17), (512, 512, 9)]:
         convs.append(('conv3x3 s2', ic, oc, res, 3, 1, 2, 0))
     for (ic, oc, res) in [(32, 64, 1023), (128, 256, 255), (512, 512, 63)]:
         convs.append(('conv1x1 s2', ic, oc, res, 1, 1, 2, 0))
