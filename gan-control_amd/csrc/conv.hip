@@ -891,6 +891,145 @@ int launch_small(const gc_conv_desc* d, const SmallArgs& sa, hipStream_t s) {
     return gc::check_launch("gc_conv2d_f32(small planes)");
 }
 
+// --------------------------------------------------------------------------------------------
+// Weight gradient of a 3 x 3 convolution onto planes <= 8 x 8 (round 5; the 4^2 / 8^2 layers of D and its 9 -> 4 / 17 -> 8 down-sampling
+// convolutions): the pixel-tile kernels fill 4 .. 8 of a tile's 32 columns, cut the pixels into eight splits to have workgroups at all and add
+// the splits up again in a second launch -- 40 .. 60 us for 0.3 .. 2.4 GFLOP.  Here ONE workgroup owns a (32 k x 32 n) block of all nine taps
+// and the pixels of ALL samples are the contraction index of v_mfma_f32_32x32x2_f32 (exact fp32, like the forward kernel of these planes):
+// the zero-haloed input planes of its 32 input channels (x in_scale) and the gradient planes of its 32 output channels (x out_scale) are
+// staged once per group of samples that fits the LDS, wave t multiplies tap t (nine waves), and the block is written once -- no workspace,
+// no second launch, sums in a fixed order.
+struct WgSmallArgs { WgradArgs a; int bgroup, xrow, yrow; };     // samples per staged group; floats per channel row of the two LDS arrays (odd: conflict-free columns)
+constexpr int WGS_THREADS = 576;
+
+// J: 64-lane chunks of one zero-haloed input plane (1, 2 or 5: planes of <= 64, 128, 320 positions)
+template <int DOWN, int J>
+__global__ __launch_bounds__(WGS_THREADS) void wgrad_f32_small_kernel(WgSmallArgs q) {
+    constexpr int KS = 3, NWV = WGS_THREADS / 64, KW = (32 + NWV - 1) / NWV, BU = 4;      // KW channel rows per wave, BU samples per staging round
+    extern __shared__ float wgs_smem[];
+    const WgradArgs& p = q.a;
+    const int pad = p.pad_y;                                              // 1 at stride 1, 0 at stride 2 (= pad_x)
+    const int ph = p.in_h + 2 * pad, pw = p.in_w + 2 * pad, plane = ph * pw, oplane = p.out_h * p.out_w;
+    float* xs = wgs_smem;                                                 // [32 k][bgroup * plane | 2 pw + 3 zeros (what a padding pixel reads under any tap) | pad to xrow]
+    float* ys = xs + 32 * q.xrow;                                         // [32 n][bgroup * oplane rounded up to 16 pixels with zeros | pad to yrow]
+    int* postab = reinterpret_cast<int*>(ys + 32 * q.yrow);               // pixel of the group -> its position under tap (0, 0)
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);            // = the tap
+    const int k0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+    const int ty = wave / KS, tx = wave % KS, tapoff = ty * pw + tx;
+    const int chan = p.in_h * p.in_w;
+    // this lane's positions of a haloed plane -> offset inside the input plane (-1: halo or past the plane); the only divisions of the staging
+    int xo[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int r0 = lane + 64 * j, yy = r0 / pw - pad, xx = r0 % pw - pad;
+        xo[j] = (r0 < plane && yy >= 0 && yy < p.in_h && xx >= 0 && xx < p.in_w) ? yy * p.in_w + xx : -1;
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int b0 = 0; b0 < p.B; b0 += q.bgroup) {
+        const int nb = min(q.bgroup, p.B - b0), npos = nb * plane, npix = nb * oplane, npix2 = (npix + 15) & ~15;
+        if (b0 > 0) __syncthreads();                                      // every wave has read the previous group
+        // Staging: wave w owns channel rows w, w + 9, ... of BOTH arrays; one round = those rows x four samples, every load of the round in flight
+        // before its first LDS store (a load per trip of a flat loop was one exposed memory latency -- and five integer divisions -- per element)
+        for (int bb = 0; bb < nb; bb += BU) {
+            float xv[KW][BU][J], yv[KW][BU], sx[KW][BU], sy[KW][BU];
+#pragma unroll
+            for (int i = 0; i < KW; ++i) {
+                const int c = wave + NWV * i;
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    const int b = bb + u;
+                    const bool okx = c < 32 && b < nb && k0 + c < p.K, oky = c < 32 && b < nb && n0 + c < p.N;
+                    const size_t rowx = okx ? (size_t)(b0 + b) * p.K + k0 + c : 0, rowy = oky ? (size_t)(b0 + b) * p.N + n0 + c : 0;
+#pragma unroll
+                    for (int j = 0; j < J; ++j) xv[i][u][j] = (okx && xo[j] >= 0) ? p.x[rowx * chan + xo[j]] : 0.f;
+                    yv[i][u] = (oky && lane < oplane) ? p.dy[rowy * oplane + lane] : 0.f;
+                    sx[i][u] = (okx && p.si) ? p.si[rowx] : 1.f;
+                    sy[i][u] = (oky && p.so) ? p.so[rowy] : 1.f;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < KW; ++i) {
+                const int c = wave + NWV * i;
+#pragma unroll
+                for (int u = 0; u < BU; ++u) {
+                    const int b = bb + u;
+                    if (c < 32 && b < nb) {
+#pragma unroll
+                        for (int j = 0; j < J; ++j)
+                            if (lane + 64 * j < plane) xs[c * q.xrow + b * plane + lane + 64 * j] = xv[i][u][j] * sx[i][u];
+                        if (lane < oplane) ys[c * q.yrow + b * oplane + lane] = yv[i][u] * sy[i][u];
+                    }
+                }
+            }
+        }
+        for (int e = tid; e < 32 * (2 * pw + 3); e += WGS_THREADS) xs[(e & 31) * q.xrow + npos + (e >> 5)] = 0.f;       // what the padding pixels read
+        for (int e = tid; e < 32 * (npix2 - npix); e += WGS_THREADS) ys[(e & 31) * q.yrow + npix + (e >> 5)] = 0.f;
+        for (int px = tid; px < npix2; px += WGS_THREADS) {
+            int pos = npos;
+            if (px < npix) {
+                const int b = px / oplane, o = px - b * oplane, oy = o / p.out_w, ox = o - oy * p.out_w;
+                pos = b * plane + oy * DOWN * pw + ox * DOWN;
+            }
+            postab[px] = pos;
+        }
+        __syncthreads();
+        const float* xa = xs + l31 * q.xrow + tapoff;
+        const float* yb = ys + l31 * q.yrow;
+        // eight products per trip, their LDS reads issued together (position table, then the values): as a plain loop every product waited for
+        // three dependent LDS round trips.  lanes 0..31 take pixel 2 j, lanes 32..63 pixel 2 j + 1
+        for (int j0 = 0; j0 < npix2 / 2; j0 += 8) {
+            int pos[8];
+            float av[8], bv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) pos[u] = postab[2 * (j0 + u) + hi];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { av[u] = xa[pos[u]]; bv[u] = yb[2 * (j0 + u) + hi]; }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc, 0, 0, 0);
+        }
+    }
+    float* out = p.ws + ((size_t)wave * p.K + k0) * p.N + n0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int k = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (k0 + k < p.K && n0 + l31 < p.N) out[(size_t)k * p.N + l31] = acc[r];
+    }
+}
+
+inline int wgs_odd(int v) { return v | 1; }
+inline size_t wgs_lds_bytes(const gc_conv_desc* d, int bg) {
+    const int pad = d->pad_y, plane = (d->in_h + 2 * pad) * (d->in_w + 2 * pad), oplane = d->out_h * d->out_w;
+    const int npix2 = (bg * oplane + 15) & ~15, zeros = 2 * (d->in_w + 2 * pad) + 3;
+    return ((size_t)32 * wgs_odd(bg * plane + zeros) + (size_t)32 * wgs_odd(npix2) + npix2) * sizeof(float);
+}
+inline int wgs_bgroup(const gc_conv_desc* d) {
+    int bg = d->batch;
+    while (bg > 1 && wgs_lds_bytes(d, bg) > small_lds_max()) bg = (bg + 1) / 2;
+    return wgs_lds_bytes(d, bg) <= small_lds_max() ? bg : 0;
+}
+
+int launch_wgrad_small(const gc_conv_desc* d, const float* x, const float* dy, const float* in_scale, const float* out_scale, float* dw, hipStream_t s) {
+    const int bg = wgs_bgroup(d), pad = d->pad_y, plane = (d->in_h + 2 * pad) * (d->in_w + 2 * pad), oplane = d->out_h * d->out_w;
+    WgSmallArgs q{{x, dy, in_scale, out_scale, dw, d->batch, d->in_ch, d->out_ch, d->in_h, d->in_w, d->out_h, d->out_w, d->pad_y, d->pad_x, 0, 0, 0},
+                  bg, wgs_odd(bg * plane + 2 * (d->in_w + 2 * pad) + 3), wgs_odd((bg * oplane + 15) & ~15)};
+    const size_t lds = wgs_lds_bytes(d, bg);
+    const dim3 grid(gc::ceil_div(d->in_ch, 32), gc::ceil_div(d->out_ch, 32));
+    const int chunks = plane <= 64 ? 1 : (plane <= 128 ? 2 : 5);
+    static bool done[6][16] = {{false}};
+#define GC_WGS_LAUNCH(DOWN_, J_, SLOT_)                                                                                                                   \
+    do {                                                                                                                                                \
+        if (int rc = gc::allow_dynamic_lds(reinterpret_cast<const void*>(&wgrad_f32_small_kernel<DOWN_, J_>), small_lds_max(), done[SLOT_], "gc_conv2d_wgrad_f32(small planes)")) return rc; \
+        hipLaunchKernelGGL((wgrad_f32_small_kernel<DOWN_, J_>), grid, dim3(WGS_THREADS), lds, s, q);                                                    \
+    } while (0)
+    if (d->down == 2) { if (chunks == 1) GC_WGS_LAUNCH(2, 1, 0); else if (chunks == 2) GC_WGS_LAUNCH(2, 2, 1); else GC_WGS_LAUNCH(2, 5, 2); }
+    else              { if (chunks == 1) GC_WGS_LAUNCH(1, 1, 3); else if (chunks == 2) GC_WGS_LAUNCH(1, 2, 4); else GC_WGS_LAUNCH(1, 5, 5); }
+#undef GC_WGS_LAUNCH
+    return gc::check_launch("gc_conv2d_wgrad_f32(small planes)");
+}
+
 template <int DOWN, int KS>
 int dispatch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
     dim3 grid(gc::ceil_div(a.K, pl.kt), gc::ceil_div(a.N, pl.nt), pl.splits);
@@ -905,6 +1044,25 @@ int dispatch_wgrad(const WgradArgs& a, const WgradPlan& pl, hipStream_t s) {
 }
 
 }  // namespace
+
+// 3 x 3 weight gradients the small-plane kernel takes: stride 1 with "same" padding or stride 2 without padding onto planes <= 8 x 8, dense rows,
+// >= 64 channels on both sides (fewer leave the launch a handful of workgroups), at most 2048 pixels over the batch, the batch in at most two LDS-sized
+// groups of samples.  Measured (512 -> 512, same box, pixel-tile kernels + reduce -> this kernel, profiles/tail_wg_ab_r05.log): @4^2 B = 2 / 4 / 8
+// 32 / 41 / 47 -> 12 / 15 / 24 us; @8^2 40 / 46 / 56 -> 19 / 27 / 47; 9 -> 4: 39 / 42 / 48 -> 13 / 16 / 26; 17 -> 8: 42 / 47 -> 22 / 37 (B = 8 stays: 4 groups)
+bool gcconv::wgrad_small_eligible(const gc_conv_desc* d) {
+#ifdef GC_NO_SMALL_WGRAD
+    return false;
+#endif
+    if (d->up != 1 || d->kh != 3 || d->kw != 3 || d->pad_y != d->pad_x || d->batch < 1) return false;
+    if (d->down == 1) { if (d->pad_y != 1 || d->out_h != d->in_h || d->out_w != d->in_w) return false; }
+    else if (d->down == 2) { if (d->pad_y != 0 || d->in_h < 3 || d->in_w < 3 || d->out_h != (d->in_h - 3) / 2 + 1 || d->out_w != (d->in_w - 3) / 2 + 1) return false; }
+    else return false;
+    if (d->in_pitch != 0 && d->in_pitch != d->in_w) return false;
+    if (d->in_ch < 64 || d->out_ch < 64 || d->out_w > 8 || d->out_h > 8) return false;
+    if ((long long)d->batch * d->out_h * d->out_w > 2048 || (d->in_h + 2 * d->pad_y) * (d->in_w + 2 * d->pad_x) > 320) return false;
+    const int bg = wgs_bgroup(d);
+    return bg >= 1 && gc::ceil_div(d->batch, bg) <= 2;       // each staged group costs ~12 us of latencies: with more than two the pixel-tile kernels win (512 -> 512, 17 -> 8, B = 8: 68 vs 59 us)
+}
 
 size_t gcconv::conv2d_f32_workspace(const gc_conv_desc* d) {
     if (!d || d->batch <= 0 || d->in_ch <= 0 || d->out_ch <= 0 || d->out_h <= 0 || d->out_w <= 0 || d->up <= 0) return 0;
@@ -1005,6 +1163,7 @@ extern "C" int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const 
         hipError_t e = hipMemsetAsync(dw, 0, count * sizeof(float), s);
         return e == hipSuccess ? GC_OK : gc::fail(GC_ERR_HIP, "gc_conv2d_wgrad_f32: memset: %s", hipGetErrorString(e));
     }
+    if (wgrad_small_eligible(d)) return launch_wgrad_small(d, x, dy, in_scale, out_scale, dw, s);        // one launch, no workspace
     const WgradPlan pl = plan_wgrad(d);
     const size_t need = gc_conv2d_wgrad_workspace(d);
     if (!workspace || workspace_bytes < need) return gc::fail(GC_ERR_WORKSPACE, "gc_conv2d_wgrad_f32: workspace %zu < %zu bytes", workspace_bytes, need);

@@ -2122,6 +2122,9 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
 }
 
 struct WgPlan { int small, ct, kt, tr, splits, tiles_per_split, tiles_x, tiles_y; };
+#ifndef GC_WG_SPLIT_TARGET
+#define GC_WG_SPLIT_TARGET 512      // workgroups a weight-gradient launch aims for (pixel splits x channel tiles)
+#endif
 
 // 64k x 64n tiles (2 rows per pixel tile) when both channel counts reach 64, else 32k x 32n tiles with the four
 // waves splitting the pixel steps of a 4-row tile
@@ -2138,7 +2141,7 @@ WgPlan plan_wg(const gc_conv_desc* d) {
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
     const int ctiles = gc::ceil_div(d->in_ch, pl.kt) * gc::ceil_div(d->out_ch, pl.ct);
-    int want = gc::ceil_div(512, ctiles);      // one workgroup per CU is resident (512 registers per lane): two rounds
+    int want = gc::ceil_div(GC_WG_SPLIT_TARGET, ctiles);      // one workgroup per CU is resident (512 registers per lane): two rounds
     if (want > total) want = total;
     if (want < 1) want = 1;
     pl.tiles_per_split = gc::ceil_div(total, want);
@@ -2499,6 +2502,132 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
             }
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// The last output row and column of a (2H + 1) x (2W + 1) transposed convolution (round 5).  q-space is (H + 1) x (W + 1): the kernel above
+// tiles it in 4 x 32 or 8 x 16 blocks, and at H = W = 32 / 64 / 128 the one extra q-row and q-column cost 47 / 29 / 16 % more tiles than the
+// H x W region, which tiles exactly.  With GC_CT_EDGE the fused kernel is launched over the H x W region only (output rows 0 .. 2H - 1, columns
+// 0 .. 2W - 1) and this kernel computes the rest: output row 2H (2W + 1 values, from input row H - 1 under the taps ty = 0) and output column 2W
+// (2H values, from input column W - 1 under the taps tx = 0) -- 1-D problems, (H + W + 1) q-positions of three taps each instead of H + W + 1
+// positions padded to whole 2-D tiles.  One workgroup = 32 q-positions x 64 output channels; its four waves take a quarter of the input
+// channels each, straight from global memory into registers (no LDS staging: 16 scalar loads of x and 12 16-byte loads of the packed weights
+// per lane and chunk, two chunks in flight), and wave 0 adds the quarters in a fixed order and applies the epilogue.
+// Same arithmetic as the fused kernel (split operands, three MFMAs per product); the sums run over the quarters one after the other instead
+// of chunk by chunk, so the edge values differ from the one-kernel form in the last bits.
+#ifndef GC_CT_EDGE
+#define GC_CT_EDGE 1
+#endif
+__global__ __launch_bounds__(256) void convt_edge_bf16x3_kernel(Bf16Args a) {
+    const ConvArgs& p = a.c;
+    __shared__ float red[3][64][64];                       // [wave - 1][accumulator register][lane]
+    const int H = p.in_h, W = p.in_w, chan = H * W;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int rblocks = (W + 1 + 31) / 32;                 // blocks of the bottom row first, then those of the right column
+    const bool col = (int)blockIdx.x >= rblocks;
+    const int e = ((int)blockIdx.x - (col ? rblocks : 0)) * 32 + l31;         // q-position along the edge
+    const int n0 = blockIdx.y * 64, b = blockIdx.z;
+    // the two input pixels of this position: `cur` (offset d = 0) and `prev` (d = -1) along the edge
+    const bool okc = col ? e < H : e < W, okp = col ? (e >= 1 && e < H) : (e >= 1 && e <= W);
+    const int cur = okc ? (col ? e * W + W - 1 : (H - 1) * W + e) : 0;
+    const int prev = okp ? (col ? (e - 1) * W + W - 1 : (H - 1) * W + e - 1) : 0;
+    // taps: prev -> phase 0 under (0, 0); cur -> phase 0 under (0, 2) | (2, 0) and -> phase 1 under (0, 1) | (1, 0)
+    const int tB = col ? 6 : 2, tC = col ? 3 : 1;
+    const float* xb = p.x + (size_t)b * p.K * chan;
+    const float* sib = p.si ? p.si + (size_t)b * p.K : nullptr;
+    const int chunks = p.K / KCB, c0 = wave * chunks / 4, c1 = (wave + 1) * chunks / 4;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ph][i][r] = 0.f;
+#pragma unroll 2
+    for (int c = c0; c < c1; ++c) {
+        const int kb = c * KCB + hi * 8;
+        float vp[8], vc[8], sc[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            vp[q] = xb[(size_t)(kb + q) * chan + prev];
+            vc[q] = xb[(size_t)(kb + q) * chan + cur];
+            sc[q] = sib ? sib[kb + q] : 1.f;
+        }
+        uint4 wa_h[2], wa_l[2], wb_h[2], wb_l[2], wc_h[2], wc_l[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const size_t col_ = (size_t)n0 + i * 32 + l31, kg = c * KG + hi;
+            wa_h[i] = a.wh[(0 * (size_t)a.kgroups + kg) * p.N + col_];  GC_LO(wa_l[i] = a.wl[(0 * (size_t)a.kgroups + kg) * p.N + col_];)
+            wb_h[i] = a.wh[(tB * (size_t)a.kgroups + kg) * p.N + col_]; GC_LO(wb_l[i] = a.wl[(tB * (size_t)a.kgroups + kg) * p.N + col_];)
+            wc_h[i] = a.wh[(tC * (size_t)a.kgroups + kg) * p.N + col_]; GC_LO(wc_l[i] = a.wl[(tC * (size_t)a.kgroups + kg) * p.N + col_];)
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { vp[q] = okp ? vp[q] : 0.f; vc[q] = okc ? vc[q] : 0.f; }
+        uint4 ph_, pl_, ch_, cl_;
+        if (sib) { split8s<true>(vp, sc, &ph_, &pl_); split8s<true>(vc, sc, &ch_, &cl_); }
+        else     { split8s<false>(vp, sc, &ph_, &pl_); split8s<false>(vc, sc, &ch_, &cl_); }
+        const bf16x8 bph = *reinterpret_cast<const bf16x8*>(&ph_), bch = *reinterpret_cast<const bf16x8*>(&ch_);
+        GC_LO(const bf16x8 bpl = *reinterpret_cast<const bf16x8*>(&pl_); const bf16x8 bcl = *reinterpret_cast<const bf16x8*>(&cl_);)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(&wa_h[i]), bh = *reinterpret_cast<const bf16x8*>(&wb_h[i]), chh = *reinterpret_cast<const bf16x8*>(&wc_h[i]);
+            GC_LO(const bf16x8 al = *reinterpret_cast<const bf16x8*>(&wa_l[i]); const bf16x8 bl = *reinterpret_cast<const bf16x8*>(&wb_l[i]); const bf16x8 cll = *reinterpret_cast<const bf16x8*>(&wc_l[i]);)
+            GC_MFMA3(acc[0][i], ah, al, bph, bpl);
+            GC_MFMA3(acc[0][i], bh, bl, bch, bcl);
+            GC_MFMA3(acc[1][i], chh, cll, bch, bcl);
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) red[wave - 1][(ph * 2 + i) * 16 + r][lane] = acc[ph][i][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 0; w < 3; ++w)
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][i][r] += red[w][(ph * 2 + i) * 16 + r][lane];
+    const EpilogueConsts ec = epilogue_consts(p);
+    const int opitch = a.out_pitch;
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        const int oy = col ? 2 * e + ph : 2 * H, ox = col ? 2 * W : 2 * e + ph;
+        if (oy >= p.out_h || ox >= p.out_w || (col && e >= H)) continue;
+        const float nz = p.noise ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                const float so = p.so ? p.so[(size_t)b * p.N + n] : 1.f, bias = p.bias ? p.bias[n] : 0.f;
+                float v = conv_epilogue(ec, acc[ph][i][r], so, bias, nz);      // absent parts are exact no-ops (conv_common.h)
+                if (p.residual) v += p.residual[(((size_t)b * p.N + n) * p.out_h + oy) * p.out_w + ox];
+                p.y[(((size_t)b * p.N + n) * p.out_h + oy) * opitch + ox] = v;
+            }
+    }
+}
+
+// the launches that take the H x W main region + edge form: the (2H + 1) x (2W + 1) geometry, whole chunks and 64-channel output blocks, >= 256 input
+// channels (below that the layer is bound by its stores, not by its tiles), an H x W region that the 4 x 32 tile covers exactly, and >= 10 % fewer tiles
+inline bool ct_edge_eligible(const Bf16Args& a) {
+    const ConvArgs& c = a.c;
+    if (!GC_CT_EDGE || a.k_per_split || c.out_h != 2 * c.in_h + 1 || c.out_w != 2 * c.in_w + 1) return false;
+    if (c.K % KCB != 0 || c.K < 256 || c.K / KCB < 4 || c.N % 64 != 0 || c.in_w % 32 != 0 || c.in_h % 4 != 0) return false;
+    const int qh = c.in_h + 1, qw = c.in_w + 1;
+    const bool narrow = GC_CONVT_NARROW && gc::ceil_div(qw, 16) * 16 < gc::ceil_div(qw, 32) * 32;
+    const long long full = (long long)gc::ceil_div(qw, narrow ? 16 : 32) * gc::ceil_div(qh, narrow ? 8 : 4), main_ = (long long)(c.in_w / 32) * (c.in_h / 4);
+    // ... and enough workgroups for two per CU: with one per CU nothing overlaps its staging (512 -> 512 @32^2, B = 4: 256 workgroups, 127 -> 137 us;
+    // 512 -> 256 @64^2, B = 2: 99 -> 133 us -- against B = 8 / B = 4 of the same layers: 226 -> 175, 197 -> 162 us; profiles/convt_ab_r05.log)
+    return 10 * main_ <= 9 * full && main_ * c.B * (c.N / 64) >= 512;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2887,9 +3016,9 @@ inline bool tws_eligible(const Bf16Args& a) {
 #endif      // GC_CTWS
 
 template <int WG_OC, int WG_PX, int WPX, int TPW>
-int launch_t(Bf16Args a, hipStream_t s) {
+int launch_t(Bf16Args a, hipStream_t s, bool main_only = false) {
     using C = TCfg<WG_OC, WG_PX, WPX, TPW>;
-    const int qh = gc::ceil_div(a.c.out_h, 2), qw = gc::ceil_div(a.c.out_w, 2);
+    const int qh = main_only ? a.c.in_h : gc::ceil_div(a.c.out_h, 2), qw = main_only ? a.c.in_w : gc::ceil_div(a.c.out_w, 2);     // main_only: the H x W region (convt_edge_bf16x3_kernel does the rest)
     a.c.tiles_y = gc::ceil_div(qh, C::TQH);
     a.c.tiles_x = gc::ceil_div(qw, TPW);
     const long long gx = (long long)a.c.tiles_x * a.c.tiles_y * a.c.B;
@@ -2924,6 +3053,13 @@ int dispatch_t(const Bf16Args& a, hipStream_t s) {
     // <= 32 output channels: the layer is bound by its stores, and 32-column q-tiles write 256-byte runs per row instead of 128-byte
     // ones (64 -> 32 @512^2: 254 -> 232 us) -- worth more than the 16 columns of lanes a 513-wide q-row wastes
     if (a.c.N <= 32) return launch_t<1, 4, 2, 32>(a, s);
+    if (ct_edge_eligible(a)) {
+        if (gc::probing()) return gc::probe_name("convt_fused_bf16x3_kernel<2,2,2,32>+edge|up2,down1,k3");
+        if (int rc = launch_t<2, 2, 2, 32>(a, s, true)) return rc;
+        const dim3 grid((unsigned)(gc::ceil_div(a.c.in_w + 1, 32) + gc::ceil_div(a.c.in_h, 32)), (unsigned)(a.c.N / 64), (unsigned)a.c.B);
+        hipLaunchKernelGGL(convt_edge_bf16x3_kernel, grid, dim3(256), 0, s, a);
+        return gc::check_launch("gc_conv2d_bf16x3_f32(transposed, edge)");
+    }
     return narrow ? launch_t<2, 2, 2, 16>(a, s) : launch_t<2, 2, 2, 32>(a, s);
 }
 
@@ -3326,7 +3462,7 @@ extern "C" int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x,
     if (!x || !dy || !dw) return gc::fail(GC_ERR_BAD_ARG, "gc_conv2d_wgrad_bf16x3_f32: null pointer");
     if (d->in_pitch != 0 && d->in_pitch != d->in_w && !(wg_eligible(d) && d->down == 2))
         return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_bf16x3_f32: in_pitch %d: only the split-bf16 stride-2 kernel reads pitched rows (gc_conv2d_in_pitch_ok)", d->in_pitch);
-    if (d->batch == 0 || !wg_eligible(d)) return gc_conv2d_wgrad_f32(d, x, dy, in_scale, out_scale, dw, workspace, workspace_bytes, stream);
+    if (d->batch == 0 || !wg_eligible(d) || wgrad_small_eligible(d)) return gc_conv2d_wgrad_f32(d, x, dy, in_scale, out_scale, dw, workspace, workspace_bytes, stream);
     return wgrad_launch(d, x, dy, in_scale, out_scale, dw, nullptr, workspace, workspace_bytes, (hipStream_t)stream, "gc_conv2d_wgrad_bf16x3_f32");
 }
 

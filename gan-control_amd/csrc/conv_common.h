@@ -158,6 +158,9 @@ size_t conv2d_f32_workspace(const gc_conv_desc* d);
 int conv2d_f32_ws(const gc_conv_desc* d, const float* x, const float* w, const float* in_scale, const float* out_scale,
                   const gc_conv_epilogue* ep, float* y, void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
+// defined in conv.hip: 3 x 3 weight gradients onto planes <= 8 x 8 that gc_conv2d_wgrad_f32 computes in one launch in exact fp32 (every arithmetic mode sends them there)
+bool wgrad_small_eligible(const gc_conv_desc* d);
+
 // defined in conv.hip: y = epilogue(sum over the K slices fin.part[z * per_slice + i]) in fixed order (split-K finish pass)
 int launch_splitk_finish(const ConvArgs& fin, int slices, long long per_slice, hipStream_t s);
 

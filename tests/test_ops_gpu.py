@@ -330,7 +330,12 @@ SMALL_CASES = [(4, 512, 512, 4, 4, 3, 1, 1, 1), (4, 512, 512, 8, 8, 3, 1, 1, 1),
 # odd planes, another padding; and batches whose planes do not fit the LDS at once, in sample groups (D's 17 -> 8 at B = 8; 4 + 3 samples; 9^2 at B = 8)
 SMALL_UP_CASES = [(4, 512, 512, 4, 4, 3, 2, 1, 2), (3, 80, 64, 3, 4, 3, 2, 1, 2), (2, 64, 96, 4, 4, 3, 2, 1, 1), (1, 64, 64, 1, 1, 3, 2, 1, 2)]
 SMALL_GROUP_CASES = [(8, 512, 512, 17, 17, 3, 1, 2, 0), (7, 512, 64, 17, 17, 3, 1, 2, 0), (8, 512, 512, 4, 4, 3, 2, 1, 2), (21, 64, 64, 8, 8, 3, 1, 1, 1)]
-SMALL_CASES = SMALL_CASES + SMALL_UP_CASES + SMALL_GROUP_CASES
+# round 5: the weight gradients of these planes run on wgrad_f32_small_kernel (3x3 taps, planes <= 8 x 8, at most two LDS-sized sample groups): every
+# 3x3 case above with up = 1 reaches it through the wgrad half of the tests; these add two sample groups at stride 1 (8 x 8 planes, B = 8), a ragged second
+# group (17 -> 8, B = 3: groups of 2 + 1), pixel counts that are not multiples of 16 and of 2, and a batch past the limit (back on the pixel-tile kernels)
+SMALL_WGRAD_CASES = [(8, 512, 64, 8, 8, 3, 1, 1, 1), (3, 128, 96, 17, 17, 3, 1, 2, 0), (3, 64, 80, 3, 5, 3, 1, 1, 1), (1, 70, 64, 3, 3, 3, 1, 1, 1), (1, 64, 64, 5, 5, 3, 1, 2, 0),
+                     (8, 128, 64, 17, 17, 3, 1, 2, 0)]
+SMALL_CASES = SMALL_CASES + SMALL_UP_CASES + SMALL_GROUP_CASES + SMALL_WGRAD_CASES
 
 @pytest.mark.parametrize('case', CONV_CASES + SMALL_CASES)
 def test_conv2d_kernel(case):
@@ -463,7 +468,10 @@ TWS_CASES = [(4, 64, 128, 64, 64, 3, 2, 1, 2), (3, 48, 128, 100, 127, 3, 2, 1, 2
 # round 5: transposed 3x3 on small planes split over the input channels (convt_fused_bf16x3_kernel + splitk_finish_kernel): the networks' @8^2 / @16^2
 # layers (8 and 3 slices), a ragged last slice, q-tiles that end inside the plane, the 16- and the 32-column tile
 CT_SPLIT_CASES = [(4, 512, 512, 8, 8, 3, 2, 1, 2), (4, 512, 128, 16, 16, 3, 2, 1, 2), (2, 272, 64, 16, 12, 3, 2, 1, 2), (8, 512, 512, 8, 8, 3, 2, 1, 2), (1, 192, 96, 20, 9, 3, 2, 1, 2)]
-BF16_CASES = BF16_CASES + WS_CASES + TWS_CASES + SMALL_CASES + CT_SPLIT_CASES + [(400, 64, 64, 1, 1, 3, 1, 1, 1)]      # ... and past the LDS: back on the general path
+# round 5: (2H + 1) x (2W + 1) transposed convolutions as an H x W main region + convt_edge_bf16x3_kernel (K % 16 == 0, K >= 256, N % 64 == 0, W % 32 == 0,
+# H % 4 == 0, >= 512 workgroups in the main region): square and flat planes, row-pitched outputs (out_w >= 129), uneven channel quarters (17 chunks)
+CT_EDGE_CASES = [(4, 256, 256, 64, 64, 3, 2, 1, 2), (8, 256, 256, 32, 64, 3, 2, 1, 2), (16, 272, 256, 32, 32, 3, 2, 1, 2), (4, 512, 64, 128, 128, 3, 2, 1, 2)]
+BF16_CASES = BF16_CASES + WS_CASES + TWS_CASES + SMALL_CASES + CT_SPLIT_CASES + CT_EDGE_CASES + [(400, 64, 64, 1, 1, 3, 1, 1, 1)]      # ... and past the LDS: back on the general path
 
 
 @pytest.mark.parametrize('case', BF16_CASES)
@@ -482,6 +490,9 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
     if case in WS_CASES:
         from gan_control_amd.utils.profiling import conv_variant
         assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_bf16x3_ws_kernel'), 'this shape is meant to reach the wave-specialised kernel'
+    if case in CT_EDGE_CASES:
+        from gan_control_amd.utils.profiling import conv_variant
+        assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).endswith('+edge|up2,down1,k3'), 'this shape is meant to run as main region + edge kernel'
     if case in CT_SPLIT_CASES:
         from gan_control_amd import _lib
         assert _lib.load().gc_conv2d_bf16x3_splitk_bytes(hip._desc(x, N, geom)) > 0, 'this shape is meant to be split over its input channels'
@@ -514,7 +525,7 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
             assert rel_err(out, ref) < 5e-5, ('wgrad', use_scales)
 
 
-EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3 and c not in WS_CASES + SMALL_CASES + CT_SPLIT_CASES][::2] + WS_CASES + SMALL_CASES[1:4] + SMALL_UP_CASES[:2] + SMALL_GROUP_CASES[:3] + CT_SPLIT_CASES[:3]
+EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3 and c not in WS_CASES + SMALL_CASES + CT_SPLIT_CASES + CT_EDGE_CASES][::2] + WS_CASES + SMALL_CASES[1:4] + SMALL_UP_CASES[:2] + SMALL_GROUP_CASES[:3] + CT_SPLIT_CASES[:3] + CT_EDGE_CASES[:3]
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
