@@ -2141,7 +2141,13 @@ WgPlan plan_wg(const gc_conv_desc* d) {
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
     const int ctiles = gc::ceil_div(d->in_ch, pl.kt) * gc::ceil_div(d->out_ch, pl.ct);
-    int want = gc::ceil_div(GC_WG_SPLIT_TARGET, ctiles);      // one workgroup per CU is resident (512 registers per lane): two rounds
+    // one workgroup per CU is resident (512 registers per lane): two rounds -- except on the shapes wgrad_bf16x3_ws2_kernel takes (see wgrad_launch): its
+    // 16-wave workgroups run longer per strip and ONE full round of 256 measured 3..12 % faster at every channel count (same box, B = 2 / 4 / 8,
+    // profiles/wg_ab_r05.log: 512 ch @64^2 232 -> 220 us, 256 @128^2 222 -> 209, 128 @256^2 235 -> 221, 64 @512^2 251 -> 231 at B = 4); everything else
+    // is 20..50 % slower with 256
+    const bool ws2_shape = GC_WG_WS == 2 && d->down == 1 && d->kh == 3 && !pl.small && d->in_ch % 64 == 0 && d->out_ch % 64 == 0 && d->pad_x == 1 && d->pad_y == 1 &&
+                           d->out_w >= 32 && d->out_h == d->in_h && d->out_w == d->in_w && d->out_h % 16 == 0;
+    int want = gc::ceil_div(ws2_shape ? GC_WG_SPLIT_TARGET / 2 : GC_WG_SPLIT_TARGET, ctiles);
     if (want > total) want = total;
     if (want < 1) want = 1;
     pl.tiles_per_split = gc::ceil_div(total, want);

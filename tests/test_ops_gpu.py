@@ -1291,10 +1291,13 @@ def test_wgrad_samples_kernels(case, mode):
         for scales in ((si, so), (None, None), (si, None)):
             dw, dws = hip.conv2d_wgrad_samples(x, dy, scales[0], scales[1], geom)
             plain = hip.conv2d_wgrad(x, dy, scales[0], scales[1], geom)
-            assert rel_err(dw, plain) < 1e-5            # same products, the splits grouped differently
+            # same products, the splits grouped differently -- except where the batch gradient runs in exact fp32 (3 x 3 onto planes <= 8 x 8,
+            # wgrad_f32_small_kernel) while the per-sample kernels keep the mode's arithmetic: then they differ by that arithmetic's error
+            same = 1e-5 if not (k == 3 and max(oh, ow) <= 8) else tol
+            assert rel_err(dw, plain) < same
             one = torch.stack([hip.conv2d_wgrad(x[i:i + 1].contiguous(), dy[i:i + 1], None if scales[0] is None else scales[0][i:i + 1],
                                                 None if scales[1] is None else scales[1][i:i + 1], geom) for i in range(b)])
-            assert rel_err(dws, one) < 1e-5
+            assert rel_err(dws, one) < same
             assert rel_err(dws.sum(0), dw) < 1e-6
             ref = emu.conv2d_wgrad(x.double().cpu(), dy.double().cpu(), *[None if t is None else t.double().cpu() for t in scales], geom)
             assert rel_err(dw, ref) < tol
