@@ -274,8 +274,9 @@ int gc_conv2d_fused_f32(const gc_conv_desc* d, const float* x, const float* w,
                         float* y, gc_stream_t stream);
 
 /* gc_conv2d_fused_f32 with scratch memory: with gc_conv2d_f32_workspace(d) bytes (0 for most shapes) the layers whose output planes are
- * <= 16 pixels wide are split over the input channels -- one 16 / 32-channel weight slab per workgroup over every sample for planes
- * <= 8 x 8 (conv_f32_small_kernel), K slices of conv_mfma_kernel otherwise -- and a fixed-order pass adds the slices and applies
+ * <= 16 pixels wide are split over the input channels -- one 16 / 32-channel weight slab per workgroup over every sample (in groups of
+ * samples when their planes exceed the LDS) for planes <= 8 x 8 and for transposed 3x3 onto planes <= 10 x 10 (conv_f32_small_kernel),
+ * K slices of conv_mfma_kernel otherwise -- and a fixed-order pass adds the slices and applies
  * out_scale and the epilogue: same arithmetic (exact fp32), 256 workgroups instead of 8..64.  Without workspace (or with too little) it
  * is gc_conv2d_fused_f32. */
 size_t gc_conv2d_f32_workspace(const gc_conv_desc* d);
@@ -287,7 +288,8 @@ int gc_conv2d_fused_f32_ws(const gc_conv_desc* d, const float* x, const float* w
  * operand is split into bf16 hi + lo parts and a*b is formed as hi*hi + hi*lo + lo*hi with fp32
  * accumulation (~5e-6 relative error per layer, 5.3x the fp32 MFMA rate).  Inputs and outputs stay
  * fp32; `workspace` (gc_conv2d_bf16x3_workspace() bytes, 16-byte aligned) receives the split weights.
- * Shapes the fast kernel does not cover (in_ch < 16, planes <= 16 px wide) run on gc_conv2d_f32.
+ * Shapes the fast kernel does not cover (in_ch < 16, planes <= 8 px wide) run on gc_conv2d_f32.  Transposed 3x3 launches of the
+ * (2H + 1) x (2W + 1) geometry with >= 256 input channels run as an H x W main region plus an edge launch (last row and column).
  */
 size_t gc_conv2d_bf16x3_workspace(const gc_conv_desc* d);
 int gc_conv2d_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* w,
@@ -342,8 +344,9 @@ int gc_conv2d_wgrad_f32(const gc_conv_desc* d, const float* x, const float* dy,
                         const float* in_scale, const float* out_scale, float* dw,
                         void* workspace, size_t workspace_bytes, gc_stream_t stream);
 
-/* Split-bf16 variant of the weight gradient (same contract; shapes it does not cover -- down = 2, fewer than
- * 32 channels, planes <= 16 px wide -- run on gc_conv2d_wgrad_f32, so size the workspace with this function). */
+/* Split-bf16 variant of the weight gradient (same contract; shapes it does not cover -- fewer than 32 channels, planes < 4 px
+ * wide, and 3x3 gradients onto planes <= 8 x 8, which one exact-fp32 launch computes without a workspace -- run on
+ * gc_conv2d_wgrad_f32, so size the workspace with this function). */
 size_t gc_conv2d_wgrad_bf16x3_workspace(const gc_conv_desc* d);
 int gc_conv2d_wgrad_bf16x3_f32(const gc_conv_desc* d, const float* x, const float* dy,
                                const float* in_scale, const float* out_scale, float* dw,
