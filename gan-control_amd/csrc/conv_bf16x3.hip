@@ -95,6 +95,9 @@
 #ifndef GC_FRAG_PIPE
 #define GC_FRAG_PIPE 1      // conv_bf16x3_kernel (up = 1): fragment reads of the next tap issued before the MFMAs of the current one (0: the compiler's order)
 #endif
+#ifndef GC_WS_XCD
+#define GC_WS_XCD 0           // 1: XCD-aware block order of conv_bf16x3_ws_kernel (see the kernel)
+#endif
 #ifndef GC_WS_EARLY_DMA
 #define GC_WS_EARLY_DMA 1   // conv_bf16x3_ws_kernel: weight slabs requested before a finished tile's stores, counted vmcnt, raw barrier (see the multiplying waves' loop)
 #endif
@@ -681,10 +684,20 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
 
-    int bid = blockIdx.x;
+    int bid = blockIdx.x, boc = blockIdx.y;
+#if GC_WS_XCD
+    // XCD-aware order: workgroups go to the eight XCDs round-robin in linear block order, so the output-channel blocks of ONE pixel group (ids gridDim.x
+    // apart) land on different L2s -- or on the same one a whole round later -- and the patch crosses the fabric once per block.  Re-deal the ids so that
+    // the blocks of a pixel group are 8 apart: same XCD, dispatched back to back.
+    if (gridDim.y > 1 && gridDim.x % 8 == 0) {
+        const unsigned l = blockIdx.x + gridDim.x * blockIdx.y, slot = l >> 3;
+        boc = (int)(slot % gridDim.y);
+        bid = (int)((slot / gridDim.y) * 8 + (l & 7));
+    }
+#endif
     const int grp = bid % a.groups;
     const int b = bid / a.groups;
-    const int n0 = blockIdx.y * OCT;
+    const int n0 = boc * OCT;
     // The `tpb` tiles of a workgroup are `groups` apart (GC_WS_STRIDED): at any moment the 256 resident workgroups then work on ~256
     // NEIGHBOURING tiles -- a band of rows of one sample, contiguous per channel in DRAM -- instead of 256 bands spread over the batch.
     const int tiles_all = p.tiles_x * p.tiles_y;
