@@ -2160,7 +2160,14 @@ WgPlan plan_wg(const gc_conv_desc* d) {
     // is 20..50 % slower with 256
     const bool ws2_shape = GC_WG_WS == 2 && d->down == 1 && d->kh == 3 && !pl.small && d->in_ch % 64 == 0 && d->out_ch % 64 == 0 && d->pad_x == 1 && d->pad_y == 1 &&
                            d->out_w >= 32 && d->out_h == d->in_h && d->out_w == d->in_w && d->out_h % 16 == 0;
-    int want = gc::ceil_div(ws2_shape ? GC_WG_SPLIT_TARGET / 2 : GC_WG_SPLIT_TARGET, ctiles);
+    int want = gc::ceil_div(GC_WG_SPLIT_TARGET, ctiles);
+    if (ws2_shape) {
+        // ... provided that kernel really takes the launch with the halved split count (wgrad_launch: at least two 16-row strips per split);
+        // 512 -> 512 @32^2 at B = 2 does not, and the one-role kernel with half the splits is 9 % slower
+        const int half = std::max(1, std::min(gc::ceil_div(GC_WG_SPLIT_TARGET / 2, ctiles), total));
+        const int splits = gc::ceil_div(total, gc::ceil_div(total, half));
+        if ((long long)pl.tiles_x * d->batch * (d->out_h / 16) >= 2LL * splits) want = half;
+    }
     if (want > total) want = total;
     if (want < 1) want = 1;
     pl.tiles_per_split = gc::ceil_div(total, want);
