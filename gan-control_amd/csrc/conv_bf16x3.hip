@@ -2544,6 +2544,9 @@ __global__ __launch_bounds__(256, 2) void convt_fused_bf16x3_kernel(Bf16Args a) 
 #ifndef GC_CT_EDGE
 #define GC_CT_EDGE 1
 #endif
+#ifndef GC_CT_EDGE_MIN_WGS
+#define GC_CT_EDGE_MIN_WGS 512      // workgroups of the main region from which the two-launch form is used (see ct_edge_eligible)
+#endif
 __global__ __launch_bounds__(256) void convt_edge_bf16x3_kernel(Bf16Args a) {
     const ConvArgs& p = a.c;
     __shared__ float red[3][64][64];                       // [wave - 1][accumulator register][lane]
@@ -2622,22 +2625,58 @@ __global__ __launch_bounds__(256) void convt_edge_bf16x3_kernel(Bf16Args a) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ph][i][r] += red[w][(ph * 2 + i) * 16 + r][lane];
+    // Epilogue in two phases like the other kernels: every value this lane needs (out_scale / bias of its 32 channels, noise, residual) is loaded BEFORE
+    // the first store -- a load between two stores waits for every store issued so far, and as first written (loads inside the store loop) this
+    // kernel took 45 us, most of it in 64 such round trips.
     const EpilogueConsts ec = epilogue_consts(p);
     const int opitch = a.out_pitch;
+    float so_[2][16], bi_[2][16];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            so_[i][r] = p.so ? p.so[(size_t)b * p.N + n] : 1.f;
+            bi_[i][r] = p.bias ? p.bias[n] : 0.f;
+        }
+    int oy_[2], ox_[2];
+    bool ok_[2];
+    float nz_[2];
 #pragma unroll
     for (int ph = 0; ph < 2; ++ph) {
-        const int oy = col ? 2 * e + ph : 2 * H, ox = col ? 2 * W : 2 * e + ph;
-        if (oy >= p.out_h || ox >= p.out_w || (col && e >= H)) continue;
-        const float nz = p.noise ? p.noise[((size_t)b * p.out_h + oy) * p.out_w + ox] : 0.f;
+        oy_[ph] = col ? 2 * e + ph : 2 * H;
+        ox_[ph] = col ? 2 * W : 2 * e + ph;
+        ok_[ph] = oy_[ph] < p.out_h && ox_[ph] < p.out_w && !(col && e >= H);
+        nz_[ph] = (p.noise && ok_[ph]) ? p.noise[((size_t)b * p.out_h + oy_[ph]) * p.out_w + ox_[ph]] : 0.f;
+    }
+    if (p.residual) {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    const float rv = ok_[ph] ? p.residual[(((size_t)b * p.N + n) * p.out_h + oy_[ph]) * p.out_w + ox_[ph]] : 0.f;
+                    acc[ph][i][r] = conv_epilogue(ec, acc[ph][i][r], so_[i][r], bi_[i][r], nz_[ph]) + rv;
+                }
+    } else {
+#pragma unroll
+        for (int ph = 0; ph < 2; ++ph)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ph][i][r] = conv_epilogue(ec, acc[ph][i][r], so_[i][r], bi_[i][r], nz_[ph]);      // absent parts are exact no-ops (conv_common.h)
+    }
+#pragma unroll
+    for (int ph = 0; ph < 2; ++ph) {
+        if (!ok_[ph]) continue;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int n = n0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                const float so = p.so ? p.so[(size_t)b * p.N + n] : 1.f, bias = p.bias ? p.bias[n] : 0.f;
-                float v = conv_epilogue(ec, acc[ph][i][r], so, bias, nz);      // absent parts are exact no-ops (conv_common.h)
-                if (p.residual) v += p.residual[(((size_t)b * p.N + n) * p.out_h + oy) * p.out_w + ox];
-                p.y[(((size_t)b * p.N + n) * p.out_h + oy) * opitch + ox] = v;
+                p.y[(((size_t)b * p.N + n) * p.out_h + oy_[ph]) * opitch + ox_[ph]] = acc[ph][i][r];
             }
     }
 }
@@ -2653,7 +2692,7 @@ inline bool ct_edge_eligible(const Bf16Args& a) {
     const long long full = (long long)gc::ceil_div(qw, narrow ? 16 : 32) * gc::ceil_div(qh, narrow ? 8 : 4), main_ = (long long)(c.in_w / 32) * (c.in_h / 4);
     // ... and enough workgroups for two per CU: with one per CU nothing overlaps its staging (512 -> 512 @32^2, B = 4: 256 workgroups, 127 -> 137 us;
     // 512 -> 256 @64^2, B = 2: 99 -> 133 us -- against B = 8 / B = 4 of the same layers: 226 -> 175, 197 -> 162 us; profiles/convt_ab_r05.log)
-    return 10 * main_ <= 9 * full && main_ * c.B * (c.N / 64) >= 512;
+    return 10 * main_ <= 9 * full && main_ * c.B * (c.N / 64) >= GC_CT_EDGE_MIN_WGS;
 }
 
 // ---------------------------------------------------------------------------------------------------------
