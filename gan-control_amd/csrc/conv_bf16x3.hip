@@ -2577,10 +2577,12 @@ __global__ __launch_bounds__(256) void convt_edge_bf16x3_kernel(Bf16Args a) {
     for (int c = c0; c < c1; ++c) {
         const int kb = c * KCB + hi * 8;
         float vp[8], vc[8], sc[8];
+        // `prev` of a lane is `cur` of the lane before it: only the first lane of each 32-lane half loads it (a column block's loads touch one
+        // cache line per lane -- 64 line requests per instruction -- so loading both pixels everywhere doubled what the texture unit had to do)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-            vp[q] = xb[(size_t)(kb + q) * chan + prev];
             vc[q] = xb[(size_t)(kb + q) * chan + cur];
+            vp[q] = l31 == 0 ? xb[(size_t)(kb + q) * chan + prev] : 0.f;
             sc[q] = sib ? sib[kb + q] : 1.f;
         }
         uint4 wa_h[2], wa_l[2], wb_h[2], wb_l[2], wc_h[2], wc_l[2];
@@ -2592,7 +2594,11 @@ __global__ __launch_bounds__(256) void convt_edge_bf16x3_kernel(Bf16Args a) {
             wc_h[i] = a.wh[(tC * (size_t)a.kgroups + kg) * p.N + col_]; GC_LO(wc_l[i] = a.wl[(tC * (size_t)a.kgroups + kg) * p.N + col_];)
         }
 #pragma unroll
-        for (int q = 0; q < 8; ++q) { vp[q] = okp ? vp[q] : 0.f; vc[q] = okc ? vc[q] : 0.f; }
+        for (int q = 0; q < 8; ++q) {
+            vc[q] = okc ? vc[q] : 0.f;
+            const float up = __shfl_up(vc[q], 1, 32);             // (zero where the lane before is past the plane, like its own `cur`)
+            vp[q] = okp ? (l31 == 0 ? vp[q] : up) : 0.f;
+        }
         uint4 ph_, pl_, ch_, cl_;
         if (sib) { split8s<true>(vp, sc, &ph_, &pl_); split8s<true>(vc, sc, &ch_, &cl_); }
         else     { split8s<false>(vp, sc, &ph_, &pl_); split8s<false>(vc, sc, &ch_, &cl_); }
