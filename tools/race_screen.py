@@ -52,4 +52,32 @@ for (B, K, N, res, k, down) in [(4, 512, 512, 64, 3, 1), (8, 256, 256, 128, 3, 1
         print(f'wgrad {B}x{K}->{N} @{res} k{k} down{down} scales={scales[0] is not None}: {wreps} launches, {n_bad} differ from the first; finite={bool(torch.isfinite(first).all())}')
         bad += n_bad
     del x, dy
+# Round 5: the transposed layers -- split over K (partial sums + finish pass), H x W main region + edge kernel (two launches writing disjoint parts of one
+# tensor; the edge kernel adds its four channel quarters through LDS in a fixed order), the zero-stuffed small-plane form -- and the small-plane weight gradient.
+for (B, K, N, res) in [(4, 512, 512, 8), (4, 512, 512, 16), (8, 512, 512, 32), (4, 512, 256, 64), (4, 256, 128, 128), (8, 512, 512, 4)]:
+    oh = 2 * res + 1
+    g = ConvGeom(3, 3, 2, 1, 2, 2, oh, oh)
+    x = torch.randn(B, K, res, res, generator=gen).cuda(); w = torch.randn(3, 3, K, N, generator=gen).cuda()
+    si = torch.randn(B, K, generator=gen).cuda(); so = (torch.rand(B, N, generator=gen) + 0.5).cuda()
+    first = be.conv2d(x, w, si, so, g).clone()
+    n_bad = 0
+    treps = max(reps // 2, 20)
+    for i in range(treps):
+        if i % 3 == 0:
+            junk.mul_(1.0001)
+        if not torch.equal(be.conv2d(x, w, si, so, g), first):
+            n_bad += 1
+    torch.cuda.synchronize()
+    print(f'convT {B}x{K}->{N} @{res}: {treps} launches, {n_bad} differ from the first; finite={bool(torch.isfinite(first).all())}')
+    bad += n_bad
+for (B, K, N, res, down) in [(8, 512, 512, 8, 1), (4, 512, 512, 17, 2), (8, 513, 512, 4, 1)]:
+    pad = 1 if down == 1 else 0
+    oh = (res + 2 * pad - 3) // down + 1
+    g = ConvGeom(3, 3, 1, down, pad, pad, oh, oh)
+    x = torch.randn(B, K, res, res, generator=gen).cuda(); dy = torch.randn(B, N, oh, oh, generator=gen).cuda()
+    first = be.conv2d_wgrad(x, dy, None, None, g).clone()
+    n_bad = sum(0 if torch.equal(be.conv2d_wgrad(x, dy, None, None, g), first) else 1 for _ in range(max(reps // 2, 20)))
+    torch.cuda.synchronize()
+    print(f'small wgrad {B}x{K}->{N} @{res} down{down}: {max(reps // 2, 20)} launches, {n_bad} differ from the first; finite={bool(torch.isfinite(first).all())}')
+    bad += n_bad
 print('RACE SCREEN', 'FAILED' if bad else 'clean')
