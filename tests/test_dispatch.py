@@ -39,7 +39,12 @@ STEP_SHAPES = [
     ((4, 512, 512, 8, 3, 1, 1, 1), 'conv_f32_small_kernel<3,1,2,1>|up1,down1', False),
     ((4, 513, 512, 4, 3, 1, 1, 1), 'conv_f32_small_kernel<3,2,1,1>|up1,down1', False),
     # stride 2 (after the Blur: 2H + 1 -> H); 17 -> 8 at B = 8 in two sample groups of the small-plane kernel (round 5: was conv_mfma_kernel)
-    ((4, 128, 256, 257, 3, 1, 2, 0), 'conv_bf16x3_kernel<1,4,2,1>|up1,down2', False),
+    # (round 6: the layers with >= 192 eight-row tiles x samples x oc blocks on the wave-specialised E / O kernel; 128- or 64-channel output blocks)
+    ((4, 128, 256, 257, 3, 1, 2, 0), 'conv_s2ws_bf16x3_kernel<2>|up1,down2', False),
+    ((8, 32, 64, 1025, 3, 1, 2, 0), 'conv_s2ws_bf16x3_kernel<1>|up1,down2', False),
+    ((4, 256, 512, 129, 3, 1, 2, 0), 'conv_s2ws_bf16x3_kernel<2>|up1,down2', False),
+    ((8, 512, 512, 65, 3, 1, 2, 0), 'conv_bf16x3_kernel<1,4,2,1>|up1,down2', False),      # 128 workgroups of that form: one-role kernel
+    ((4, 512, 512, 65, 3, 1, 2, 0), 'conv_bf16x3_kernel<1,4,2,1>|up1,down2', True),
     ((8, 512, 512, 17, 3, 1, 2, 0), 'conv_f32_small_kernel<3,2,1,2>|up1,down2', False),
     ((4, 512, 512, 9, 3, 1, 2, 0), 'conv_f32_small_kernel<3,2,1,2>|up1,down2', False),
     # transposed: small planes on the zero-stuffed small-plane kernel / split over K; H x W main region + edge kernel only with >= 512 main-region workgroups

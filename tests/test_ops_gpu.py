@@ -471,7 +471,11 @@ CT_SPLIT_CASES = [(4, 512, 512, 8, 8, 3, 2, 1, 2), (4, 512, 128, 16, 16, 3, 2, 1
 # round 5: (2H + 1) x (2W + 1) transposed convolutions as an H x W main region + convt_edge_bf16x3_kernel (K % 16 == 0, K >= 256, N % 64 == 0, W % 32 == 0,
 # H % 4 == 0, >= 512 workgroups in the main region): square and flat planes, row-pitched outputs (out_w >= 129), uneven channel quarters (17 chunks)
 CT_EDGE_CASES = [(4, 256, 256, 64, 64, 3, 2, 1, 2), (8, 256, 256, 32, 64, 3, 2, 1, 2), (16, 272, 256, 32, 32, 3, 2, 1, 2), (4, 512, 64, 128, 128, 3, 2, 1, 2)]
-BF16_CASES = BF16_CASES + WS_CASES + TWS_CASES + SMALL_CASES + CT_SPLIT_CASES + CT_EDGE_CASES + [(400, 64, 64, 1, 1, 3, 1, 1, 1)]      # ... and past the LDS: back on the general path
+# round 6: stride-2 3x3 convolutions on the wave-specialised E / O kernel (conv_s2ws_bf16x3_kernel: pad 0, K % 16 == 0, K >= 32, N % 64 == 0, >= 192 tiles x samples
+# x oc blocks): both output-channel block widths (64 / 128), odd chunk counts, several tiles per workgroup, widths / heights that end inside a tile
+S2WS_CASES = [(1, 32, 64, 513, 513, 3, 1, 2, 0), (3, 48, 128, 257, 259, 3, 1, 2, 0), (4, 32, 64, 205, 267, 3, 1, 2, 0), (4, 64, 256, 257, 257, 3, 1, 2, 0),
+              (2, 80, 192, 223, 331, 3, 1, 2, 0)]
+BF16_CASES = BF16_CASES + WS_CASES + TWS_CASES + SMALL_CASES + CT_SPLIT_CASES + CT_EDGE_CASES + S2WS_CASES + [(400, 64, 64, 1, 1, 3, 1, 1, 1)]      # ... and past the LDS: back on the general path
 
 
 @pytest.mark.parametrize('case', BF16_CASES)
@@ -499,7 +503,10 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
     if case in SMALL_CASES:
         from gan_control_amd.utils.profiling import conv_variant
         assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_f32_small_kernel'), 'this shape is meant to reach the small-plane kernel (exact fp32 in this mode too)'
-    tws = False
+    if case in S2WS_CASES:
+        from gan_control_amd.utils.profiling import conv_variant
+        assert conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('conv_s2ws_bf16x3_kernel'), 'this shape is meant to reach the wave-specialised stride-2 kernel'
+    tws = case in S2WS_CASES       # LDS-DMA weights behind counted waits: repeated next to other traffic below
     if case in TWS_CASES:
         from gan_control_amd.utils.profiling import conv_variant
         tws = conv_variant(geom, N, b, K, 'bf16x3', (h, w)).startswith('convt_bf16x3_ws_kernel')      # only in a library built with -DGC_CTWS=1
@@ -525,7 +532,7 @@ def test_conv2d_bf16x3_kernel(case, bf16x3_mode):
             assert rel_err(out, ref) < 5e-5, ('wgrad', use_scales)
 
 
-EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3 and c not in WS_CASES + SMALL_CASES + CT_SPLIT_CASES + CT_EDGE_CASES][::2] + WS_CASES + SMALL_CASES[1:4] + SMALL_UP_CASES[:2] + SMALL_GROUP_CASES[:3] + CT_SPLIT_CASES[:3] + CT_EDGE_CASES[:3]
+EPILOGUE_CASES = [c for c in BF16_CASES if c[1] >= 3 and c not in WS_CASES + SMALL_CASES + CT_SPLIT_CASES + CT_EDGE_CASES + S2WS_CASES][::2] + WS_CASES + SMALL_CASES[1:4] + SMALL_UP_CASES[:2] + SMALL_GROUP_CASES[:3] + CT_SPLIT_CASES[:3] + CT_EDGE_CASES[:3] + S2WS_CASES[:4]
 
 
 @pytest.mark.parametrize('mode', ['f32', 'bf16x3'])
@@ -790,7 +797,7 @@ def test_row_pitched_fir_and_plane_dot(shape):
         hip.conv_mode = prev
 
 
-@pytest.mark.parametrize('case', [(2, 32, 64, 131, 133, 3), (1, 64, 64, 257, 257, 3), (2, 48, 96, 129, 161, 1)])
+@pytest.mark.parametrize('case', [(2, 32, 64, 131, 133, 3), (1, 64, 64, 257, 257, 3), (2, 48, 96, 129, 161, 1), (4, 32, 64, 257, 257, 3), (3, 32, 128, 257, 261, 3)])
 def test_stride2_kernels_read_row_pitched_input(case, bf16x3_mode):
     """The split-bf16 stride-2 convolution and its weight gradient on a row-pitched input (gc_conv_desc.in_pitch): bit-identical to the dense
     input; the transposed convolution's pitched output (gc_conv_desc.out_pitch) equals its dense values."""
