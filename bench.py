@@ -83,14 +83,47 @@ def parse(argv=None):
 RANK_ENV_FLAGS = (('rccl_algo', 'NCCL_ALGO'), ('rccl_proto', 'NCCL_PROTO'), ('bucket_mb', 'GANCONTROL_BUCKET_MB'), ('last_bucket_mb', 'GANCONTROL_LAST_BUCKET_MB'))
 
 
+def visible_gpu_count():
+    """GPUs this process would see, WITHOUT touching the HIP runtime in this process (the launcher parent must stay free to start children, and on
+    some ROCm builds torch.cuda.device_count() falls through to hipGetDeviceCount): KFD topology nodes with SIMDs, cut down by the usual visibility
+    variables; if sysfs is not readable, a short-lived child process asks torch."""
+    n = None
+    try:
+        root = '/sys/class/kfd/kfd/topology/nodes'
+        n = 0
+        for node in os.listdir(root):
+            with open(os.path.join(root, node, 'properties')) as f:
+                props = dict(line.split()[:2] for line in f if len(line.split()) >= 2)
+            n += int(props.get('simd_count', '0')) > 0
+        # a container is usually handed a subset of the host's GPUs: only the render nodes it can open count
+        import glob
+        nodes = glob.glob('/dev/dri/renderD*')
+        if nodes:
+            n = min(n, sum(os.access(d, os.R_OK | os.W_OK) for d in nodes))
+        if not os.access('/dev/kfd', os.R_OK | os.W_OK):
+            n = 0
+    except (OSError, ValueError):
+        n = None
+    if n is None:
+        r = subprocess.run([sys.executable, '-c', 'import torch; print(torch.cuda.device_count())'], capture_output=True, text=True)
+        try:
+            return int(r.stdout.strip().splitlines()[-1])
+        except (ValueError, IndexError):
+            return 0
+    for var in ('HIP_VISIBLE_DEVICES', 'ROCR_VISIBLE_DEVICES', 'CUDA_VISIBLE_DEVICES'):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(',') if t.strip() != '']))
+    return n
+
+
 def self_launch(args, argv, entry):
     """``bench.py --gpus N`` outside torch.distributed.run: start the N-rank job as a child and relay it.
 
     Runs before any GPU call or torch.cuda query of this process (re-exec'ing a process that has initialised the GPU takes
     the machine down on this pool; a child process is safe)."""
     if not _TEST_CPU['enabled']:
-        # torch.cuda.device_count() does not initialise the GPU on this image (is_available() would): safe before the child starts
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if have < args.gpus:
             print('bench.py: --gpus %d asked for, %d GPU(s) visible on this machine: not starting the %d-rank job (the ranks beyond the visible '
                   'devices would fail at set_device and leave the others waiting at the rendezvous)' % (args.gpus, have, args.gpus), file=sys.stderr)

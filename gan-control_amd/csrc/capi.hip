@@ -83,3 +83,7 @@ extern "C" int gc_struct_sizes(size_t* sizes, int n) {
     return GC_STRUCT_COUNT;
 }
 extern "C" const char* gc_last_error(void) { return gc::err_buf(); }
+#ifndef GC_SOURCE_HASH
+#define GC_SOURCE_HASH "unstamped"
+#endif
+extern "C" const char* gc_source_hash(void) { return GC_SOURCE_HASH; }

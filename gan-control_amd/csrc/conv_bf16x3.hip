@@ -698,8 +698,10 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     // reach memory -- once per tile, with only one or two items per tile at 32 / 64 input channels to hide it behind.  With the request older than
     // the stores the wait is counted: `vmcnt(S)`, S = the stores a lane issues per tile (at most 63), lets them stay in flight across the barrier.
     // The barrier is then the raw instruction (the `__syncthreads()` fence would drain the stores again).
-    constexpr bool EARLY = GC_WS_EARLY_DMA && !GC_WS_DMA_STAGER && !(GC_WS_ABL & 2);
+    constexpr bool EARLY = GC_WS_EARLY_DMA && !GC_WS_DMA_STAGER && !(GC_WS_ABL & (2 | 8));      // (the no-store ablation makes the stores conditional: no counted wait)
     constexpr int NSTORES = WOC * WPX * 16 > 63 ? 63 : WOC * WPX * 16;
+    // (the counted wait below is only right while finish_tile issues exactly WOC * WPX * 16 unconditional stores per lane AFTER the newest request,
+    //  which is why the no-store ablation GC_WS_ABL & 8 is excluded from EARLY)
     bool stored = false;             // the previous item ended a tile: its stores were issued after the newest weight request
     if (EARLY) weights(KCB < p.K ? KCB : 0, 1);                       // item 1
     for (int it = 0; it < items; ++it) {
@@ -779,6 +781,9 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
         k0_c += KCB;
         if (k0_c >= p.K) { finish_tile(tile_c); k0_c = 0; tile_c += tstep; stored = true; }
     }
+    // the slabs requested for the two items past the last one (valid rows into stages nobody reads) must have landed before the wave ends and the
+    // LDS is handed to the next workgroup: costs nothing, the wave is ending (round-5 advisor finding)
+    if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -2834,9 +2839,9 @@ __global__ __launch_bounds__(768) void convt_bf16x3_ws_kernel(Bf16Args a) {
 }
 
 template <int WOCB, int TPW>
-int launch_tws(Bf16Args a, hipStream_t s) {
+int launch_tws(Bf16Args a, hipStream_t s, bool main_only = false) {
     using C = TWCfg<WOCB, TPW>;
-    const int qh = gc::ceil_div(a.c.out_h, 2), qw = gc::ceil_div(a.c.out_w, 2);
+    const int qh = main_only ? a.c.in_h : gc::ceil_div(a.c.out_h, 2), qw = main_only ? a.c.in_w : gc::ceil_div(a.c.out_w, 2);     // main_only: the H x W region (convt_edge_bf16x3_kernel does the rest)
     a.c.tiles_y = gc::ceil_div(qh, C::TQH);
     a.c.tiles_x = gc::ceil_div(qw, TPW);
     const int tiles = a.c.tiles_x * a.c.tiles_y, ocb = a.c.N / C::OCT;
@@ -2895,7 +2900,7 @@ int launch_t(Bf16Args a, hipStream_t s, bool main_only = false) {
 int dispatch_t(const Bf16Args& a, hipStream_t s) {
     const int qw = gc::ceil_div(a.c.out_w, 2);
     const bool narrow = GC_CONVT_NARROW && gc::ceil_div(qw, 16) * 16 < gc::ceil_div(qw, 32) * 32;
-#if GC_CTWS
+#if GC_CTWS == 1
     if (tws_eligible(a)) {
         if (a.c.N % 64 != 0) return launch_tws<1, 32>(a, s);                 // 32 oc x 16 rows x 32 q-columns
         return narrow ? launch_tws<2, 16>(a, s) : launch_tws<2, 32>(a, s);    // 64 oc x (16 x 16 | 8 x 32) q-pixels
@@ -2905,6 +2910,16 @@ int dispatch_t(const Bf16Args& a, hipStream_t s) {
     // ones (64 -> 32 @512^2: 254 -> 232 us) -- worth more than the 16 columns of lanes a 513-wide q-row wastes
     if (a.c.N <= 32) return launch_t<1, 4, 2, 32>(a, s);
     if (ct_edge_eligible(a)) {
+#if GC_CTWS == 2
+        // round 6 experiment: the H x W main region on the wave-specialised kernel (its 8 x 32 q-tiles then cover the region exactly)
+        if (a.c.in_h % 8 == 0 && !(a.c.bias || a.c.noise || a.c.act || a.c.residual)) {
+            if (gc::probing()) return gc::probe_name("convt_bf16x3_ws_kernel<2,32>+edge|up2,down1,k3");
+            if (int rc = launch_tws<2, 32>(a, s, true)) return rc;
+            const dim3 grid((unsigned)(gc::ceil_div(a.c.in_w + 1, 32) + gc::ceil_div(a.c.in_h, 32)), (unsigned)(a.c.N / 64), (unsigned)a.c.B);
+            hipLaunchKernelGGL(convt_edge_bf16x3_kernel, grid, dim3(256), 0, s, a);
+            return gc::check_launch("gc_conv2d_bf16x3_f32(transposed ws, edge)");
+        }
+#endif
         if (gc::probing()) return gc::probe_name("convt_fused_bf16x3_kernel<2,2,2,32>+edge|up2,down1,k3");
         if (int rc = launch_t<2, 2, 2, 32>(a, s, true)) return rc;
         const dim3 grid((unsigned)(gc::ceil_div(a.c.in_w + 1, 32) + gc::ceil_div(a.c.in_h, 32)), (unsigned)(a.c.N / 64), (unsigned)a.c.B);

@@ -29,6 +29,12 @@
 #ifndef GC_S2WS_STAGER_PRIO
 #define GC_S2WS_STAGER_PRIO 0
 #endif
+#ifndef GC_S2WS_NT_LOAD
+#define GC_S2WS_NT_LOAD 0   // 1: non-temporal patch loads where the patch is read by ONE output-channel block (N == the block width); 2: always
+#endif
+#ifndef GC_S2WS_STRIDED
+#define GC_S2WS_STRIDED 1   // a workgroup's tiles are `groups` apart (0: consecutive)
+#endif
 #ifndef GC_S2WS_MIN_WGS
 #define GC_S2WS_MIN_WGS 192  // tiles x samples x output-channel blocks from which the kernel is used (one workgroup per CU is resident)
 #endif
@@ -75,8 +81,8 @@ __global__ __launch_bounds__(768) void conv_s2ws_bf16x3_kernel(Bf16Args a) {
     const int n0 = blockIdx.y * OCT;
     // a workgroup's tiles are `groups` apart (the resident workgroups work on neighbouring tiles of one sample: DRAM locality)
     const int tiles_all = p.tiles_x * p.tiles_y;
-    const int tstep = a.groups, tile_begin = grp;
-    const int ntiles = (tiles_all - grp + a.groups - 1) / a.groups;
+    const int tstep = GC_S2WS_STRIDED ? a.groups : 1, tile_begin = GC_S2WS_STRIDED ? grp : grp * a.tpb;
+    const int ntiles = GC_S2WS_STRIDED ? (tiles_all - grp + a.groups - 1) / a.groups : min(tiles_all, tile_begin + a.tpb) - tile_begin;
     const int nchunks = p.K / KCB;
     const int items = ntiles * nchunks;          // an item = E sub-item + O sub-item
     const int chan = p.in_h * a.in_pitch;        // floats per input channel (pitched rows: the Blur's output)
@@ -98,6 +104,7 @@ __global__ __launch_bounds__(768) void conv_s2ws_bf16x3_kernel(Bf16Args a) {
         const __amdgpu_buffer_rsrc_t rx = make_rsrc(xb, (unsigned)p.K * chan * 4u);
         // one register set per row parity: the loads of the sub-item after the next are in flight while the next one is converted and written
         uint4 pe[C::NT_E][8], po[C::NT_O][8];
+        const bool nt_loads = p.N == OCT;
         auto loads = [&](auto ph, auto& preg, int tile, int k0, bool valid) {
             constexpr int PHASE = decltype(ph)::value, ROWS = PHASE == 0 ? C::ROWS_E : C::ROWS_O, NT = PHASE == 0 ? C::NT_E : C::NT_O;
             const int iy0 = (tile / p.tiles_x) * (2 * TR) + PHASE, ix0 = (tile % p.tiles_x) * 64;
@@ -108,7 +115,13 @@ __global__ __launch_bounds__(768) void conv_s2ws_bf16x3_kernel(Bf16Args a) {
                 const bool ok = valid && t < ROWS * C::TPR;
                 const unsigned boff = ok ? (unsigned)((iy0 + 2 * row) * a.in_pitch + ix0 + 4 * g) * 4u : OOB;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) preg[j][q] = buf_load_u128(rx, boff, (unsigned)(k0 + kgl * 8 + q) * chan * 4u);
+                for (int q = 0; q < 8; ++q) {
+                    const unsigned soff = (unsigned)(k0 + kgl * 8 + q) * chan * 4u;
+                    if (GC_S2WS_NT_LOAD == 2 || (GC_S2WS_NT_LOAD == 1 && nt_loads))
+                        preg[j][q] = __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(rx, (int)boff, (int)__builtin_amdgcn_readfirstlane(soff), 2));
+                    else
+                        preg[j][q] = buf_load_u128(rx, boff, soff);
+                }
             }
         };
         auto convert = [&](auto ph, auto& preg, int k0) {
@@ -312,7 +325,7 @@ __global__ __launch_bounds__(768) void conv_s2ws_bf16x3_kernel(Bf16Args a) {
         __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
         multiply(PE{});
         __builtin_amdgcn_s_setprio(0);
-        if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTORES) : "memory");
+        if (stored && !(GC_S2WS_ABL & 8)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTORES) : "memory");
         else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0): this wave's fragment reads have returned
         __builtin_amdgcn_s_barrier();

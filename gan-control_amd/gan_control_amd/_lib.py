@@ -57,6 +57,7 @@ SIGNATURES = {
     'gc_abi_version': (_i32, []),
     'gc_last_error': (ctypes.c_char_p, []),
     'gc_struct_sizes': (_i32, [ctypes.POINTER(_sz), _i32]),
+    'gc_source_hash': (ctypes.c_char_p, []),
     'gc_upfirdn2d_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 14 + [_vp]),
     'gc_upfirdn2d_act_f32': (_i32, [_vp, _vp, _vp] + [_i32] * 11 + [_vp, _vp, _vp, _f32, _f32, _vp]),
     'gc_bias_act_f32': (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i64, _f32, _f32, _vp]),
@@ -125,19 +126,12 @@ SIGNATURES = {
 _lib = None
 
 
-def source_hash(files=('conv_bf16x3.hip', 'conv_common.h', 'common.h')):
-    """sha256 (first 16 hex digits) over the sources of the split-bf16 convolution kernels, next to the library: what a counter file
-    collected on one build is stamped with, so that it is never quoted for another (bench.py roofline.traffic, tools/pmc_mix.py)."""
-    import hashlib
-    h = hashlib.sha256()
-    root = os.path.dirname(_DEFAULT)
-    for name in files:
-        try:
-            with open(os.path.join(root, name), 'rb') as f:
-                h.update(name.encode() + b'\0' + f.read())
-        except OSError:
-            return None
-    return h.hexdigest()[:16]
+def source_hash():
+    """The hash the LOADED library was stamped with at build time (gc_source_hash: sha256 over every kernel source, header and the compiler
+    flags; alt builds of tools/build_alt.sh carry their extra flags in it): what a counter file collected on one build is tagged with, so that it
+    is never quoted for another (bench.py roofline.traffic / mfma_busy, tools/pmc_mix.py)."""
+    v = load().gc_source_hash()
+    return v.decode() if v else None
 
 
 def library_path():
@@ -182,10 +176,13 @@ class UnsupportedError(RuntimeError):
     """GC_ERR_UNSUPPORTED: a legal request outside what the kernels implement -- the one failure a caller may answer with another route."""
 
 
+GC_ERR_UNSUPPORTED = -2        # include/gancontrol_hip.h
+
+
 def check(rc, what):
     if rc != 0:
         msg = load().gc_last_error()
-        kind = UnsupportedError if rc == -2 else RuntimeError
+        kind = UnsupportedError if rc == GC_ERR_UNSUPPORTED else RuntimeError
         raise kind(f'{what} failed (code {rc}): {msg.decode() if msg else "?"}')
 
 

@@ -622,6 +622,8 @@ class HipBackend:
                     _lib.require_cuda_f32(w_t)
                     desc = _lib.ConvDesc(*fields)
                     pbytes = lib.gc_conv2d_bf16x3_packed_bytes(desc)
+                    if pbytes == 0:      # a stale recipe (the shape has no packed form under this build): per-tensor make() decides
+                        raise _lib.UnsupportedError('weight_prep_batch: descriptor %r takes no packed weights' % (tuple(fields),))
                     buf = torch.empty(pbytes // 4, dtype=torch.float32, device=dev)
                     g.desc, g.w, g.packed, g.packed_bytes = desc, w_t.data_ptr(), buf.data_ptr(), pbytes
                     outs.append(buf)
@@ -635,7 +637,8 @@ class HipBackend:
                     outs.append(out)
                 _lib.check(lib.gc_weight_sq_grouped_f32(table, len(items), _lib.stream_of(items[0][0])), 'gc_weight_sq_grouped_f32')
             else:
-                raise ValueError(kind)
+                # a kind this backend has no grouped entry for: the one answer weight_cache's refill takes as "do it per tensor" 
+                raise _lib.UnsupportedError('weight_prep_batch: no grouped form for %r' % (kind,))
         return outs
 
     def weight_sq_bwd(self, weights, grads):

@@ -44,6 +44,9 @@ const char* gc_last_error(void);
  * gc_wpack_group, gc_glin_group, gc_wsq_group.  Writes min(n, count) entries and returns count. */
 #define GC_STRUCT_COUNT 6
 int gc_struct_sizes(size_t* sizes, int n);
+/* sha256 (first 16 hex digits) over the kernel sources and build flags this library was compiled from, stamped at build time (csrc/Makefile,
+ * tools/build_alt.sh): measurements are tagged with it so that counters collected on one build are never quoted for another. */
+const char* gc_source_hash(void);
 
 /* ------------------------------------------------------------------------------------------
  * K1  upfirdn2d: zero-stuff by (up) -> pad / crop -> 2-D FIR -> decimate by (down).
