@@ -642,7 +642,8 @@ def test_headline_iteration_against_the_reference(mode):
         # measured (profiles/headline_parity_r04.json): losses <= 4e-4; per-parameter norms 1.0e-3 (f32) / 2.1e-3 (bf16x3); sampled elements 9.4e-4 / 2.2e-3 in the
         # plain passes and 4.6e-3 / 9.3e-3 in the path-length pass (elements are bounded at 2 x param_tol, double-backward passes at 3 x that)
         step_checks.check_isolated(DEV, name='step_1024_b4', tol=2e-3, param_tol=None if mode == 'f32' else 5e-3,
-                                   trainer=lambda size, batch: GeneratorTrainer(default_config(size, batch), device=DEV, seed=0))
+                                   trainer=lambda size, batch: GeneratorTrainer(default_config(size, batch), device=DEV, seed=0),
+                                   ratchet=step_checks.load_measured().get('%s/' % 'step_1024_b4' + mode))
     finally:
         hip.conv_mode = prev
         torch.cuda.empty_cache()

@@ -14,7 +14,8 @@ import step_checks  # noqa: E402
 from gan_control_amd.models.op import _backend  # noqa: E402
 from gan_control_amd.trainers.generator_trainer import GeneratorTrainer, default_config  # noqa: E402
 
-names = sys.argv[1:] or ['step_1024_b4']
+write = '--write' in sys.argv
+names = [a for a in sys.argv[1:] if a != '--write'] or ['step_1024_b4']
 out = {}
 for name in names:
     for mode in os.environ.get('PROBE_MODES', 'f32,bf16x3').split(','):
@@ -24,3 +25,9 @@ for name in names:
         out[f'{name}/{mode}'] = {k: float('%.3e' % v) for k, v in m.items() if not k.startswith('_')}
         torch.cuda.empty_cache()
 print(json.dumps(out, indent=1))
+if write:      # merge into the committed ratchet table (tests/step_checks.py::check_ratchet)
+    path = os.path.join(REPO, 'tests', 'golden', 'parity_measured.json')
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    table.update(out)
+    json.dump(table, open(path, 'w'), indent=1, sort_keys=True)
+    print('wrote', path)
