@@ -167,6 +167,7 @@ _SIMPLE = (
     ('wgrad', re.compile(r'wgrad_')),
     ('pointwise', re.compile(r'pw_(narrow|widen|wgrad)')),
     ('convt', re.compile(r'convt_')),
+    ('conv_s2', re.compile(r'conv_s2ws_')),          # the wave-specialised stride-2 kernel (conv_s2ws.hip): its template arguments carry no geometry
     ('fir', re.compile(r'fir44|firK|generic_kernel|affine_warp|reflect_pad')),
     ('bias_act', re.compile(r'bias_act|plane_dot|channel_sum|rows_sum_div')),
     ('weights', re.compile(r'weight_layout|pack_weights')),
@@ -214,13 +215,69 @@ def family_table(trainer, it, real, backend, precision, steps, KernelTimer, worl
         print('bench.py: profiler did not start (%s: %s)' % (type(e).__name__, e), file=sys.stderr)
         prof = None
     backend.timer = tally
+    # Algorithmic bytes of the memory-bound families the backend's own tallies do not cover (activation passes, plane reductions, the RGB-side
+    # kernels) and of the ATen launches: every CUDA tensor a call reads counted once, every tensor it returns counted once.  For ATen that is an
+    # ESTIMATE of what its kernels move (a dispatch-mode tally over the ops that launch kernels; views and allocations excluded).
+    extra = {'bias_act': 0.0, 'pointwise': 0.0, 'aten': 0.0}
+    HBM_METHODS = {'bias_act_bwd': 'bias_act', 'bias_act_bwd_reduce': 'bias_act', 'bias_act_bwd_reduce_adjoint': 'bias_act', 'plane_dot': 'bias_act',
+                   'channel_sum': 'bias_act', 'rows_sum_div': 'bias_act', 'pw_act_wgrad': 'pointwise', 'pw_act_dgrad': 'pointwise'}
+
+    def cuda_tensors(obj):
+        if torch.is_tensor(obj):
+            if obj.is_cuda:
+                yield obj
+        elif isinstance(obj, (tuple, list)):
+            for o in obj:
+                yield from cuda_tensors(o)
+
+    def nbytes(obj):
+        return float(sum(t.numel() * t.element_size() for t in cuda_tensors(obj)))
+
+    saved = {}
+    for meth, famname in HBM_METHODS.items():
+        fn = getattr(backend, meth, None)
+        if fn is None:
+            continue
+        saved[meth] = fn
+
+        def wrapped(*a, _fn=fn, _fam=famname, **kw):
+            res = _fn(*a, **kw)
+            extra[_fam] += nbytes(list(a) + list(kw.values())) + nbytes(res)
+            return res
+        setattr(backend, meth, wrapped)
+    # the thin 1x1 convolutions (ToRGB / FromRGB on the vector ALUs) are HBM-bound: their forward / input-gradient launches in bytes
+    from gan_control_amd.utils.profiling import conv_variant as _variant
+    conv_fn = backend.conv2d
+    saved['conv2d'] = conv_fn
+
+    def conv_wrapped(x, w_t, in_scale, out_scale, geom, *a, **kw):
+        res = conv_fn(x, w_t, in_scale, out_scale, geom, *a, **kw)
+        if _variant(geom, w_t.shape[3], x.shape[0], x.shape[1], backend.conv_mode, in_hw=(x.shape[2], x.shape[3])).startswith('pw_'):
+            extra['pointwise'] += nbytes([x, res]) + nbytes(list(a) + list(kw.values()))
+        return res
+    backend.conv2d = conv_wrapped
+    from torch.utils._python_dispatch import TorchDispatchMode
+    NO_KERNEL = ('view', 'reshape', 'empty', 'as_strided', 'expand', 'permute', 'transpose', 'detach', 'alias', 'slice', 'select', 'unsqueeze', 'squeeze',
+                 'unbind', 'split', 'chunk', 't.', 'size', 'stride', 'is_', 'lift', 'new_empty', '_unsafe_view', 'diagonal', 'unfold', 'narrow', '_local_scalar_dense', 'set_', 'resize_')
+
+    class AtenBytes(TorchDispatchMode):
+        def __torch_dispatch__(self, func, types, args=(), kwargs=None):
+            res = func(*args, **(kwargs or {}))
+            name = func.__name__
+            if not any(name.startswith(pfx) for pfx in NO_KERNEL):
+                extra['aten'] += nbytes(list(args) + list((kwargs or {}).values())) + nbytes(res)
+            return res
     try:
-        for _ in range(steps):
-            trainer.train_iteration(it, real)
-            it += 1
+        with AtenBytes():
+            for _ in range(steps):
+                trainer.train_iteration(it, real)
+                it += 1
         torch.cuda.synchronize()
     finally:
         backend.timer = None
+        for meth, fn in saved.items():
+            if meth in backend.__dict__:
+                delattr(backend, meth)
     if prof is None:
         return None, None, it
     try:
@@ -241,7 +298,12 @@ def family_table(trainer, it, real, backend, precision, steps, KernelTimer, worl
     work = {}
     for name, _, _, w in tally.records:
         f = 'wgrad' if name.startswith('wgrad') else ('bias_act' if name.startswith('bias_act') else family_of(name))
+        if f == 'pointwise':
+            continue                 # tallied in flops by the backend; its rate is stated in bytes below (thin 1x1 convolutions: HBM-bound)
         work[f] = work.get(f, 0.0) + w
+    flops_pw = sum(w for name, _, _, w in tally.records if family_of(name) == 'pointwise' and not name.startswith('wgrad'))
+    for f, b in extra.items():
+        work[f] = work.get(f, 0.0) + b
     mfma_peak = PEAK_FP32_MFMA_TFLOPS if precision == 'f32' else PEAK_BF16_MFMA_TFLOPS
     out = {}
     for f, d in sorted(fam.items(), key=lambda kv: -kv[1]['us']):
@@ -251,12 +313,14 @@ def family_table(trainer, it, real, backend, precision, steps, KernelTimer, worl
         if w and d['us'] > 0:
             if f in ('conv_s1', 'conv_s2', 'convt', 'wgrad'):
                 row.update(achieved=round(w / (d['us'] * 1e-6) / 1e12, 1), peak=mfma_peak, unit='TFLOP/s')
-            elif f in ('fir',):
+            elif f in ('fir', 'bias_act', 'pointwise', 'aten'):
                 row.update(achieved=round(w / (d['us'] * 1e-6) / 1e9, 1), peak=PEAK_HBM_GBS, unit='GB/s')
+                if f == 'aten':
+                    row['note'] = 'bytes estimated from the tensors each ATen op reads and returns (dispatch-mode tally); many of these launches are latency-bound scalars'
             if row['achieved'] is not None:
                 row['frac'] = round(row['achieved'] / row['peak'], 4)
         out[f] = row
-    conv_flops = sum(work.get(f, 0.0) for f in ('conv_s1', 'conv_s2', 'convt', 'wgrad', 'pointwise'))
+    conv_flops = sum(work.get(f, 0.0) for f in ('conv_s1', 'conv_s2', 'convt', 'wgrad')) + flops_pw
     return out, conv_flops / steps, it
 
 
@@ -594,6 +658,20 @@ def main(argv=None, entry=None):
                         out['roofline']['traffic_unit'] = 'bytes/launch'
                         out['roofline']['traffic_source'] = pmc['source'] + ' (profiles/%s)' % traffic_file
                         break
+                # MFMA-utilisation counters of the same kernel (tools/pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x launch cycles)), under the same
+                # source-hash rule as `traffic`; newest file first
+                for mf in sorted((f for f in os.listdir(os.path.join(REPO, 'profiles')) if f.startswith('pmc_r') and f.endswith('.json') and '_mfma' in f), reverse=True):
+                    pm = json.load(open(os.path.join(REPO, 'profiles', mf)))
+                    row = next((k for k in pm.get('kernels', []) if name.split('|')[0].replace(',', ', ').rstrip('>') in k.get('name_substring', '')), None)
+                    if row is None:
+                        continue
+                    if pm.get('source_hash') != _lib.source_hash():
+                        out['roofline']['mfma_busy_source'] = 'dropped: profiles/%s was collected on other kernel sources (%s, now %s); re-run tools/pmc_mfma.sh' % (mf, pm.get('source_hash'), _lib.source_hash())
+                        break
+                    out['roofline']['mfma_busy'] = round(row['mfma_busy'], 4)
+                    out['roofline']['mfma_busy_source'] = ('share of the launch in which a SIMD\'s matrix pipe executes an MFMA, %s (profiles/%s; wave time parked %.0f %%, issue-stalled %.0f %%, '
+                                                           '%.2f vector instructions per MFMA)' % (row['kernel'], mf, 100 * (row.get('wait_any_frac') or 0), 100 * (row.get('wait_inst_any_frac') or 0), row.get('valu_per_mfma') or 0))
+                    break
                 if name.startswith('conv_bf16x3_ws_kernel'):
                     out['roofline']['rocprof_names'] = ('rocprofv3 lists this kernel once per epilogue variant -- %s, <KS, WOC, CB, 0 | 1 | 2, residual> (full / scale-or-residual / none): '
                                                         'compare avg_launch_us with their launch-weighted average' % name.split('|')[0].replace('>', ', EPK, RES>'))

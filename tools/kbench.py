@@ -46,6 +46,9 @@ def main():
         convs.append(('conv3x3 s2', ic, oc, res, 3, 1, 2, 0))
     for (ic, oc, res) in [(32, 64, 1023), (128, 256, 255), (512, 512, 63)]:
         convs.append(('conv1x1 s2', ic, oc, res, 1, 1, 2, 0))
+    # the 1x1 convolutions of D's skip paths (after the FIR down-sampling) and their input gradients: HBM-bound
+    for (ic, oc, res) in [(32, 64, 512), (64, 128, 256), (128, 256, 128), (256, 512, 64), (64, 32, 512), (128, 64, 256), (256, 128, 128)]:
+        convs.append(('conv1x1 s1', ic, oc, res, 1, 1, 1, 0))
     convs.append(('conv1x1 torgb', 32, 3, 1024, 1, 1, 1, 0))
     convs.append(('conv1x1 fromrgb', 3, 32, 1024, 1, 1, 1, 0))
     for name, ic, oc, res, k, up, down, pad in convs:
