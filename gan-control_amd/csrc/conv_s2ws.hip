@@ -35,6 +35,15 @@
 #ifndef GC_S2WS_STRIDED
 #define GC_S2WS_STRIDED 1   // a workgroup's tiles are `groups` apart (0: consecutive)
 #endif
+#ifndef GC_S2WS_DEEP
+#define GC_S2WS_DEEP 0      // 1: the 64-channel variant (eight staging waves) keeps two register sets per row parity, loads two intervals ahead.  MEASURED NEUTRAL (round 6,
+                            // profiles/s2ws_deep_r06_i.log: 32 -> 64 @1025^2, B = 8, 400 vs 403 us): that layer is not bound by what the staging waves have in flight -- without any
+                            // patch staging it still takes 255 us of the ~300 us its HBM traffic needs: with two chunks per tile the four multiplying waves spend a
+                            // third of a tile in the epilogue and the 64 stores per lane, during which no MFMA issues
+#endif
+#ifndef GC_S2WS_WOCB1_MAX_K
+#define GC_S2WS_WOCB1_MAX_K 0    // input channels up to which layers with N % 128 == 0 take the 64-channel variant too (eight staging waves, the patch staged per 64 channels): 64 -> 128 @513^2 measured 8 % SLOWER on it
+#endif
 #ifndef GC_S2WS_MIN_WGS
 #define GC_S2WS_MIN_WGS 192  // tiles x samples x output-channel blocks from which the kernel is used (one workgroup per CU is resident)
 #endif
@@ -64,6 +73,7 @@ template <int WOCB, int EPK, bool RES>
 __global__ __launch_bounds__(768) void conv_s2ws_bf16x3_kernel(Bf16Args a) {
     using C = S2Cfg<WOCB>;
     constexpr int OCT = C::OCT, MW = C::MW, RP = C::RP, TR = C::TR;
+    constexpr bool DEEP = GC_S2WS_DEEP && C::NT_E == 1 && C::NT_O == 1;
     static_assert((C::STAGE_E + C::STAGE_O) * 16 + (MAX_K_BF16X3 + KCB + 2 * OCT) * 4 <= 160 * 1024, "the E and the O stage fit the 160 KiB of LDS");
     const ConvArgs& p = a.c;
     __shared__ uint4 smem[C::STAGE_E + C::STAGE_O];
@@ -163,6 +173,30 @@ __global__ __launch_bounds__(768) void conv_s2ws_bf16x3_kernel(Bf16Args a) {
         using PE = std::integral_constant<int, 0>;
         using PO = std::integral_constant<int, 1>;
         auto advance = [&](int& tile, int& k0) { k0 += KCB; if (k0 >= p.K) { k0 = 0; tile += tstep; } };
+        if constexpr (DEEP) {
+            // Eight staging waves, one task per lane and sub-item: a register set is 32 registers, so every parity keeps TWO sets and the loads of a
+            // sub-item are in flight for two intervals instead of one (the 64-channel variant serves the layers with 32 / 64 input channels: they are
+            // bound by what the staging waves have in flight, not by the matrix pipes).  Fetch order E(0) O(0) E(1) | O(1) E(2) O(2) E(3) ...
+            uint4 pe2[C::NT_E][8], po2[C::NT_O][8];
+            int tF = tile_begin, kF = 0, nFE = 0, nFO = 0;      // the E and the O fetch of an item share its (tile, chunk): one cursor, advanced after the O fetch ...
+            int tG = tile_begin, kG = 0;                        // ... but the E fetches run one item ahead of the O fetches: a cursor of their own
+            int kcE = 0, kcO = 0;                               // chunk of the next E / O sub-item to convert (its scales)
+            auto fetchE = [&](auto& set) { if (!(GC_S2WS_ABL & 1)) loads(PE{}, set, tG, kG, nFE < items); advance(tG, kG); ++nFE; };
+            auto fetchO = [&](auto& set) { if (!(GC_S2WS_ABL & 1)) loads(PO{}, set, tF, kF, nFO < items); advance(tF, kF); ++nFO; };
+            auto convE = [&](auto& set) { if (!(GC_S2WS_ABL & 1)) convert(PE{}, set, kcE); kcE += KCB; if (kcE >= p.K) kcE = 0; };
+            auto convO = [&](auto& set) { if (!(GC_S2WS_ABL & 1)) convert(PO{}, set, kcO); kcO += KCB; if (kcO >= p.K) kcO = 0; };
+            fetchE(pe); fetchO(po); fetchE(pe2);
+            convE(pe);
+            __syncthreads();
+            for (int it = 0; it < items; it += 2) {
+                fetchO(po2); convO(po);  __syncthreads();       // the multiplying waves are on E(it)
+                fetchE(pe);  convE(pe2); __syncthreads();       // ... on O(it)
+                if (it + 1 >= items) break;
+                fetchO(po);  convO(po2); __syncthreads();       // ... on E(it + 1)
+                fetchE(pe2); convE(pe);  __syncthreads();       // ... on O(it + 1)
+            }
+            return;
+        }
         int tE = tile_begin, kE = 0, tO = tile_begin, kO = 0, nE = 0, nO = 0;         // cursors of the next E / O sub-item to fetch, and their item numbers
         if (!(GC_S2WS_ABL & 1)) { loads(PE{}, pe, tE, kE, true); loads(PO{}, po, tO, kO, true); convert(PE{}, pe, kE); }
         __syncthreads();
@@ -384,13 +418,13 @@ bool s2ws_eligible(const Bf16Args& a) {
     const ConvArgs& c = a.c;
     if (a.k_per_split || c.K % KCB != 0 || c.K < 32 || c.K > MAX_K_BF16X3 || c.N % 64 != 0 || c.pad_x != 0 || c.pad_y != 0) return false;
     if (c.out_w < 32 || c.out_h < 8) return false;
-    const int oct = c.N % 128 == 0 ? 128 : 64;
+    const int oct = (c.N % 128 == 0 && c.K > GC_S2WS_WOCB1_MAX_K) ? 128 : 64;
     const long long wgs = (long long)gc::ceil_div(c.out_w, 32) * gc::ceil_div(c.out_h, 8) * c.B * (c.N / oct);
     return wgs >= GC_S2WS_MIN_WGS;
 }
 
 int launch_s2ws(Bf16Args a, hipStream_t s) {
-    return a.c.N % 128 == 0 ? launch_s2ws_t<2>(a, s) : launch_s2ws_t<1>(a, s);
+    return (a.c.N % 128 == 0 && a.c.K > GC_S2WS_WOCB1_MAX_K) ? launch_s2ws_t<2>(a, s) : launch_s2ws_t<1>(a, s);
 }
 
 }  // namespace gcconv
