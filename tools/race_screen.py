@@ -80,4 +80,31 @@ for (B, K, N, res, down) in [(8, 512, 512, 8, 1), (4, 512, 512, 17, 2), (8, 513,
     torch.cuda.synchronize()
     print(f'small wgrad {B}x{K}->{N} @{res} down{down}: {max(reps // 2, 20)} launches, {n_bad} differ from the first; finite={bool(torch.isfinite(first).all())}')
     bad += n_bad
+# Round 6: the wave-specialised stride-2 kernel (conv_s2ws.hip): LDS-DMA weight slabs behind counted vmcnt waits (a finished tile's 64 stores per lane may stay in
+# flight across the barrier), E / O half stages filled by the staging waves one sub-item ahead -- both output-block widths, full epilogue with a residual,
+# a pitched-free dense input and a ragged plane; additionally the result must equal the one-role kernel's to rounding (different summation order: not bit for bit).
+from gan_control_amd.utils.profiling import conv_variant
+for (B, K, N, res) in [(8, 128, 256, 257), (8, 32, 64, 1025), (4, 256, 512, 129), (4, 64, 128, 513), (3, 48, 192, 259)]:
+    oh = (res - 3) // 2 + 1
+    g = ConvGeom(3, 3, 1, 2, 0, 0, oh, oh)
+    assert conv_variant(g, N, B, K, 'bf16x3', (res, res)).startswith('conv_s2ws_bf16x3_kernel'), 'shape does not reach the stride-2 ws kernel'
+    x = torch.randn(B, K, res, res, generator=gen).cuda(); w = torch.randn(3, 3, K, N, generator=gen).cuda()
+    si = torch.randn(B, K, generator=gen).cuda(); so = (torch.rand(B, N, generator=gen) + 0.5).cuda()
+    bias = torch.randn(N, generator=gen).cuda(); resid = torch.randn(B, N, oh, oh, generator=gen).cuda()
+    ep = (bias, None, None, 0.2, 1.4, True, resid)
+    first = be.conv2d(x, w, si, so, g, epilogue=ep).clone()
+    ref = torch.nn.functional.conv2d((x * si[:, :, None, None]).double(), w.permute(3, 2, 0, 1).double(), stride=2) * so[:, :, None, None].double() + bias.double()[None, :, None, None]
+    ref = torch.where(ref > 0, ref, 0.2 * ref) * 1.4 + resid.double()
+    err = float((first.double() - ref).norm() / ref.norm())
+    n_bad = 0
+    sreps = max(reps // 2, 20)
+    for i in range(sreps):
+        if i % 3 == 0:
+            junk.mul_(1.0001)
+        if not torch.equal(be.conv2d(x, w, si, so, g, epilogue=ep), first):
+            n_bad += 1
+    torch.cuda.synchronize()
+    print(f'conv s2ws {B}x{K}->{N} @{res}: {sreps} launches, {n_bad} differ from the first; relative error vs float64 {err:.2e}; finite={bool(torch.isfinite(first).all())}')
+    bad += n_bad + (err > 5e-5)
+    del x, w, resid, ref
 print('RACE SCREEN', 'FAILED' if bad else 'clean')
