@@ -10,8 +10,11 @@ name=$1; extra=$2; src=${3:-$R/conv_bf16x3.hip}
 unit=$(basename "$src" .hip)
 mkdir -p $R/alt
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R -I$R/../../include -Wall -Wno-unused-result $extra -c -x hip $src -o $R/build/alt_$name.o 2> /dev/null
-objs=""
-for u in capi upfirdn2d bias_act conv conv_bf16x3 conv_s2ws weight_layout pointwise warp inception small_gemm style conv_bf16; do
+# the experiment build carries its own stamp (gc_source_hash): counters collected on it are never quoted for the in-tree library or another experiment
+stamp="alt:$name:$( (cat $src; echo "$extra") | sha256sum | cut -c1-12)"
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$R -I$R/../../include -Wall -Wno-unused-result -DGC_SOURCE_HASH="\"$stamp\"" -c $R/capi.hip -o $R/build/alt_capi_$name.o 2> /dev/null
+objs="$R/build/alt_capi_$name.o"
+for u in upfirdn2d bias_act conv conv_bf16x3 conv_s2ws weight_layout pointwise warp inception small_gemm style conv_bf16; do
     [ "$u" = "$unit" ] || objs="$objs $R/build/$u.o"
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $R/alt/libalt_$name.so $R/build/alt_$name.o $objs
