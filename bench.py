@@ -644,34 +644,41 @@ def main(argv=None, entry=None):
                 out['roofline'] = roofline_of(summ, elapsed)
                 name = out['roofline']['kernel']
                 ach, peak, split = out['roofline']['achieved'], out['roofline']['peak'], name.startswith('conv_bf16x3')
-                # separate rocprofv3 --pmc passes (tools/pmc_mix.py), launch-weighted over this kernel's shape mix; newest round first
-                for traffic_file in sorted((f for f in os.listdir(os.path.join(REPO, 'profiles')) if f.startswith('pmc_r') and f.endswith('_traffic.json')), reverse=True):
-                    pmc = json.load(open(os.path.join(REPO, 'profiles', traffic_file)))
-                    if pmc.get('kernel') == name:
-                        # the counters were collected on SOME build of the kernel: only one made from the sources this library was made
-                        # from may be quoted (the file carries the hash of the kernel's sources, tools/pmc_mix.py --parse)
-                        if pmc.get('source_hash') != _lib.source_hash():
-                            out['roofline']['traffic_source'] = ('dropped: profiles/%s was collected on other kernel sources (%s, now %s); re-run tools/pmc_mix.py'
-                                                                 % (traffic_file, pmc.get('source_hash'), _lib.source_hash()))
-                            break
-                        out['roofline']['traffic'] = pmc['traffic_bytes_per_launch']
-                        out['roofline']['traffic_unit'] = 'bytes/launch'
-                        out['roofline']['traffic_source'] = pmc['source'] + ' (profiles/%s)' % traffic_file
-                        break
-                # MFMA-utilisation counters of the same kernel (tools/pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x launch cycles)), under the same
-                # source-hash rule as `traffic`; newest file first
-                for mf in sorted((f for f in os.listdir(os.path.join(REPO, 'profiles')) if f.startswith('pmc_r') and f.endswith('.json') and '_mfma' in f), reverse=True):
-                    pm = json.load(open(os.path.join(REPO, 'profiles', mf)))
-                    row = next((k for k in pm.get('kernels', []) if name.split('|')[0].replace(',', ', ').rstrip('>') in k.get('name_substring', '')), None)
-                    if row is None:
-                        continue
-                    if pm.get('source_hash') != _lib.source_hash():
-                        out['roofline']['mfma_busy_source'] = 'dropped: profiles/%s was collected on other kernel sources (%s, now %s); re-run tools/pmc_mfma.sh' % (mf, pm.get('source_hash'), _lib.source_hash())
-                        break
+                # Counters of this kernel from separate rocprofv3 --pmc passes: HBM-side traffic (tools/pmc_mix.py, launch-weighted over its shape mix) and
+                # MFMA utilisation (tools/pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES / (SIMDs x launch cycles)).  The counters were collected on SOME build of the
+                # kernels: only a file stamped with the hash of the sources THIS library was built from (gc_source_hash) may be quoted.  Among the
+                # files of profiles/ the one with the matching hash is taken; if none matches, the newest is named as dropped.
+                prof_dir, my_hash = os.path.join(REPO, 'profiles'), _lib.source_hash()
+
+                def counter_files(suffix_test):
+                    cands = []
+                    for f in sorted((f for f in os.listdir(prof_dir) if f.startswith('pmc_r') and f.endswith('.json') and suffix_test(f)), reverse=True):
+                        try:
+                            cands.append((f, json.load(open(os.path.join(prof_dir, f)))))
+                        except (OSError, ValueError):
+                            pass
+                    return cands
+                traffic = [(f, d) for f, d in counter_files(lambda f: f.endswith('_traffic.json')) if d.get('kernel') == name]
+                hit = next(((f, d) for f, d in traffic if d.get('source_hash') == my_hash), None)
+                if hit is not None:
+                    out['roofline']['traffic'] = hit[1]['traffic_bytes_per_launch']
+                    out['roofline']['traffic_unit'] = 'bytes/launch'
+                    out['roofline']['traffic_source'] = hit[1]['source'] + ' (profiles/%s)' % hit[0]
+                elif traffic:
+                    out['roofline']['traffic_source'] = ('dropped: profiles/%s was collected on other kernel sources (%s, now %s); re-run tools/pmc_mix.py'
+                                                         % (traffic[0][0], traffic[0][1].get('source_hash'), my_hash))
+                sub = name.split('|')[0].replace(',', ', ').rstrip('>')
+                mfma = [(f, d, next((k for k in d.get('kernels', []) if sub in k.get('name_substring', '')), None)) for f, d in counter_files(lambda f: '_mfma' in f)]
+                mfma = [(f, d, row) for f, d, row in mfma if row is not None]
+                hit = next(((f, d, row) for f, d, row in mfma if d.get('source_hash') == my_hash), None)
+                if hit is not None:
+                    f, d, row = hit
                     out['roofline']['mfma_busy'] = round(row['mfma_busy'], 4)
                     out['roofline']['mfma_busy_source'] = ('share of the launch in which a SIMD\'s matrix pipe executes an MFMA, %s (profiles/%s; wave time parked %.0f %%, issue-stalled %.0f %%, '
-                                                           '%.2f vector instructions per MFMA)' % (row['kernel'], mf, 100 * (row.get('wait_any_frac') or 0), 100 * (row.get('wait_inst_any_frac') or 0), row.get('valu_per_mfma') or 0))
-                    break
+                                                           '%.2f vector instructions per MFMA)' % (row['kernel'], f, 100 * (row.get('wait_any_frac') or 0), 100 * (row.get('wait_inst_any_frac') or 0), row.get('valu_per_mfma') or 0))
+                elif mfma:
+                    out['roofline']['mfma_busy_source'] = ('dropped: profiles/%s was collected on other kernel sources (%s, now %s); re-run tools/pmc_mfma.sh'
+                                                           % (mfma[0][0], mfma[0][1].get('source_hash'), my_hash))
                 if name.startswith('conv_bf16x3_ws_kernel'):
                     out['roofline']['rocprof_names'] = ('rocprofv3 lists this kernel once per epilogue variant -- %s, <KS, WOC, CB, 0 | 1 | 2, residual> (full / scale-or-residual / none): '
                                                         'compare avg_launch_us with their launch-weighted average' % name.split('|')[0].replace('>', ', EPK, RES>'))
