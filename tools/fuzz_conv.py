@@ -52,6 +52,11 @@ for c in range(cases):
     elif kind == 'bigpw':
         k = 1; h, w_ = rng.choice([512, 515, 600]), rng.choice([512, 511, 700]); b = rng.randint(1, 2)
         K, N = rng.choice([(3, 32), (32, 3), (20, 2), (3, 33)])
+    elif kind == 's2ws':       # round 6: shapes for conv_s2ws_bf16x3_kernel (3x3, stride 2, pad 0, K % 16 == 0, N % 64 == 0, >= 192 tiles x samples x blocks)
+        k = 3; down = 2
+        h, w_ = rng.randint(130, 420), rng.randint(130, 420)
+        b = rng.randint(1, 6)
+        K, N = rng.choice([32, 48, 64, 80, 128, 256]), rng.choice([64, 128, 192, 256, 320])
     elif kind == 'ws':
         h, w_ = rng.choice([64, 65, 100, 128, 130, 150, 200, 257]), rng.choice([64, 96, 129, 132, 170, 190, 259, 262])
         b = rng.randint(2, 4)
