@@ -448,6 +448,15 @@ __global__ __launch_bounds__(256, GC_CONV_OCC(WOC, WPX, DOWN)) void conv_bf16x3_
 // RES: the launch adds a residual (gc_conv_epilogue.residual).  Compile-time as well: the residual form keeps 64 loads in flight next to the
 // accumulators, and as a run-time branch of the SAME kernel its register pressure spilled values that live across the whole kernel (34 VGPRs,
 // a -9 .. -20 % on the 64-channel layers WITHOUT a residual, same-box A/B profiles/kernel_ab_r05_b.log).
+#ifndef GC_WS_TRACE
+#define GC_WS_TRACE 0        // dev instrumentation (tools/ws_trace.py): workgroup 0 records s_memtime at the phase boundaries of its first items -- one multiplying and one staging wave
+#endif
+#if GC_WS_TRACE
+__device__ unsigned long long gc_ws_trace[2][512];      // [role][event]: (tag << 56) | time
+#define GC_TR(role, tag) do { if (tr_on && tr_n[role] < 512) { gc_ws_trace[role][tr_n[role]++] = ((unsigned long long)(tag) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); } } while (0)
+#else
+#define GC_TR(role, tag) do { } while (0)
+#endif
 template <int KS, int WOC, int CB, int EPK = 0, bool RES = false>
 __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     using C = BCfg<1, 8, WOC, 2, 1, 1, KS, CB>;      // CB = 1: 16 rows x 32 px tiles; CB = 2: 8 rows x 64 px (longer contiguous runs per row: the HBM-bound layers)
@@ -464,6 +473,10 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
 
+#if GC_WS_TRACE
+    const bool tr_on = blockIdx.x == GC_WS_TRACE - 1 && blockIdx.y == 0 && (threadIdx.x == 0 || threadIdx.x == 512);
+    int tr_n[2] = {0, 0};
+#endif
     int bid = blockIdx.x, boc = blockIdx.y;
 #if GC_WS_XCD
     // XCD-aware order: workgroups go to the eight XCDs round-robin in linear block order, so the output-channel blocks of ONE pixel group (ids gridDim.x
@@ -509,9 +522,14 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     constexpr int RPI = 64 / OCT, INSTR = ROWS / RPI;
     static_assert(ROWS % RPI == 0 && (NTAP * KG) % RPI == 0, "row groups do not straddle the hi / lo halves");
     // GC_WS_DMA_STAGER = 1: the four staging waves issue it instead (right after their patch loads, vmcnt(0) before their barrier)
-    constexpr int DMA_WAVES = GC_WS_DMA_STAGER ? 4 : 8;
+    // GC_WS_DMA_HALF (round 6): only multiplying waves 0..3 -- one per SIMD -- issue the slab.  A wave-level LDS-DMA instruction costs 100-185 cycles to issue next to
+    // fragment reads, and with all eight waves issuing their share right after the barrier BOTH waves of every SIMD were busy with it for ~750 of an item's ~8 900
+    // cycles while the matrix pipe idled (tools/ws_trace.py, profiles/ws_trace_r06_m.log); now the partner wave starts its MFMAs at once and has the pipe to itself meanwhile.
+    constexpr int DMA_WAVES = (GC_WS_DMA_STAGER || GC_WS_DMA_HALF) ? 4 : 8;
     const int dma_wave = GC_WS_DMA_STAGER ? (wave - 8) & 3 : wave;
+    const bool dma_mine = GC_WS_DMA_STAGER || wave < DMA_WAVES;          // (wave-uniform)
     auto weights = [&](int k0, int buf) {
+        if (!dma_mine) return;
         uint4* const base = smem + buf * STAGE;
 #pragma unroll
         for (int j = 0; j < (INSTR + DMA_WAVES - 1) / DMA_WAVES; ++j) {
@@ -599,15 +617,24 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
         // interval `it`: the multiplying waves work on item it; item it + 1 is converted here, item it + 2 is fetched
         for (int it = 0; it < items; it += 2) {
             int t2 = t1, k2 = k1; advance(t2, k2);
-            if (!(GC_WS_ABL & 1)) { loads(pa, t2, k2); if (GC_WS_DMA_STAGER) weights(k1, 1); convert(pb, t1, k1, 1); }
+            GC_TR(1, 1);
+            if (!(GC_WS_ABL & 1)) { loads(pa, t2, k2); GC_TR(1, 2); if (GC_WS_TRACE) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(C::NT * 8) : "memory"); GC_TR(1, 3); } if (GC_WS_DMA_STAGER) weights(k1, 1); convert(pb, t1, k1, 1); }
             if (GC_WS_DMA_STAGER) wait_staged_loads();
+            if (GC_WS_TRACE) { __builtin_amdgcn_s_waitcnt(0xC07F); GC_TR(1, 4); }
             __syncthreads();
+            GC_TR(1, 5);
             if (it + 1 >= items) break;
             t1 = t2; k1 = k2; advance(t1, k1);
-            if (!(GC_WS_ABL & 1)) { loads(pb, t1, k1); if (GC_WS_DMA_STAGER) weights(k2, 0); convert(pa, t2, k2, 0); }
+            GC_TR(1, 1);
+            if (!(GC_WS_ABL & 1)) { loads(pb, t1, k1); GC_TR(1, 2); if (GC_WS_TRACE) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(C::NT * 8) : "memory"); GC_TR(1, 3); } if (GC_WS_DMA_STAGER) weights(k2, 0); convert(pa, t2, k2, 0); }
             if (GC_WS_DMA_STAGER) wait_staged_loads();
+            if (GC_WS_TRACE) { __builtin_amdgcn_s_waitcnt(0xC07F); GC_TR(1, 4); }
             __syncthreads();
+            GC_TR(1, 5);
         }
+#if GC_WS_TRACE
+        if (tr_on) gc_ws_trace[1][511] = tr_n[1];
+#endif
         return;
     }
 
@@ -710,6 +737,7 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
         const uint4* const wl_l = wl_h + C::WUNITS;
         const uint4* const p_h = wl_l + C::WUNITS;
         const uint4* const p_l = p_h + C::PUNITS;
+        GC_TR(0, 1);
         __builtin_amdgcn_s_setprio(GC_MFMA_PRIO);
         // Fragment double buffer: the eight ds_read_b128 of tap t + 1 are issued BEFORE the twelve MFMAs of tap t (the scheduling
         // barriers pin that order; left alone the compiler sinks every read to 1-3 MFMAs before its use, far less than the LDS latency).
@@ -764,12 +792,18 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         __builtin_amdgcn_s_setprio(0);
+        GC_TR(0, 2);
         if (EARLY) {
             // the rows of item it + 1 were requested one item ago, before any store still in flight
-            if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTORES) : "memory");
-            else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            // (a wave that issued no slab rows has nothing to wait for: its stores stay in flight, the issuing waves' waits + the barrier order the slab)
+            if (dma_mine) {
+                if (stored) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NSTORES) : "memory");
+                else        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_waitcnt(0xC07F);          // lgkmcnt(0): this wave's LDS reads have returned
+            GC_TR(0, 3);
             __builtin_amdgcn_s_barrier();
+            GC_TR(0, 4);
             // item it + 2 goes into the stage item it has just left: (it + 2) chunks on from the start, modulo the chunks of a tile
             const int k2 = k0_c + 2 * KCB;
             weights(k2 < p.K ? k2 : (k2 - p.K < p.K ? k2 - p.K : 0), it & 1);
@@ -779,8 +813,11 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
         __syncthreads();             // this stage may be rewritten from the next item on; the other one is staged
         }
         k0_c += KCB;
-        if (k0_c >= p.K) { finish_tile(tile_c); k0_c = 0; tile_c += tstep; stored = true; }
+        if (k0_c >= p.K) { GC_TR(0, 5); finish_tile(tile_c); GC_TR(0, 6); k0_c = 0; tile_c += tstep; stored = true; }
     }
+#if GC_WS_TRACE
+    if (tr_on) gc_ws_trace[0][511] = tr_n[0];
+#endif
     // the slabs requested for the two items past the last one (valid rows into stages nobody reads) must have landed before the wave ends and the
     // LDS is handed to the next workgroup: costs nothing, the wave is ending (round-5 advisor finding)
     if (EARLY) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -2781,3 +2818,10 @@ extern "C" int gc_conv2d_wgrad_samples_bf16x3_f32(const gc_conv_desc* d, const f
         return gc::fail(GC_ERR_UNSUPPORTED, "gc_conv2d_wgrad_samples_bf16x3_f32: in_pitch %d: only the stride-2 kernel reads pitched rows", d->in_pitch);
     return wgrad_launch(d, x, dy, in_scale, out_scale, dw, dw_samples, workspace, workspace_bytes, (hipStream_t)stream, "gc_conv2d_wgrad_samples_bf16x3_f32");
 }
+
+#if GC_WS_TRACE && !defined(GC_SINGLE)
+// dev: copy the trace of the last conv_bf16x3_ws_kernel launches to the host (tools/ws_trace.py)
+extern "C" int gc_debug_ws_trace(unsigned long long* dst) {
+    return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(gc_ws_trace), sizeof(unsigned long long) * 2 * 512, 0, hipMemcpyDeviceToHost);
+}
+#endif

@@ -104,6 +104,12 @@
                              // convolution tests) and SLOWER -- 512 -> 512 @64^2 181 -> 216 us, 64 -> 64 @512^2 197 -> 280 (round 4, same box): 16 v_mov_b32_dpp per tap
                              // on the MULTIPLYING waves (and 20 spilled registers) cost more than the 4 ds_read_b128 they replace
 #endif
+#ifndef GC_WS_DMA_HALF
+#define GC_WS_DMA_HALF 0      // 1: the weight slab is issued by multiplying waves 0..3 only (one per SIMD), so that the partner wave has the matrix pipe meanwhile.  MEASURED NEUTRAL
+                              // (round 6, profiles/ws_dma_half_r06_n.log: every shape within +-2 %): the trace then shows the issuing wave spending 4 260 cycles on its nine LDS-DMA
+                              // instructions (470 each; 166 each when all eight waves issue 4-5) -- the instructions queue behind the staging waves' loads in the CU's one
+                              // vector-memory path, whoever issues them
+#endif
 #ifndef GC_WS_BARE
 #define GC_WS_BARE 1         // reduced epilogues (EPK 1 / 2) of the wave-specialised kernel for launches without bias / noise / activation (0: always the full epilogue)
 #endif
