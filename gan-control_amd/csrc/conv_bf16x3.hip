@@ -725,14 +725,17 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
     // reach memory -- once per tile, with only one or two items per tile at 32 / 64 input channels to hide it behind.  With the request older than
     // the stores the wait is counted: `vmcnt(S)`, S = the stores a lane issues per tile (at most 63), lets them stay in flight across the barrier.
     // The barrier is then the raw instruction (the `__syncthreads()` fence would drain the stores again).
-    constexpr bool EARLY = GC_WS_EARLY_DMA && !GC_WS_DMA_STAGER && !(GC_WS_ABL & (2 | 8));      // (the no-store ablation makes the stores conditional: no counted wait)
+    // GC_WS_DMA_MID (round 6 experiment): the slab of item it + 1 is requested INSIDE the MFMA phase of item it -- waves 0..3 in front of tap 1, waves 4..7 in front of
+    // tap 5 -- so that the two waves of a SIMD are never both busy issuing LDS-DMA instructions (the ~750 idle cycles per item of profiles/ws_trace_r06.md)
+    constexpr bool MID = GC_WS_DMA_MID && !GC_WS_DMA_STAGER && !(GC_WS_ABL & 2);
+    constexpr bool EARLY = GC_WS_EARLY_DMA && !MID && !GC_WS_DMA_STAGER && !(GC_WS_ABL & (2 | 8));      // (the no-store ablation makes the stores conditional: no counted wait)
     constexpr int NSTORES = WOC * WPX * 16 > 63 ? 63 : WOC * WPX * 16;
     // (the counted wait below is only right while finish_tile issues exactly WOC * WPX * 16 unconditional stores per lane AFTER the newest request,
     //  which is why the no-store ablation GC_WS_ABL & 8 is excluded from EARLY)
     bool stored = false;             // the previous item ended a tile: its stores were issued after the newest weight request
     if (EARLY) weights(KCB < p.K ? KCB : 0, 1);                       // item 1
     for (int it = 0; it < items; ++it) {
-        if (!EARLY && !(GC_WS_ABL & 2) && !GC_WS_DMA_STAGER) weights(k0_c + KCB < p.K ? k0_c + KCB : 0, (it + 1) & 1);          // after the last item: a valid slab into a stage nobody reads
+        if (!EARLY && !MID && !(GC_WS_ABL & 2) && !GC_WS_DMA_STAGER) weights(k0_c + KCB < p.K ? k0_c + KCB : 0, (it + 1) & 1);          // after the last item: a valid slab into a stage nobody reads
         const uint4* const wl_h = smem + (it & 1) * STAGE;
         const uint4* const wl_l = wl_h + C::WUNITS;
         const uint4* const p_h = wl_l + C::WUNITS;
@@ -784,6 +787,9 @@ __global__ __launch_bounds__(768) void conv_bf16x3_ws_kernel(Bf16Args a) {
 #pragma unroll
         for (int t = 0; t < NTAP; ++t) {
             if (t + 1 < NTAP && !(GC_WS_ABL & 4)) load_tap(t + 1, (t + 1) & 1);
+            if (MID && (NTAP == 1 || t == 1 || t == 5)) {
+                if (NTAP == 1 || (t == 1) == (wave < 4)) weights(k0_c + KCB < p.K ? k0_c + KCB : 0, (it + 1) & 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int i = 0; i < WOC; ++i)

@@ -110,6 +110,10 @@
                               // instructions (470 each; 166 each when all eight waves issue 4-5) -- the instructions queue behind the staging waves' loads in the CU's one
                               // vector-memory path, whoever issues them
 #endif
+#ifndef GC_WS_DMA_MID
+#define GC_WS_DMA_MID 0       // 1: weight slab of the next item requested inside the MFMA phase, staggered by wave group (see the multiplying waves' loop).  MEASURED neutral at >= 128
+                              // channels and 3-5 % SLOWER at 32 / 64 (round 6, profiles/ws_dma_mid_r06_n2.log): where the slab is requested does not matter
+#endif
 #ifndef GC_WS_BARE
 #define GC_WS_BARE 1         // reduced epilogues (EPK 1 / 2) of the wave-specialised kernel for launches without bias / noise / activation (0: always the full epilogue)
 #endif
