@@ -1478,9 +1478,12 @@ __global__ __launch_bounds__(1024) void wgrad_bf16x3_ws2_kernel(WgArgs p, int ba
 // staged DE-INTERLEAVED: units of 8 even columns and units of 8 odd columns, so tap tx = 0 reads an even unit,
 // tx = 1 an odd unit and tx = 2 the even units funnel-shifted by one pixel -- every ds_read_b128 stays aligned.
 
-template <int TR, int KS, int WK>
+template <int TR, int KS, int WK, int WN = 2>
 struct WgS2Cfg {
-    static constexpr int KT = 32 * WK, NTL = 64;       // WK = 2: 64k x 64n, one 32 x 32 block per wave; WK = 1: 32k x 64n, two pixel-waves per block
+    // WK = 2: 64k x 64n, one 32 x 32 block per wave; WK = 1: 32k x 64n, two pixel-waves per block; WK = 1, WN = 4 (round 6): 32k x 128n, one block per wave --
+    // the X tile (at stride 2 four times the pixels of the dY tile, and de-interleaved while staged) is then shared by four output-channel blocks instead of two:
+    // 29 % fewer operand bytes and conversions per MFMA than the 64k x 64n tile
+    static constexpr int KT = 32 * WK, NTL = 32 * WN;
     static constexpr int PH = (TR - 1) * 2 + KS;
     static constexpr int XE = KS == 3 ? 5 : 4, XO = KS == 3 ? 4 : 0, RU = XE + XO, YU = 4;
     static constexpr int NI = XE;                                    // 16-column staging items per row
@@ -1495,10 +1498,11 @@ struct WgS2Cfg {
 // staging phases of the first; every input row is fetched 3 instead of 2.5 times, from L2 since tiles run down a column strip),
 // or 32k x 64n tiles of two rows for 32..63 input channels.  A two-row 64k x 64n tile needs 110 KB -- one workgroup per CU --
 // and measured 130 against 171 TFLOP/s on 64 -> 128 channels at 513^2.
-template <int TR, int KS, int WK>
+template <int TR, int KS, int WK, int WN = 2>
 __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x3_s2_kernel(WgArgs p) {
-    using C = WgS2Cfg<TR, KS, WK>;
-    constexpr int WP = 2 / WK;              // waves sharing a (k, n) block: they split the half-rows and are summed at the end
+    using C = WgS2Cfg<TR, KS, WK, WN>;
+    static_assert(WK * WN == 4 || WK * WN == 2, "four waves: WK x WN blocks, two pixel-waves per block when there are only two blocks");
+    constexpr int WP = 4 / (WK * WN);       // waves sharing a (k, n) block: they split the half-rows and are summed at the end
     constexpr int KT = C::KT, NTL = C::NTL, PH = C::PH, XE = C::XE, RU = C::RU, YU = C::YU, NI = C::NI, NT = C::NT;
     __shared__ uint4 smem[C::SMEM_UNITS];
     uint4* xh = smem;
@@ -1508,7 +1512,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, hi = lane >> 5;
-    const int wn = wave & 1, wk = WK == 2 ? wave >> 1 : 0, wp = WK == 2 ? 0 : wave >> 1;
+    const int wn = wave % WN, wk = (wave / WN) % WK, wp = wave / (WN * WK);
     const WgBlock blk = wg_block<GC_WG_XCD != 0>();      // stride 2: +3..10 % (same-box A/B)
     const int k0 = blk.x * KT, n0 = blk.y * NTL, split = blk.z;
 
@@ -1549,7 +1553,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
     };
     // 64k x 64n: the descriptors stay in registers (6 of them); 32k x 64n has two more staged items per lane and no register to
     // spare -- it rebuilds them from the lane index per use (measured: keeping them there costs scratch reloads in front of the loads)
-    constexpr bool KEEP = WK == 2;
+    constexpr bool KEEP = WK * WN == 4;
     unsigned xdesc[KEEP ? C::NPX : 1], ydesc[KEEP ? C::NPY : 1];
     if (KEEP) {
 #pragma unroll
@@ -1580,7 +1584,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
         for (int j = 0; j < C::NPY; ++j) {
             const unsigned d = yd(j);
             const int r = (int)((d >> 20) & 15u);
-            const int lin = (int)((d >> 24) & 63u) * (ychan * 4) + r * (p.out_w * 4) + (int)((d >> 16) & 15u) * 32 + yoff;
+            const int lin = (int)((d >> 24) & 127u) * (ychan * 4) + r * (p.out_w * 4) + (int)((d >> 16) & 15u) * 32 + yoff;      // (dY channel: bits 24..30, up to 128 per tile)
             const unsigned off = ((int)d >= 0 && oy0 + r < p.out_h) ? (unsigned)lin : OUTSIDE;
             yreg[j][0] = __builtin_bit_cast(float4, WG_LOAD1(false, ry, off, 0));
             yreg[j][1] = __builtin_bit_cast(float4, WG_LOAD1(false, ry, off, 16));
@@ -1629,7 +1633,7 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
             for (int j = 0; j < C::NPY; ++j) {
                 const unsigned d = yd(j);
                 const int col0 = ox0 + 8 * (int)((d >> 16) & 15u);
-                const float sc = SC ? s_scale[KT + ((d >> 24) & 63u)] : 1.f;
+                const float sc = SC ? s_scale[KT + ((d >> 24) & 127u)] : 1.f;
                 float v[8] = {yreg[j][0].x, yreg[j][0].y, yreg[j][0].z, yreg[j][0].w, yreg[j][1].x, yreg[j][1].y, yreg[j][1].z, yreg[j][1].w};
                 const int room = p.out_w - col0;
 #pragma unroll
@@ -1731,6 +1735,9 @@ __global__ __launch_bounds__(256, (TR == 1 || WK == 1) ? 2 : 1) void wgrad_bf16x
 }
 
 struct WgPlan { int small, ct, kt, tr, splits, tiles_per_split, tiles_x, tiles_y; };
+#ifndef GC_WG_S2_N128
+#define GC_WG_S2_N128 1      // stride-2 weight gradients with N % 128 == 0 and K % 32 == 0 (K >= 64) on 32k x 128n tiles (wgrad_bf16x3_s2_kernel<1, KS, 1, 4>); 0: 64k x 64n
+#endif
 #ifndef GC_WG_SPLIT_TARGET
 #define GC_WG_SPLIT_TARGET 512      // workgroups a weight-gradient launch aims for (pixel splits x channel tiles)
 #endif
@@ -1745,7 +1752,9 @@ WgPlan plan_wg(const gc_conv_desc* d) {
     // (round 3: THREE rows for the 64 x 64 tiles -- 162 MFMAs per wave between barriers, 78 KB of LDS, still two workgroups per CU -- measured
     // 15-26 % SLOWER: 64 -> 64 @512^2, B = 8: 557 -> 748 us; 512 -> 512 @64^2: 470 -> 543 us: the two extra staging register sets spill 108 bytes per lane)
     pl.tr = pl.small ? 6 : 2;          // 32 x 32 channel tiles: six rows (81 MFMAs per wave between barriers, 65 KB of LDS; four rows: 923 vs 880 us at 32 -> 32 @1024^2)
-    if (d->down == 2 && pl.kt == 64) pl.tr = 1;     // stride 2, 64k x 64n: one output row per tile keeps two workgroups per CU (two-row tiles need 110 KB of LDS: 130 vs 171 TFLOP/s)     // stride 2, small planes: one output row per tile, two workgroups per CU
+    if (d->down == 2 && pl.kt == 64) pl.tr = 1;
+    // round 6: 32k x 128n tiles at stride 2 where both channel counts allow it (GC_WG_S2_N128): the X tile is shared by four output-channel blocks
+    if (GC_WG_S2_N128 && d->down == 2 && d->in_ch >= 64 && d->in_ch % 32 == 0 && d->out_ch % 128 == 0) { pl.kt = 32; pl.ct = 128; pl.tr = 1; }     // stride 2, 64k x 64n: one output row per tile keeps two workgroups per CU (two-row tiles need 110 KB of LDS: 130 vs 171 TFLOP/s)     // stride 2, small planes: one output row per tile, two workgroups per CU
     pl.tiles_x = gc::ceil_div(d->out_w, 32);
     pl.tiles_y = gc::ceil_div(d->out_h, pl.tr);
     const int total = pl.tiles_x * pl.tiles_y * d->batch;
@@ -2758,7 +2767,11 @@ int wgrad_launch(const gc_conv_desc* d, const float* x, const float* dy, const f
     }
 #endif
     if (d->down == 2) {
-        if (pl.kt == 32) {
+        if (pl.ct == 128) {
+            if (gc::probing()) return gc::probe_name("wgrad_bf16x3_s2_kernel<1,%d,1,4>", d->kh);
+            if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 3, 1, 4>), grid, dim3(256), 0, s, a);
+            else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<1, 1, 1, 4>), grid, dim3(256), 0, s, a);
+        } else if (pl.kt == 32) {
             if (d->kh == 3) hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 3, 1>), grid, dim3(256), 0, s, a);
             else            hipLaunchKernelGGL((wgrad_bf16x3_s2_kernel<2, 1, 1>), grid, dim3(256), 0, s, a);
         } else if (pl.tr == 1) {

@@ -51,7 +51,9 @@ _managed = {}    # id(tensor) -> weakref: roots with a known invalidation channe
 _derived = {}    # data_ptr of a cached tensor -> (id(root), key)
 _group_of = {}   # id(root) -> group id (parameters registered together as one module)
 _group_members = {}   # group id -> [weakref(root)]
-_recipes = {}    # id(root) -> {key: recipe}: every derived form ever asked of this root and how to make it (survives invalidation)
+_recipes = {}    # id(root) -> [weakref(root), {key: recipe}]: every derived form ever asked of this root and how to make it (survives invalidation).  The weak
+                 # reference pins the OWNER: Python re-uses the id of a dead tensor, and a parameter of a later network must not inherit the recipes (shapes!) of
+                 # an unrelated dead one (round 6: `shape '[6, 5, 3, 3]' is invalid for input of size 1` in a long test session)
 _warned = set()  # kinds of batched refill already reported as unsupported
 stats = {'hit': 0, 'miss': 0, 'bypass': 0, 'batched': 0, 'batch_failed': 0}
 batch_runner = None   # set by op/_backend.py: () -> callable(kind, items) -> [tensor] of the active backend, or None
@@ -104,6 +106,20 @@ def _ensure_entry(root):
     return entry
 
 
+def _recipes_of(root, create=False):
+    """The recipe table of THIS tensor (not of a dead one whose id it re-uses)."""
+    rid = id(root)
+    ent = _recipes.get(rid)
+    if ent is not None and ent[0]() is not root:
+        _recipes.pop(rid, None)
+        ent = None
+    if ent is None:
+        if not create or root is None:
+            return {}
+        ent = _recipes[rid] = [weakref.ref(root), {}]
+    return ent[1]
+
+
 def _forget(rid):
     _drop(rid)
     _recipes.pop(rid, None)
@@ -125,7 +141,7 @@ def _refill_group(gid):
         if m is None or m() is not root:
             continue
         bucket = _ensure_entry(root)[2]
-        for key, recipe in _recipes.get(id(root), {}).items():
+        for key, recipe in _recipes_of(root).items():
             if key not in bucket:
                 todo.append((len(key), id(root), root, key, recipe))
     if len(todo) < 2:
@@ -190,8 +206,12 @@ def derive(src, op, make, recipe=None):
     if out is None and recipe is not None:
         if callable(recipe):             # built on a miss only: the hot path (a hit) pays nothing for it
             recipe = recipe()
-        _recipes.setdefault(rid, {})[key] = recipe
+        owner = _roots[rid][0]()
+        _recipes_of(owner, create=True)[key] = recipe
         gid = _group_of.get(rid)
+        if gid is not None and not any(ref() is owner for ref in _group_members.get(gid, ())):
+            _group_of.pop(rid, None)         # a stale mapping of a dead tensor whose id this one re-uses
+            gid = None
         if BATCHED and gid is not None:
             _refill_group(gid)
             bucket = _roots[rid][2]

@@ -245,3 +245,22 @@ def test_scale_grads_from_sample_wgrad(level, emu_backend):
 
 def test_torgb_fork(emu_backend):
     oc.check_torgb_fork('cpu', size=32, batch=2, tol=1e-10, dtype=torch.float64)
+
+
+def test_weight_cache_recipes_do_not_outlive_their_tensor():
+    """Python re-uses the id of a dead tensor: a later parameter must not inherit the remembered derived forms (with their shapes) of an unrelated dead one
+    (round 6: a long test session hit `shape '[6, 5, 3, 3]' is invalid for input of size 1` inside the batched refill)."""
+    import weakref
+    import torch
+    from gan_control_amd.models.op import weight_cache as wc
+    dead = torch.nn.Parameter(torch.zeros(6, 5, 3, 3))
+    live = torch.nn.Parameter(torch.zeros(1))
+    stale = [weakref.ref(dead), {('layout',): ('layout', 9, 5, 6)}]
+    wc._recipes[id(live)] = stale                      # what an id collision leaves behind
+    try:
+        assert wc._recipes_of(live) == {} and id(live) not in wc._recipes
+        mine = wc._recipes_of(live, create=True)
+        mine[('wsq',)] = ('wsq',)
+        assert wc._recipes_of(live) == {('wsq',): ('wsq',)} and wc._recipes[id(live)][0]() is live
+    finally:
+        wc._recipes.pop(id(live), None)

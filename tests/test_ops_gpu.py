@@ -798,7 +798,7 @@ def test_row_pitched_fir_and_plane_dot(shape):
         hip.conv_mode = prev
 
 
-@pytest.mark.parametrize('case', [(2, 32, 64, 131, 133, 3), (1, 64, 64, 257, 257, 3), (2, 48, 96, 129, 161, 1), (4, 32, 64, 257, 257, 3), (3, 32, 128, 257, 261, 3)])
+@pytest.mark.parametrize('case', [(2, 32, 64, 131, 133, 3), (1, 64, 64, 257, 257, 3), (2, 48, 96, 129, 161, 1), (4, 32, 64, 257, 257, 3), (3, 32, 128, 257, 261, 3), (2, 64, 128, 131, 197, 3), (2, 96, 256, 67, 131, 1)])
 def test_stride2_kernels_read_row_pitched_input(case, bf16x3_mode):
     """The split-bf16 stride-2 convolution and its weight gradient on a row-pitched input (gc_conv_desc.in_pitch): bit-identical to the dense
     input; the transposed convolution's pitched output (gc_conv_desc.out_pitch) equals its dense values."""
@@ -827,7 +827,10 @@ def test_stride2_kernels_read_row_pitched_input(case, bf16x3_mode):
             dense = hip.conv2d(dy, wa, so, si, tg)
         finally:
             be_mod._PITCHED_OUTPUT = keep
-        assert dense.is_contiguous() and torch.equal(out, dense)
+        # (a transposed layer on a small plane is split over its input channels only in the dense form -- the finish pass writes dense rows --, and the
+        #  two forms then add the channel slices in different orders: equal to rounding there, bit for bit everywhere else)
+        split = _lib.load().gc_conv2d_bf16x3_splitk_bytes(hip._desc(dy, K, tg)) > 0
+        assert dense.is_contiguous() and (rel_err(out, dense) < 1e-5 if split else torch.equal(out, dense))
         if (2 * ow + 1) >= 129:
             assert _lib.row_pitch(out) % 32 == 0 and _lib.row_pitch(out) >= 2 * ow + 1
 
